@@ -1,0 +1,464 @@
+// chad_oracle.cpp -- TEST INFRASTRUCTURE ONLY (the parity checker and the CPU baseline).
+//
+// A single-threaded CPU restatement of the reference's chad::TSDFMap::insert() path, written from
+// the behaviour of /root/reference (M2-TE/chad_tsdf @ 2025-07-25).  Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load this library; the product (libchad_hip.so) never does.
+//
+// PARITY UNPINNED: upstream ships no tests, fixtures or golden vectors for this path,
+// and the reference cannot be built in this image (its CMake fetches glm 1.0.1, gtl v1.2.0,
+// libmorton v0.2.12 and fmt 11.2.0 from the network; none is vendored or installed).  The third-party
+// pieces on the path are restated from their published definitions:
+//   * libmorton v0.2.12 morton3D_64_encode(x,y,z): x -> bits 0,3,6,.., y -> bits 1,4,7,.., z -> bits 2,5,8,..,
+//     21 bits per axis (BMI2 pdep masks 0x1249249249249249 / <<1 / <<2);
+//   * glm 1.0.1 generic (non-SIMD) vec3 code: dot(a,b) = a.x*b.x + a.y*b.y + a.z*b.z (left to right),
+//     normalize(v) = v * (1 / sqrt(dot(v,v))), distance = sqrt(dot(d,d)), floor/abs/sign component-wise;
+//   * gtl::flat_hash_map only affects speed (results depend on insertion order, not on the hash).
+// The only external anchors are the scalar summaries SURVEY.md section 8(c) G7 records from a reference run
+// (distinct voxels, sum of weights, block count); tests/test_oracle_survey_pins.py checks them.
+//
+// Arithmetic is strict IEEE (build with -ffp-contract=off, no -ffast-math) so that voxel sets are
+// well defined; upstream's default -ffast-math never was.
+//
+// Deviations from the reference, all where the reference has undefined behaviour:
+//   D1 (Q3) normals.hpp:100-101 reads one element past the end while grouping the last sorted point;
+//      here that comparison counts as a mismatch, so the last point always gets the fallback normal.
+//   D2 (Q5) a point equal to the sensor position, or with a non-finite coordinate, makes
+//      octree.hpp:92-97 convert NaN to int; such points are dropped before Morton encoding.
+//   D3 (Q2) std::sort leaves the order of equal codes unspecified (morton.hpp:89); here ties are
+//      ordered by ascending input index, which is one of the orders std::sort may produce.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cfloat>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+#if defined(__BMI2__)
+#include <immintrin.h>
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Morton code: morton.hpp:21-37 over libmorton's 3D 64-bit interleave.
+inline uint64_t spread21(uint64_t v) {
+    v &= 0x1fffffULL;
+    v = (v | (v << 32)) & 0x001f00000000ffffULL;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffULL;
+    v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+    v = (v | (v << 2)) & 0x1249249249249249ULL;
+    return v;
+}
+inline uint32_t compact21(uint64_t v) {
+    v &= 0x1249249249249249ULL;
+    v = (v | (v >> 2)) & 0x10c30c30c30c30c3ULL;
+    v = (v | (v >> 4)) & 0x100f00f00f00f00fULL;
+    v = (v | (v >> 8)) & 0x001f0000ff0000ffULL;
+    v = (v | (v >> 16)) & 0x001f00000000ffffULL;
+    v = (v | (v >> 32)) & 0x1fffffULL;
+    return uint32_t(v);
+}
+#if defined(__BMI2__)
+inline uint64_t morton_encode(int32_t vx, int32_t vy, int32_t vz) {
+    // morton.hpp:24-27: bias by 2^20 in uint32 arithmetic, then keep 21 bits per axis
+    uint32_t x = (1u << 20) + uint32_t(vx), y = (1u << 20) + uint32_t(vy), z = (1u << 20) + uint32_t(vz);
+    return _pdep_u64(x, 0x1249249249249249ULL) | _pdep_u64(y, 0x2492492492492492ULL) | _pdep_u64(z, 0x4924924924924924ULL);
+}
+inline void morton_decode(uint64_t mc, int32_t& vx, int32_t& vy, int32_t& vz) {
+    // morton.hpp:30-36
+    vx = int32_t(uint32_t(_pext_u64(mc, 0x1249249249249249ULL)) - (1u << 20));
+    vy = int32_t(uint32_t(_pext_u64(mc, 0x2492492492492492ULL)) - (1u << 20));
+    vz = int32_t(uint32_t(_pext_u64(mc, 0x4924924924924924ULL)) - (1u << 20));
+}
+#else
+inline uint64_t morton_encode(int32_t vx, int32_t vy, int32_t vz) {
+    uint32_t x = (1u << 20) + uint32_t(vx), y = (1u << 20) + uint32_t(vy), z = (1u << 20) + uint32_t(vz);
+    return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2);
+}
+inline void morton_decode(uint64_t mc, int32_t& vx, int32_t& vy, int32_t& vz) {
+    vx = int32_t(compact21(mc) - (1u << 20));
+    vy = int32_t(compact21(mc >> 1) - (1u << 20));
+    vz = int32_t(compact21(mc >> 2) - (1u << 20));
+}
+#endif
+
+struct V3 { float x, y, z; };
+struct D3 { double x, y, z; };
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 normalize(V3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
+inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// morton.hpp:58 -- pair<vec3, MortonCode> is 24 bytes with 4 bytes of padding; the padding carries the
+// input index here so that the tie order (D3) can be made deterministic at no extra memory traffic.
+struct PointMc { V3 p; uint32_t idx; uint64_t mc; };
+static_assert(sizeof(PointMc) == 24, "same footprint as the reference's sort element");
+
+inline bool finite3(const float* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
+// morton.hpp:59-80
+void calc_morton_vector(const float* xyz, size_t n, const float pos[3], float sdf_res, std::vector<PointMc>& out) {
+    const float recip = float(1.0 / double(sdf_res));  // morton.hpp:63
+    out.clear();
+    out.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        const float* p = xyz + 3 * i;
+        if (!finite3(p) || (p[0] == pos[0] && p[1] == pos[1] && p[2] == pos[2])) continue;  // D2
+        float fx = std::floor(p[0] * recip), fy = std::floor(p[1] * recip), fz = std::floor(p[2] * recip);  // :71
+        out.push_back({{p[0], p[1], p[2]}, uint32_t(i), morton_encode(int32_t(fx), int32_t(fy), int32_t(fz))});  // :73
+    }
+}
+
+// morton.hpp:81-102 (descending; ties by input index, D3)
+void sort_morton_vector(std::vector<PointMc>& v, std::vector<V3>& sorted_points) {
+    std::sort(v.begin(), v.end(), [](const PointMc& a, const PointMc& b) {
+        return a.mc > b.mc || (a.mc == b.mc && a.idx < b.idx);
+    });
+    sorted_points.clear();
+    sorted_points.reserve(v.size());
+    for (const auto& e : v) sorted_points.push_back(e.p);
+}
+
+// normals.hpp:10-80 ("plane from points 2")
+V3 estimate_normal(const PointMc* beg, const PointMc* end) {
+    D3 c{0, 0, 0};
+    for (const PointMc* it = beg; it != end; ++it) { c.x += double(it->p.x); c.y += double(it->p.y); c.z += double(it->p.z); }
+    const double recip = 1.0 / double(end - beg);
+    c.x *= recip; c.y *= recip; c.z *= recip;
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (const PointMc* it = beg; it != end; ++it) {
+        double rx = double(it->p.x) - c.x, ry = double(it->p.y) - c.y, rz = double(it->p.z) - c.z;
+        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+    }
+    xx *= recip; xy *= recip; xz *= recip; yy *= recip; yz *= recip; zz *= recip;
+    D3 wd{0, 0, 0};
+    auto accumulate = [&wd](D3 axis, double det) {
+        double weight = det * det;
+        if (dot(wd, axis) < 0.0) weight = -weight;
+        wd.x += axis.x * weight; wd.y += axis.y * weight; wd.z += axis.z * weight;
+    };
+    { double det = yy * zz - yz * yz; accumulate({det, xz * yz - xy * zz, xy * yz - xz * yy}, det); }  // :42-52
+    { double det = xx * zz - xz * xz; accumulate({xz * yz - xy * zz, det, xy * xz - yz * xx}, det); }  // :54-64
+    { double det = xx * yy - xy * xy; accumulate({xy * yz - xz * yy, xy * xz - yz * xx, det}, det); }  // :66-76
+    const double inv = 1.0 / std::sqrt(dot(wd, wd));  // glm::normalize(dvec3)
+    return {float(wd.x * inv), float(wd.y * inv), float(wd.z * inv)};  // :79
+}
+
+// normals.hpp:81-148.  group_start (optional) gets 1 at the first element of every neighbourhood.
+void estimate_normals(const std::vector<PointMc>& v, V3 pos, std::vector<V3>& normals, uint8_t* group_start) {
+    const size_t n = v.size();
+    normals.resize(n);
+    constexpr size_t min_points = 8;  // :88
+    for (size_t i = 0; i < n;) {
+        size_t end = i + 1;
+        for (unsigned depth = 0; depth < 3; depth++) {  // :94
+            const uint64_t mask = ~uint64_t(0) << (depth * 3);
+            const uint64_t key = v[i].mc & mask;
+            // :100 -- the guard stops one short of the last element; at end == n the reference reads out of
+            // bounds (D1): treated as a mismatch.
+            while (end != n - 1 && end < n) {
+                if ((v[end].mc & mask) == key) end++;
+                else break;
+            }
+            if (end - i >= min_points) break;
+        }
+        const size_t size = end - i;
+        if (group_start) group_start[i] = 1;
+        if (size >= min_points) {
+            V3 nrm = estimate_normal(&v[i], &v[end]);
+            if (dot(nrm, normalize(pos - v[i].p)) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};  // :117-118
+            for (size_t j = i; j < end; j++) normals[j] = nrm;
+        } else {
+            for (size_t j = i; j < end; j++) normals[j] = normalize(pos - v[j].p);  // :127-134
+        }
+        i += size;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// octree.hpp:86-152 -- voxel traversal of the segment [p - trunc*dir, p + trunc*dir].
+struct I3 { int32_t x, y, z; };
+inline int32_t isign(int32_t v) { return (v > 0) - (v < 0); }
+
+template <class Emit>
+inline void walk_ray(V3 p, V3 pos, float res, float res_recip, float trunc, Emit&& emit) {
+    const V3 dir = normalize(p - pos);                                     // :92
+    const V3 dir_recip{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};           // :93
+    const V3 start = p - dir * trunc, fin = p + dir * trunc;                // :94-95
+    const I3 v0{int32_t(std::floor(start.x * res_recip)), int32_t(std::floor(start.y * res_recip)), int32_t(std::floor(start.z * res_recip))};
+    const I3 v1{int32_t(std::floor(fin.x * res_recip)), int32_t(std::floor(fin.y * res_recip)), int32_t(std::floor(fin.z * res_recip))};
+    const I3 step{isign(v1.x - v0.x), isign(v1.y - v0.y), isign(v1.z - v0.z)};  // :100
+    const V3 delta{std::fabs(res * dir_recip.x), std::fabs(res * dir_recip.y), std::fabs(res * dir_recip.z)};  // :102
+    V3 tmax;
+    auto boundary = [&](int32_t s, float st) {  // :106-116
+        if (s < 0) return res * std::floor(st * res_recip);
+        if (s > 0) return res * std::ceil(st * res_recip);
+        return std::numeric_limits<float>::max();
+    };
+    tmax.x = boundary(step.x, start.x); tmax.y = boundary(step.y, start.y); tmax.z = boundary(step.z, start.z);
+    tmax = tmax - start;                                                                   // :117
+    tmax = {std::fabs(tmax.x * dir_recip.x), std::fabs(tmax.y * dir_recip.y), std::fabs(tmax.z * dir_recip.z)};  // :118
+    I3 cur = v0;
+    emit(cur);  // :122
+    for (;;) {  // :125-152
+        if (tmax.x < tmax.y) {
+            if (tmax.x < tmax.z) { cur.x += step.x; tmax.x += delta.x; if (cur.x == v1.x + step.x) break; }
+            else                 { cur.z += step.z; tmax.z += delta.z; if (cur.z == v1.z + step.z) break; }
+        } else {
+            if (tmax.y < tmax.z) { cur.y += step.y; tmax.y += delta.y; if (cur.y == v1.y + step.y) break; }
+            else                 { cur.z += step.z; tmax.z += delta.z; if (cur.z == v1.z + step.z) break; }
+        }
+        emit(cur);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// octree.hpp:12-78 -- pointer octree of depth 20 + leaves, with a hash shortcut at 4x4x4-voxel granularity.
+struct Leaf { float sd; uint32_t w; };
+struct Node { uint32_t child[8]; };
+
+struct BlockLookup {  // stands in for gtl::flat_hash_map<MortonCode, Node*> (octree.hpp:187)
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> vals;
+    size_t mask = 0, count = 0;
+    static constexpr uint64_t EMPTY = ~uint64_t(0);
+    BlockLookup() { rehash(1 << 12); }
+    void rehash(size_t cap) {
+        std::vector<uint64_t> ok; ok.swap(keys);
+        std::vector<uint32_t> ov; ov.swap(vals);
+        keys.assign(cap, EMPTY); vals.assign(cap, 0); mask = cap - 1; count = 0;
+        for (size_t i = 0; i < ok.size(); i++) if (ok[i] != EMPTY) *find_or_insert(ok[i]).first = ov[i], void();
+    }
+    static inline size_t hash(uint64_t k) { k >>= 6; k *= 0x9E3779B97F4A7C15ULL; return size_t(k >> 20); }
+    // returns (value slot, inserted)
+    std::pair<uint32_t*, bool> find_or_insert(uint64_t key) {
+        size_t i = hash(key) & mask;
+        for (;; i = (i + 1) & mask) {
+            if (keys[i] == key) return {&vals[i], false};
+            if (keys[i] == EMPTY) {
+                if ((count + 1) * 2 > mask + 1) { rehash((mask + 1) * 2); return find_or_insert(key); }
+                keys[i] = key; count++;
+                return {&vals[i], true};
+            }
+        }
+    }
+    void clear() { std::fill(keys.begin(), keys.end(), EMPTY); count = 0; }
+};
+
+struct Octree {
+    std::vector<Node> nodes;
+    std::vector<Leaf> leaves;
+    std::vector<uint64_t> leaf_mc;  // oracle-only: the code of each leaf, for export without a tree walk
+    BlockLookup lookup;
+    Octree() { clear(); }
+    void clear() {  // octree.hpp:22-29
+        lookup.clear();
+        nodes.clear(); leaves.clear(); leaf_mc.clear();
+        nodes.push_back(Node{});
+        leaves.push_back(Leaf{0.0f, 0});
+        leaf_mc.push_back(0);
+    }
+    Leaf& find_or_create(uint64_t mc) {  // octree.hpp:31-78
+        constexpr uint32_t lookup_depth = 18;
+        constexpr uint64_t lookup_mask = 0xffffffffffffffc0ULL;  // :33-35
+        auto [val, inserted] = lookup.find_or_insert(mc & lookup_mask);
+        uint32_t depth = 0, node = 0;
+        if (!inserted) { depth = lookup_depth + 1; node = *val; }
+        while (depth < 20) {
+            const uint64_t shift = uint64_t(20 - depth) * 3;
+            const uint32_t ci = uint32_t(mc >> shift) & 7u;
+            uint32_t child = nodes[node].child[ci];
+            if (child == 0) {
+                child = uint32_t(nodes.size());
+                nodes.push_back(Node{});
+                nodes[node].child[ci] = child;
+                if (inserted && depth == lookup_depth) *val = child;  // :57-59 (cache the depth-19 node)
+            }
+            node = child;
+            depth++;
+        }
+        const uint32_t li = uint32_t(mc) & 7u;
+        uint32_t leaf = nodes[node].child[li];
+        if (leaf == 0) {
+            leaf = uint32_t(leaves.size());
+            leaves.push_back(Leaf{0.0f, 0});
+            leaf_mc.push_back(mc);
+            nodes[node].child[li] = leaf;
+        }
+        return leaves[leaf];
+    }
+};
+
+struct Snapshot {  // a closed submap's leaves, sorted by code (stands in for the out-of-scope DAG)
+    std::vector<uint64_t> mc; std::vector<float> sd; std::vector<uint32_t> w;
+};
+
+struct Map {
+    float res, trunc;
+    Octree oct;
+    std::vector<V3> positions;        // submap.hpp:110 (active submap)
+    std::vector<Snapshot> closed;     // tsdf.cpp:54 (_submaps)
+    // scratch reused across frames
+    std::vector<PointMc> pmc; std::vector<V3> sorted, normals; std::vector<uint64_t> walked;
+    // last-frame stats
+    double ms_calc = 0, ms_sort = 0, ms_norm = 0, ms_upd = 0, ms_total = 0;
+    uint64_t updates = 0, frames = 0;
+};
+
+void snapshot(const Octree& o, Snapshot& s) {
+    const size_t n = o.leaves.size() - 1;
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = uint32_t(i + 1);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return o.leaf_mc[a] < o.leaf_mc[b]; });
+    s.mc.resize(n); s.sd.resize(n); s.w.resize(n);
+    for (size_t i = 0; i < n; i++) { s.mc[i] = o.leaf_mc[order[i]]; s.sd[i] = o.leaves[order[i]].sd; s.w[i] = o.leaves[order[i]].w; }
+}
+
+inline double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// octree.hpp:80-170
+void octree_insert(Map& m, V3 pos) {
+    const float res = m.res, trunc = m.trunc;
+    const float res_recip = float(1.0 / double(res));  // :82
+    uint64_t updates = 0;
+    for (size_t i = 0; i < m.sorted.size(); i++) {
+        const V3 p = m.sorted[i], nrm = m.normals[i];
+        m.walked.clear();
+        walk_ray(p, pos, res, res_recip, trunc, [&](I3 v) { m.walked.push_back(morton_encode(v.x, v.y, v.z)); });
+        for (uint64_t mc : m.walked) {  // :153-164
+            Leaf& leaf = m.oct.find_or_create(mc);
+            int32_t vx, vy, vz;
+            morton_decode(mc, vx, vy, vz);
+            const V3 p2v{float(vx) * res - p.x, float(vy) * res - p.y, float(vz) * res - p.z};  // :157 (voxel corner)
+            float d = dot(nrm, p2v);
+            d = std::min(std::max(d, -trunc), trunc);  // std::clamp, :159
+            leaf.sd = leaf.sd * float(leaf.w) + d;     // :161
+            leaf.w++;
+            leaf.sd = leaf.sd / float(leaf.w);         // :163
+        }
+        updates += m.walked.size();
+    }
+    m.updates = updates;
+}
+
+// tsdf.cpp:39-75
+void map_insert(Map& m, const float* xyz, size_t n, const float position[3]) {
+    auto t_total = std::chrono::steady_clock::now();
+    const V3 pos{position[0], position[1], position[2]};
+    if (m.positions.empty()) m.positions.push_back(pos);  // :48
+    else {
+        const V3 d = pos - m.positions.front();
+        if (std::sqrt(dot(d, d)) > 5.0f) {  // :52
+            m.closed.emplace_back();
+            snapshot(m.oct, m.closed.back());  // stands in for Submap::finalize, :53-54
+            m.positions.clear();
+            m.positions.push_back(pos);        // :55-56
+            m.oct.clear();                     // :57
+        } else m.positions.push_back(pos);     // :60
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    calc_morton_vector(xyz, n, position, m.res, m.pmc);  // :64
+    m.ms_calc = ms_since(t0); t0 = std::chrono::steady_clock::now();
+    sort_morton_vector(m.pmc, m.sorted);                 // :65
+    m.ms_sort = ms_since(t0); t0 = std::chrono::steady_clock::now();
+    estimate_normals(m.pmc, pos, m.normals, nullptr);    // :67
+    m.ms_norm = ms_since(t0); t0 = std::chrono::steady_clock::now();
+    octree_insert(m, pos);                               // :70
+    m.ms_upd = ms_since(t0);
+    m.ms_total = ms_since(t_total);
+    m.frames++;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C entry points (loaded with ctypes by tests/ and bench.py's cpu_baseline leg)
+extern "C" {
+
+void* oracle_map_create(float res, float trunc) { Map* m = new Map(); m->res = res; m->trunc = trunc; return m; }
+void oracle_map_destroy(void* h) { delete static_cast<Map*>(h); }
+void oracle_map_insert(void* h, const float* xyz, size_t n, const float* pos3) { map_insert(*static_cast<Map*>(h), xyz, n, pos3); }
+// empties the active submap without archiving it (what a fresh TSDFMap would hold)
+void oracle_map_reset(void* h) { Map* m = static_cast<Map*>(h); m->oct.clear(); m->positions.clear(); m->closed.clear(); }
+size_t oracle_map_closed_count(void* h) { return static_cast<Map*>(h)->closed.size(); }
+
+// submap < 0: the active octree; otherwise the submap closed at that roll-over.  Leaves sorted by code, ascending.
+size_t oracle_map_leaf_count(void* h, int submap) {
+    Map* m = static_cast<Map*>(h);
+    if (submap < 0) return m->oct.leaves.size() - 1;
+    return size_t(submap) < m->closed.size() ? m->closed[size_t(submap)].mc.size() : 0;
+}
+size_t oracle_map_export_leaves(void* h, int submap, uint64_t* mc, float* sd, uint32_t* w, size_t cap) {
+    Map* m = static_cast<Map*>(h);
+    Snapshot tmp;
+    const Snapshot* s;
+    if (submap < 0) { snapshot(m->oct, tmp); s = &tmp; }
+    else if (size_t(submap) < m->closed.size()) s = &m->closed[size_t(submap)];
+    else return 0;
+    const size_t n = std::min(cap, s->mc.size());
+    std::memcpy(mc, s->mc.data(), n * 8); std::memcpy(sd, s->sd.data(), n * 4); std::memcpy(w, s->w.data(), n * 4);
+    return s->mc.size();
+}
+// out[0..9]: ms calc, sort, normals, update, total; updates U, leaves V, hash entries B, octree nodes, frames
+void oracle_map_stats(void* h, double* out) {
+    Map* m = static_cast<Map*>(h);
+    out[0] = m->ms_calc; out[1] = m->ms_sort; out[2] = m->ms_norm; out[3] = m->ms_upd; out[4] = m->ms_total;
+    out[5] = double(m->updates); out[6] = double(m->oct.leaves.size() - 1); out[7] = double(m->oct.lookup.count);
+    out[8] = double(m->oct.nodes.size()); out[9] = double(m->frames);
+}
+
+// ---- stage-level entry points for unit parity tests ----
+// morton.hpp:21-28,59-80: codes of n points (no D2 filtering: callers pass valid points)
+void oracle_morton_codes(const float* xyz, size_t n, float res, uint64_t* out) {
+    const float recip = float(1.0 / double(res));
+    for (size_t i = 0; i < n; i++)
+        out[i] = morton_encode(int32_t(std::floor(xyz[3 * i] * recip)), int32_t(std::floor(xyz[3 * i + 1] * recip)), int32_t(std::floor(xyz[3 * i + 2] * recip)));
+}
+void oracle_morton_encode_ivec(const int32_t* v, size_t n, uint64_t* out) { for (size_t i = 0; i < n; i++) out[i] = morton_encode(v[3 * i], v[3 * i + 1], v[3 * i + 2]); }
+void oracle_morton_decode_ivec(const uint64_t* mc, size_t n, int32_t* v) { for (size_t i = 0; i < n; i++) morton_decode(mc[i], v[3 * i], v[3 * i + 1], v[3 * i + 2]); }
+// portable (non-BMI2) interleave, to cross-check the pdep/pext path against the published bit layout
+uint64_t oracle_morton_encode_portable(int32_t vx, int32_t vy, int32_t vz) {
+    uint32_t x = (1u << 20) + uint32_t(vx), y = (1u << 20) + uint32_t(vy), z = (1u << 20) + uint32_t(vz);
+    return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2);
+}
+
+// Stages a4+a5+a6 on one frame: writes the sorted order (input indices), sorted codes, normals per sorted
+// index and the group-start flags.  Returns the number of points kept (D2).
+size_t oracle_frame_normals(const float* xyz, size_t n, const float* pos3, float res,
+                            uint32_t* order, uint64_t* mc_sorted, float* normals, uint8_t* group_start) {
+    std::vector<PointMc> pmc; std::vector<V3> sorted, nrm;
+    calc_morton_vector(xyz, n, pos3, res, pmc);
+    sort_morton_vector(pmc, sorted);
+    std::vector<uint8_t> gs(pmc.size(), 0);
+    estimate_normals(pmc, V3{pos3[0], pos3[1], pos3[2]}, nrm, gs.data());
+    for (size_t i = 0; i < pmc.size(); i++) {
+        if (order) order[i] = pmc[i].idx;
+        if (mc_sorted) mc_sorted[i] = pmc[i].mc;
+        if (normals) { normals[3 * i] = nrm[i].x; normals[3 * i + 1] = nrm[i].y; normals[3 * i + 2] = nrm[i].z; }
+        if (group_start) group_start[i] = gs[i];
+    }
+    return pmc.size();
+}
+
+// a8: voxel list of one ray; returns the count (writes at most cap voxels)
+size_t oracle_walk_ray(const float* p3, const float* pos3, float res, float trunc, int32_t* voxels, size_t cap) {
+    size_t k = 0;
+    walk_ray(V3{p3[0], p3[1], p3[2]}, V3{pos3[0], pos3[1], pos3[2]}, res, float(1.0 / double(res)), trunc, [&](I3 v) {
+        if (k < cap) { voxels[3 * k] = v.x; voxels[3 * k + 1] = v.y; voxels[3 * k + 2] = v.z; }
+        k++;
+    });
+    return k;
+}
+// a8 for a batch: counts[i] voxels of ray i written at voxels[(i*stride + j)*3]
+void oracle_walk_rays(const float* xyz, size_t n, const float* pos3, float res, float trunc, int32_t* voxels, uint32_t* counts, size_t stride) {
+    for (size_t i = 0; i < n; i++) counts[i] = uint32_t(oracle_walk_ray(xyz + 3 * i, pos3, res, trunc, voxels + 3 * i * stride, stride));
+}
+
+}  // extern "C"
