@@ -1,0 +1,31 @@
+# Builds the product library (HIP, gfx950 only) and the test oracle.  No cmake: hipcc and g++ directly.
+#   make            -> chad_tsdf_amd/lib/libchad_hip.so  +  oracle/_build/libchad_oracle.so
+# -ffp-contract=off on host AND device: voxel traversal must round like the reference's strict-IEEE CPU build.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result
+CSRC := chad_tsdf_amd/csrc
+LIB := chad_tsdf_amd/lib/libchad_hip.so
+HDRS := $(wildcard $(CSRC)/*.hpp) include/chad_hip.h include/chad/tsdf.hpp
+
+all: $(LIB) oracle
+
+$(LIB): $(CSRC)/chad_hip.hip $(CSRC)/tsdf_shim.cpp $(HDRS)
+	@mkdir -p chad_tsdf_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -Iinclude -o $@ $(CSRC)/chad_hip.hip -x hip $(CSRC)/tsdf_shim.cpp
+
+oracle:
+	$(MAKE) -C oracle -s
+
+# C++ demo in the shape of the reference's src/chad/main.cpp (links the drop-in class)
+demo: $(LIB) examples/sphere_demo.cpp
+	$(HIPCC) -O2 -std=c++17 -Iinclude -o examples/sphere_demo examples/sphere_demo.cpp -Lchad_tsdf_amd/lib -lchad_hip -Wl,-rpath,'$$ORIGIN/../chad_tsdf_amd/lib'
+
+asm: $(CSRC)/chad_hip.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -Iinclude --cuda-device-only -S -o build/chad_hip.s $(CSRC)/chad_hip.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true
+
+clean:
+	rm -rf chad_tsdf_amd/lib/*.so build examples/sphere_demo
+	$(MAKE) -C oracle clean
+.PHONY: all oracle demo asm clean

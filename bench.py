@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config: inserted points/sec on the 1 M-point room scan
+(cfg2: voxel 0.05 m, trunc 0.10 m), one process per GPU.
+
+A step = chad::TSDFMap::insert() of one 1 M-point synthetic scan into an EMPTY map on this rank's GPU
+(map.reset() + map.insert(), both inside the timed region), with the scan already resident in HBM.  With N > 1
+ranks every rank inserts its own scans (frames dealt round-robin: weak scaling) and the ranks' submaps are merged
+once at the end of the timed region with the RCCL exchange of chad_tsdf_amd/sharded.py (all_gather of block keys
++ all_reduce of the per-block partial sums), which is the path's only collective.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      the TSDF-update kernel against the HBM roofline: algorithmic bytes (24 B/point + 16 B/distinct voxel,
+                SURVEY.md section 8(d)) / its mean duration, measured with HIP events on the map's stream inside the
+                timed region;
+  cpu_baseline  the oracle (CPU restatement of the reference, single-threaded like the reference) on the same
+                workload, timed on this host for a bounded number of frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000, help="points per scan (BASELINE config: 1 M)")
+    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic scans cycled through per rank")
+    ap.add_argument("--update-mode", type=int, default=0, help="0 default, 1 scatter, 2 LDS-tiled")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from chad_tsdf_amd import TSDFMap, synth
+    from chad_tsdf_amd.sharded import merge_blocks
+
+    res, trunc = synth.CFG2["res"], synth.CFG2["trunc"]
+    # scans of the cfg2 room from slightly different sensor poses / seeds; frame f of the job belongs to rank f % world
+    scans = []
+    for j in range(args.frames):
+        f = j * world + rank
+        sensor = (0.3 + 0.01 * f, -0.2, 0.1)
+        pts, pos = synth.cfg2_frame(args.points, seed=synth.CFG2["seed"] + f, sensor=sensor)
+        scans.append((torch.from_numpy(pts).cuda(), pos, pts))
+    torch.cuda.synchronize()
+
+    m = TSDFMap(res, trunc, timing=True, update_mode=args.update_mode, max_points=args.points)
+
+    def step(i):
+        d_pts, pos, _ = scans[i % len(scans)]
+        m.reset()
+        m.insert(d_pts, pos)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    m.sync()
+    if world > 1:  # warm the collective path once as well
+        merge_blocks(*m.export_blocks(-1))
+    m.stats()  # drop the warm-up's stage timings
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        merged_keys, merged_sum, merged_cnt = merge_blocks(*m.export_blocks(-1))
+    m.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = m.stats()  # mean stage times over the timed steps (HIP events on the map's stream)
+    mc, sd, w = m.export_leaves()  # of the last step's map: V for the roofline's algorithmic bytes
+    n_voxels = int(len(mc))
+    algo_bytes = 24 * args.points + 16 * n_voxels  # K7 = 24 B/point + 16 B/distinct voxel
+    upd_ms = float(st["ms_oct_upd"])
+    achieved = algo_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")  # written from a separate rocprofv3 --pmc run
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "inserted points/sec",
+        "value": world * args.steps * args.points / elapsed,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "cfg2: single 1M-point synthetic room scan (10x8x3 m box), voxel 0.05 m, trunc 0.10 m, inserted into an empty map each step",
+            "points_per_frame": args.points,
+            "frames_per_step_per_gpu": 1,
+            "parallelism": f"frames round-robin over {world} GPU(s); one RCCL block-partial merge per timed region" if world > 1 else "1 GPU",
+            "update_kernel": {0: "tiled", 1: "scatter", 2: "tiled"}[args.update_mode],
+        },
+        "stage_ms": {k: round(float(st[k]), 4) for k in ("ms_mc_calc", "ms_mc_sort", "ms_norm_est", "ms_oct_upd", "ms_total")},
+        "frame": {"updates": int(st["updates"]), "voxels": n_voxels, "blocks": int(st["blocks"]), "sort_passes": int(st["sort_passes"]),
+                  "hash_load": round(st["blocks"] / max(1, st["hash_capacity"]), 5)},
+        "roofline": {
+            "kernel": "k_update_tiled" if args.update_mode != 1 else "k_update_scatter",
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "kernel_ms": round(upd_ms, 4),
+        },
+    }
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from oracle import pyoracle  # CPU baseline leg only: the checker, timed -- never on the product path
+
+        o = pyoracle.OracleMap(res, trunc)
+        frames, t_cpu = 0, 0.0
+        stage = np.zeros(5)
+        while t_cpu < args.cpu_seconds and frames < 200:
+            _, pos, pts = scans[frames % len(scans)]
+            t1 = time.perf_counter()
+            o.reset()
+            o.insert(pts, pos)
+            t_cpu += time.perf_counter() - t1
+            s = o.stats()
+            stage += np.array([s["ms_calc"], s["ms_sort"], s["ms_norm"], s["ms_upd"], s["ms_total"]])
+            frames += 1
+        cpu_model = ""
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            pass
+        out["cpu_baseline"] = {
+            "value": frames * args.points / t_cpu,
+            "unit": "points/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{frames} of the same 1M-point cfg2 scans, reset + insert each, {t_cpu:.1f} s on 1 of {os.cpu_count()} cores ({cpu_model}); "
+                      "the reference is single-threaded (no threads anywhere; par_unseq commented out at morton.hpp:88)",
+            "ms_per_frame": round(t_cpu / frames * 1e3, 2),
+            "stage_ms": dict(zip(("mc_calc", "mc_sort", "norm_est", "oct_upd", "total"), (stage / frames).round(2).tolist())),
+        }
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+
+    if rank == 0:
+        print(json.dumps(out))
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

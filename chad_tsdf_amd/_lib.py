@@ -1,0 +1,104 @@
+"""ctypes binding of chad_tsdf_amd/lib/libchad_hip.so (the C ABI of include/chad_hip.h).
+
+There is no fallback: if the library is missing or cannot be loaded, importing the binding raises.
+`import torch` happens first on purpose -- PyTorch ships its own libamdhip64.so.7, and loading it first makes
+the dynamic linker resolve our library's HIP dependency to the same runtime, so device pointers, streams and
+torch tensors are interchangeable in one process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libchad_hip.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_CAPACITY, ERR_HIP = range(6)
+FLAG_VERBOSE, FLAG_TIMING = 1, 2
+UPDATE_DEFAULT, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
+
+
+class ChadError(RuntimeError):
+    def __init__(self, status: int, where: str, message: str):
+        super().__init__(f"{where}: {message} (chad_status {status})")
+        self.status = status
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("max_blocks", C.c_uint64),
+        ("max_points", C.c_uint64),
+        ("stream", C.c_void_p),
+        ("flags", C.c_uint32),
+        ("update_mode", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint64),
+        ("points_in", C.c_uint64),
+        ("points_used", C.c_uint64),
+        ("updates", C.c_uint64),
+        ("blocks", C.c_uint64),
+        ("block_capacity", C.c_uint64),
+        ("hash_capacity", C.c_uint64),
+        ("closed_submaps", C.c_uint64),
+        ("sort_passes", C.c_uint32),
+        ("overflow", C.c_uint32),
+        ("ms_mc_calc", C.c_float),
+        ("ms_mc_sort", C.c_float),
+        ("ms_norm_est", C.c_float),
+        ("ms_oct_upd", C.c_float),
+        ("ms_total", C.c_float),
+    ]
+
+
+# every symbol include/chad_hip.h declares: name -> (restype, argtypes)
+_vp, _sz, _i32, _f32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_float
+SYMBOLS = {
+    "chad_map_create": (_i32, [_f32, _f32, C.POINTER(Options), C.POINTER(_vp)]),
+    "chad_map_destroy": (None, [_vp]),
+    "chad_map_insert": (_i32, [_vp, _vp, _sz, _vp]),
+    "chad_map_insert_device": (_i32, [_vp, _vp, _sz, _vp]),
+    "chad_map_sync": (_i32, [_vp]),
+    "chad_map_reset": (_i32, [_vp]),
+    "chad_map_close_submap": (_i32, [_vp]),
+    "chad_map_leaf_count": (_i32, [_vp, _i32, C.POINTER(_sz)]),
+    "chad_map_export_leaves": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "chad_map_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "chad_map_block_count": (_i32, [_vp, _i32, C.POINTER(_sz)]),
+    "chad_map_export_blocks_device": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
+    "chad_map_close_submap_with_blocks_device": (_i32, [_vp, _vp, _vp, _vp, _sz]),
+    "chad_map_last_frame": (_i32, [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "chad_walk_rays": (_i32, [_vp, _sz, _vp, _f32, _f32, _vp, _vp, _sz]),
+    "chad_morton_codes": (_i32, [_vp, _sz, _f32, _vp]),
+    "chad_last_error": (C.c_char_p, []),
+    "chad_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libchad_hip.so (once).  Raises ImportError with the build hint if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); there is no CPU fallback")
+        import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, see module docstring)
+
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, where: str):
+    if status != OK:
+        raise ChadError(status, where, load().chad_last_error().decode(errors="replace"))

@@ -1,0 +1,588 @@
+// chad_hip.hip -- host side of the C ABI in include/chad_hip.h: owns the device-resident map, applies the
+// reference's submap roll-over rule (tsdf.cpp:46-61) and enqueues the per-frame kernel pipeline
+// (tsdf.cpp:64-70: calc_morton_vector -> sort_morton_vector -> estimate_normals -> Octree::insert).
+// There is no CPU fallback: without a HIP device every entry point fails with CHAD_ERR_NO_DEVICE.
+#include "../../include/chad_hip.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "frame_kernels.hpp"
+#include "map_kernels.hpp"
+#include "radix_sort.hpp"
+#include "tile_update.hpp"
+
+using namespace chadhip;
+
+namespace {
+
+thread_local std::string g_error;
+
+chad_status fail(chad_status code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            (void)hipGetLastError();                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY                                     \
+                        : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorNoBinaryForGpu || e_ == hipErrorInsufficientDriver) ? CHAD_ERR_NO_DEVICE \
+                                                                                                               : CHAD_ERR_HIP,                                             \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                    \
+        }                                                                                                      \
+    } while (0)
+
+#define TRY(expr)                          \
+    do {                                   \
+        chad_status s_ = (expr);           \
+        if (s_ != CHAD_OK) return s_;      \
+    } while (0)
+
+struct Submap {  // a closed submap: dense copies of its bricks (stands in for the reference's DAG, out of scope)
+    uint64_t* keys = nullptr;
+    float* sum = nullptr;
+    uint32_t* cnt = nullptr;
+    uint32_t blocks = 0;
+};
+
+enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
+
+}  // namespace
+
+struct chad_map {
+    float res = 0, trunc = 0, recip = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t flags = 0, update_mode = CHAD_UPDATE_TILED;
+
+    MapView view{};
+    uint32_t hash_capacity = 0, brick_capacity = 0;
+    FrameHeader* d_hdr = nullptr;
+    FrameHeader* h_hdr = nullptr;  // pinned
+    FramePartial* d_part = nullptr;  // kFrameBlocks partial reductions of the frame kernels
+
+    size_t cap_points = 0;
+    float* d_xyz = nullptr;  // staging for host inserts
+    RadixSortBuffers sort{};
+    float4* d_pts = nullptr;
+    uint64_t* d_codes = nullptr;
+    float4* d_normals = nullptr;
+    uint32_t* d_seg = nullptr;
+
+    std::vector<std::array<float, 3>> positions;  // poses of the active submap (submap.hpp:110)
+    std::vector<Submap> closed;                   // tsdf.cpp:54
+    uint64_t frames = 0, last_points_in = 0;
+    // stage timing (CHAD_FLAG_TIMING): a ring of event sets, one per insert, read back lazily by chad_map_stats so
+    // that timing adds no synchronisation to insert()
+    static constexpr int kTimingRing = 64;
+    hipEvent_t ev[kTimingRing][T_COUNT] = {};
+    uint64_t timed_begin = 0, timed_end = 0;  // inserts [timed_begin, timed_end) have unread event sets
+    float ms[T_COUNT] = {};                   // mean stage times over the inserts read at the last stats call
+};
+
+namespace {
+
+struct DeviceGuard {  // entry points run on the map's device and restore the caller's
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess)) ok = true;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+inline dim3 grid_for(size_t n, int threads = 256, int max_blocks = 2048) {
+    size_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > size_t(max_blocks)) b = max_blocks;
+    return dim3(unsigned(b));
+}
+
+void free_frame_buffers(chad_map* m) {
+    (void)hipFree(m->d_xyz); (void)hipFree(m->sort.keys[0]); (void)hipFree(m->sort.keys[1]);
+    (void)hipFree(m->sort.idx[0]); (void)hipFree(m->sort.idx[1]); (void)hipFree(m->sort.tile_hist);
+    (void)hipFree(m->d_pts); (void)hipFree(m->d_codes); (void)hipFree(m->d_normals); (void)hipFree(m->d_seg);
+    m->d_xyz = nullptr; m->sort = RadixSortBuffers{}; m->d_pts = nullptr; m->d_codes = nullptr; m->d_normals = nullptr; m->d_seg = nullptr;
+    m->cap_points = 0;
+}
+
+chad_status ensure_frame_capacity(chad_map* m, size_t n) {
+    if (n <= m->cap_points) return CHAD_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    size_t cap = std::max<size_t>(n, m->cap_points * 2);
+    cap = (cap + kSortTile - 1) / kSortTile * kSortTile;
+    free_frame_buffers(m);
+    HIP_TRY(hipMalloc(&m->d_xyz, cap * 12));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMalloc(&m->sort.keys[i], cap * 8));
+        HIP_TRY(hipMalloc(&m->sort.idx[i], cap * 4));
+    }
+    HIP_TRY(hipMalloc(&m->sort.tile_hist, size_t(kRadix) * radix_tiles(cap) * 4));
+    HIP_TRY(hipMalloc(&m->d_pts, cap * 16));
+    HIP_TRY(hipMalloc(&m->d_codes, cap * 8));
+    HIP_TRY(hipMalloc(&m->d_normals, cap * 16));
+    HIP_TRY(hipMalloc(&m->d_seg, cap * 16));  // point-block starts [cap], lengths [cap], update work items [2*cap]
+    m->cap_points = cap;
+    return CHAD_OK;
+}
+
+// Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  `blocks` = bricks in use.
+chad_status clear_active(chad_map* m, uint32_t blocks, bool whole_table) {
+    if (whole_table) {
+        hipLaunchKernelGGL(k_fill_u64, grid_for(m->hash_capacity), dim3(256), 0, m->stream, m->view.hash_keys, size_t(m->hash_capacity), kEmptyKey);
+        hipLaunchKernelGGL(k_fill_u32, grid_for(m->hash_capacity), dim3(256), 0, m->stream, m->view.hash_vals, size_t(m->hash_capacity), kPending);
+    } else if (blocks) {
+        hipLaunchKernelGGL(k_release_slots, grid_for(blocks), dim3(256), 0, m->stream, m->view.brick_slot, blocks, m->view.hash_keys, m->view.hash_vals);
+    }
+    if (blocks) {
+        HIP_TRY(hipMemsetAsync(m->view.brick_sum, 0, size_t(blocks) * 64 * 4, m->stream));
+        HIP_TRY(hipMemsetAsync(m->view.brick_cnt, 0, size_t(blocks) * 64 * 4, m->stream));
+    }
+    HIP_TRY(hipMemsetAsync(m->view.brick_count, 0, 4, m->stream));
+    HIP_TRY(hipGetLastError());
+    return CHAD_OK;
+}
+
+chad_status read_block_count(chad_map* m, uint32_t* blocks) {
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, m->view.brick_count, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    *blocks = std::min(v, m->brick_capacity);
+    return CHAD_OK;
+}
+
+void free_submap(Submap& s) {
+    (void)hipFree(s.keys); (void)hipFree(s.sum); (void)hipFree(s.cnt);
+    s = Submap{};
+}
+
+chad_status alloc_submap(Submap& s, uint32_t blocks) {
+    s.blocks = blocks;
+    const size_t nb = std::max<uint32_t>(blocks, 1);
+    HIP_TRY(hipMalloc(&s.keys, nb * 8));
+    HIP_TRY(hipMalloc(&s.sum, nb * 64 * 4));
+    HIP_TRY(hipMalloc(&s.cnt, nb * 64 * 4));
+    return CHAD_OK;
+}
+
+// Submap roll-over (tsdf.cpp:52-57): archive the active submap's bricks and start an empty one.
+chad_status close_active(chad_map* m) {
+    uint32_t blocks = 0;
+    TRY(read_block_count(m, &blocks));
+    Submap s;
+    TRY(alloc_submap(s, blocks));
+    if (blocks)
+        hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(blocks) * 64), dim3(256), 0, m->stream, (const uint32_t*)nullptr, blocks, m->view.brick_key,
+                           m->view.brick_sum, m->view.brick_cnt, s.keys, s.sum, s.cnt);
+    m->closed.push_back(s);
+    return clear_active(m, blocks, false);
+}
+
+chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const uint64_t** keys, const float** sum, const uint32_t** cnt) {
+    if (submap < 0) {
+        TRY(read_block_count(m, blocks));
+        *keys = m->view.brick_key; *sum = m->view.brick_sum; *cnt = m->view.brick_cnt;
+        return CHAD_OK;
+    }
+    if (size_t(submap) >= m->closed.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const Submap& s = m->closed[size_t(submap)];
+    *blocks = s.blocks; *keys = s.keys; *sum = s.sum; *cnt = s.cnt;
+    return CHAD_OK;
+}
+
+struct HostBricks {
+    std::vector<uint64_t> keys; std::vector<float> sum; std::vector<uint32_t> cnt; std::vector<uint32_t> order;
+};
+
+chad_status fetch_bricks(chad_map* m, int32_t submap, HostBricks& hb) {
+    uint32_t blocks = 0;
+    const uint64_t* keys; const float* sum; const uint32_t* cnt;
+    TRY(select_submap(m, submap, &blocks, &keys, &sum, &cnt));
+    hb.keys.resize(blocks); hb.sum.resize(size_t(blocks) * 64); hb.cnt.resize(size_t(blocks) * 64);
+    if (blocks) {
+        HIP_TRY(hipMemcpy(hb.keys.data(), keys, size_t(blocks) * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hb.sum.data(), sum, size_t(blocks) * 256, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hb.cnt.data(), cnt, size_t(blocks) * 256, hipMemcpyDeviceToHost));
+    }
+    hb.order.resize(blocks);
+    std::iota(hb.order.begin(), hb.order.end(), 0u);
+    std::sort(hb.order.begin(), hb.order.end(), [&](uint32_t a, uint32_t b) { return hb.keys[a] < hb.keys[b]; });
+    return CHAD_OK;
+}
+
+void record(chad_map* m, Stage s) {
+    if (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) (void)hipEventRecord(m->ev[m->timed_end % chad_map::kTimingRing][s], m->stream);
+}
+
+// mean stage times over the inserts whose event sets have not been read yet (the stream must be idle)
+void collect_timing(chad_map* m) {
+    if (!(m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) || m->timed_end == m->timed_begin) return;
+    double sum[T_COUNT] = {};
+    int count = 0;
+    for (uint64_t f = m->timed_begin; f < m->timed_end; f++) {
+        hipEvent_t* e = m->ev[f % chad_map::kTimingRing];
+        float t = 0;
+        bool ok = true;
+        for (int s = T_CALC; s < T_COUNT; s++) { if (hipEventElapsedTime(&t, e[s - 1], e[s]) != hipSuccess) { ok = false; break; } sum[s] += t; }
+        if (!ok || hipEventElapsedTime(&t, e[T_BEGIN], e[T_UPD]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        sum[T_BEGIN] += t;
+        count++;
+    }
+    if (count) for (int s = 0; s < T_COUNT; s++) m->ms[s] = float(sum[s] / count);
+    m->timed_begin = m->timed_end;
+}
+
+// tsdf.cpp:39-75 with the points already on the device
+chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float position[3]) {
+    if (n > 0xfffffff0ull) return fail(CHAD_ERR_INVALID_ARG, "more than 2^32 points in one frame");
+    // submap bookkeeping, tsdf.cpp:46-61 (f32 distance in the reference's operation order; this file is built
+    // with -ffp-contract=off)
+    const std::array<float, 3> pose{position[0], position[1], position[2]};
+    if (m->positions.empty()) m->positions.push_back(pose);
+    else {
+        const std::array<float, 3>& first = m->positions.front();
+        const float dx = pose[0] - first[0], dy = pose[1] - first[1], dz = pose[2] - first[2];
+        if (std::sqrt(dx * dx + dy * dy + dz * dz) > 5.0f) {
+            TRY(close_active(m));
+            m->positions.clear();
+            m->positions.push_back(pose);
+        } else m->positions.push_back(pose);
+    }
+
+    const F3 pos{position[0], position[1], position[2]};
+    const uint32_t count = uint32_t(n);
+    record(m, T_BEGIN);
+    hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, m->stream, m->d_hdr);
+    if (count) {
+        uint32_t* item_start = m->d_seg + 2 * m->cap_points;
+        hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_part);
+        hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0]);
+        record(m, T_CALC);
+        radix_sort_enqueue(m->sort, count, 64 / kRadixBits, &m->d_hdr->sort_passes, m->stream);
+        hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, m->recip, m->d_hdr, m->d_part, m->sort.keys[0], m->sort.keys[1],
+                           m->sort.idx[0], m->sort.idx[1], m->d_pts, m->d_codes, m->d_seg, item_start);
+        record(m, T_SORT);
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * 8), dim3(64 * kNormalWavesPerBlock), 0, m->stream, m->d_pts, m->d_codes, m->d_seg, m->d_seg + m->cap_points, m->d_hdr, pos, m->d_normals);
+        record(m, T_NORM);
+        if (m->update_mode == CHAD_UPDATE_SCATTER)
+            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, m->d_pts, m->d_normals, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view);
+        else
+            tile_update_enqueue(m->d_pts, m->d_normals, m->d_codes, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream);
+        record(m, T_UPD);
+    } else {
+        record(m, T_CALC); record(m, T_SORT); record(m, T_NORM); record(m, T_UPD);
+    }
+    HIP_TRY(hipGetLastError());
+    m->frames++;
+    m->last_points_in = n;
+    if (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) {
+        m->timed_end++;
+        if (m->timed_end - m->timed_begin > chad_map::kTimingRing) m->timed_begin = m->timed_end - chad_map::kTimingRing;
+        if (m->flags & CHAD_FLAG_VERBOSE) {  // the reference prints its five stage lines on every insert
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            collect_timing(m);
+            std::printf("mc  calc %.2f\nmc  sort %.2f\nnorm est %.2f\noct  upd %.2f\ntotal    %.2f\n", m->ms[T_CALC], m->ms[T_SORT], m->ms[T_NORM], m->ms[T_UPD], m->ms[T_BEGIN]);
+        }
+    }
+    return CHAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* chad_last_error(void) { return g_error.c_str(); }
+const char* chad_version(void) { return "chad_hip 0.1 gfx950"; }
+
+chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* opt, chad_map** out) {
+    if (!out) return fail(CHAD_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!(sdf_res > 0.0f) || !(sdf_trunc > 0.0f) || !std::isfinite(sdf_res) || !std::isfinite(sdf_trunc))
+        return fail(CHAD_ERR_INVALID_ARG, "sdf_res and sdf_trunc must be positive and finite");
+    chad_options o{};
+    o.device = -1;
+    if (opt) {
+        if (opt->struct_size < sizeof(uint32_t) * 2) return fail(CHAD_ERR_INVALID_ARG, "chad_options.struct_size not set");
+        std::memcpy(&o, opt, std::min<size_t>(opt->struct_size, sizeof(o)));
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return fail(CHAD_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    }
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(CHAD_ERR_NO_DEVICE, "device ordinal out of range");
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(CHAD_ERR_NO_DEVICE, "cannot select the requested device");
+
+    chad_map* m = new chad_map();
+    m->res = sdf_res; m->trunc = sdf_trunc;
+    m->recip = float(1.0 / double(sdf_res));  // morton.hpp:63, octree.hpp:82
+    m->device = dev; m->flags = o.flags;
+    m->update_mode = o.update_mode ? o.update_mode : CHAD_UPDATE_TILED;
+    auto bail = [&](chad_status s) { chad_map_destroy(m); return s; };
+#define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+        return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
+    if (o.stream) m->stream = hipStream_t(o.stream);
+    else { CREATE_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+
+    uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
+    if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
+    uint64_t hcap = 1024;
+    while (hcap < blocks * 2) hcap <<= 1;  // load factor <= 0.5
+    m->brick_capacity = uint32_t(blocks); m->hash_capacity = uint32_t(hcap);
+    CREATE_TRY(hipMalloc(&m->view.hash_keys, hcap * 8));
+    CREATE_TRY(hipMalloc(&m->view.hash_vals, hcap * 4));
+    CREATE_TRY(hipMalloc(&m->view.brick_key, blocks * 8));
+    CREATE_TRY(hipMalloc(&m->view.brick_sum, blocks * 256));
+    CREATE_TRY(hipMalloc(&m->view.brick_cnt, blocks * 256));
+    CREATE_TRY(hipMalloc(&m->view.brick_slot, blocks * 4));
+    CREATE_TRY(hipMalloc(&m->view.brick_count, 4));
+    CREATE_TRY(hipMalloc(&m->d_hdr, sizeof(FrameHeader)));
+    CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
+    CREATE_TRY(hipMalloc(&m->d_part, sizeof(FramePartial) * kFrameBlocks));
+    m->view.hash_mask = uint32_t(hcap - 1); m->view.brick_capacity = uint32_t(blocks);
+    CREATE_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
+    CREATE_TRY(hipMemsetAsync(m->view.brick_sum, 0, blocks * 256, m->stream));
+    CREATE_TRY(hipMemsetAsync(m->view.brick_cnt, 0, blocks * 256, m->stream));
+    if (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE))
+        for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
+    if (clear_active(m, 0, true) != CHAD_OK) return bail(CHAD_ERR_HIP);
+    if (ensure_frame_capacity(m, o.max_points ? o.max_points : (1u << 20)) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
+    CREATE_TRY(hipStreamSynchronize(m->stream));
+#undef CREATE_TRY
+    *out = m;
+    return CHAD_OK;
+}
+
+void chad_map_destroy(chad_map* m) {
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    free_frame_buffers(m);
+    for (auto& s : m->closed) free_submap(s);
+    (void)hipFree(m->view.hash_keys); (void)hipFree(m->view.hash_vals); (void)hipFree(m->view.brick_key);
+    (void)hipFree(m->view.brick_sum); (void)hipFree(m->view.brick_cnt); (void)hipFree(m->view.brick_count);
+    (void)hipFree(m->view.brick_slot); (void)hipFree(m->d_hdr); (void)hipFree(m->d_part);
+    if (m->h_hdr) (void)hipHostFree(m->h_hdr);
+    for (auto& set : m->ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
+    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t n, const float position[3]) {
+    if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(ensure_frame_capacity(m, n));
+    return insert_device(m, xyz_device, n, position);
+}
+
+chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float position[3]) {
+    if (!m || !position || (n && !xyz)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(ensure_frame_capacity(m, n));
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(m->d_xyz, xyz, n * 12, hipMemcpyHostToDevice, m->stream));
+        // the caller's buffer is only borrowed for the duration of the call (pageable memory: the copy has been
+        // staged when hipMemcpyAsync returns; pinned memory: wait for it)
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    return insert_device(m, m->d_xyz, n, position);
+}
+
+chad_status chad_map_sync(chad_map* m) {
+    if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    DeviceGuard guard(m->device);
+    HIP_TRY(hipMemcpyAsync(m->h_hdr, m->d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->h_hdr->overflow) return fail(CHAD_ERR_CAPACITY, "block capacity of the active submap exceeded; raise chad_options.max_blocks");
+    return CHAD_OK;
+}
+
+chad_status chad_map_reset(chad_map* m) {
+    if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    DeviceGuard guard(m->device);
+    uint32_t blocks = 0;
+    TRY(read_block_count(m, &blocks));
+    for (auto& s : m->closed) free_submap(s);
+    m->closed.clear();
+    m->positions.clear();
+    HIP_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
+    return clear_active(m, blocks, false);
+}
+
+chad_status chad_map_close_submap(chad_map* m) {
+    if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    DeviceGuard guard(m->device);
+    if (m->positions.empty()) return CHAD_OK;
+    TRY(close_active(m));
+    m->positions.clear();
+    return CHAD_OK;
+}
+
+chad_status chad_map_leaf_count(chad_map* m, int32_t submap, size_t* count) {
+    if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    return chad_map_export_leaves(m, submap, nullptr, nullptr, nullptr, 0, count);
+}
+
+chad_status chad_map_export_leaves(chad_map* m, int32_t submap, uint64_t* mc, float* sd, uint32_t* w, size_t capacity, size_t* count) {
+    if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    HostBricks hb;
+    TRY(fetch_bricks(m, submap, hb));
+    size_t k = 0;
+    for (uint32_t b : hb.order) {
+        for (uint32_t v = 0; v < 64; v++) {
+            const uint32_t c = hb.cnt[size_t(b) * 64 + v];
+            if (!c) continue;
+            if (k < capacity) {
+                if (mc) mc[k] = hb.keys[b] | v;
+                if (sd) sd[k] = hb.sum[size_t(b) * 64 + v] / float(c);  // mean of the observations (octree.hpp:161-163)
+                if (w) w[k] = c;
+            }
+            k++;
+        }
+    }
+    *count = k;
+    return CHAD_OK;
+}
+
+chad_status chad_map_stats(chad_map* m, chad_stats* out) {
+    if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    HIP_TRY(hipMemcpyAsync(m->h_hdr, m->d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost, m->stream));
+    uint32_t blocks = 0;
+    TRY(read_block_count(m, &blocks));
+    collect_timing(m);
+    std::memset(out, 0, sizeof(*out));
+    out->frames = m->frames; out->points_in = m->last_points_in; out->points_used = m->h_hdr->n_usable;
+    out->updates = 0;
+    for (int k = 0; k < 32; k++) out->updates += m->h_hdr->n_updates[k * 16];
+    out->blocks = blocks; out->block_capacity = m->brick_capacity;
+    out->hash_capacity = m->hash_capacity; out->closed_submaps = m->closed.size();
+    out->sort_passes = m->h_hdr->sort_passes; out->overflow = m->h_hdr->overflow;
+    out->ms_mc_calc = m->ms[T_CALC]; out->ms_mc_sort = m->ms[T_SORT]; out->ms_norm_est = m->ms[T_NORM];
+    out->ms_oct_upd = m->ms[T_UPD]; out->ms_total = m->ms[T_BEGIN];
+    return CHAD_OK;
+}
+
+chad_status chad_map_block_count(chad_map* m, int32_t submap, size_t* blocks) {
+    if (!m || !blocks) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    uint32_t nb = 0;
+    const uint64_t* k; const float* s; const uint32_t* c;
+    TRY(select_submap(m, submap, &nb, &k, &s, &c));
+    *blocks = nb;
+    return CHAD_OK;
+}
+
+chad_status chad_map_export_blocks_device(chad_map* m, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks) {
+    if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    DeviceGuard guard(m->device);
+    uint32_t nb = 0;
+    const uint64_t* keys; const float* sum; const uint32_t* cnt;
+    TRY(select_submap(m, submap, &nb, &keys, &sum, &cnt));
+    if (nb > capacity_blocks) return fail(CHAD_ERR_INVALID_ARG, "capacity_blocks too small");
+    if (!nb) return CHAD_OK;
+    if (!keys_device || !sum_device || !cnt_device) return fail(CHAD_ERR_INVALID_ARG, "null output");
+    TRY(ensure_frame_capacity(m, nb));
+    // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
+    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->sort.keys[0], nb);
+    radix_sort_enqueue(m->sort, nb, 64 / kRadixBits, nullptr, m->stream);
+    hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->sort.idx[0], nb, keys, sum, cnt, keys_device, sum_device, cnt_device);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHAD_OK;
+}
+
+chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t* keys_device, const float* sum_device, const uint32_t* cnt_device, size_t blocks) {
+    if (!m || (blocks && (!keys_device || !sum_device || !cnt_device))) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (blocks > 0xffffffffull) return fail(CHAD_ERR_INVALID_ARG, "too many blocks");
+    DeviceGuard guard(m->device);
+    uint32_t live = 0;
+    TRY(read_block_count(m, &live));
+    Submap s;
+    TRY(alloc_submap(s, uint32_t(blocks)));
+    if (blocks) {
+        HIP_TRY(hipMemcpyAsync(s.keys, keys_device, blocks * 8, hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(s.sum, sum_device, blocks * 256, hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(s.cnt, cnt_device, blocks * 256, hipMemcpyDeviceToDevice, m->stream));
+    }
+    m->closed.push_back(s);
+    m->positions.clear();
+    TRY(clear_active(m, live, false));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHAD_OK;
+}
+
+chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, float* normals, size_t capacity, size_t* count) {
+    if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    HIP_TRY(hipMemcpyAsync(m->h_hdr, m->d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const size_t n = m->frames ? m->h_hdr->n_usable : 0;
+    *count = n;
+    const size_t k = std::min(n, capacity);
+    if (!k) return CHAD_OK;
+    std::vector<float> tmp(k * 4);
+    if (order) {
+        HIP_TRY(hipMemcpy(tmp.data(), m->d_pts, k * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < k; i++) std::memcpy(&order[i], &tmp[4 * i + 3], 4);
+    }
+    if (mc) HIP_TRY(hipMemcpy(mc, m->d_codes, k * 8, hipMemcpyDeviceToHost));
+    if (normals) {
+        HIP_TRY(hipMemcpy(tmp.data(), m->d_normals, k * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < k; i++) std::memcpy(&normals[3 * i], &tmp[4 * i], 12);
+    }
+    return CHAD_OK;
+}
+
+chad_status chad_walk_rays(const float* xyz, size_t n, const float position[3], float sdf_res, float sdf_trunc, int32_t* voxels, uint32_t* counts, size_t stride) {
+    if ((n && (!xyz || !voxels || !counts)) || !position || !stride) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (!n) return CHAD_OK;
+    float* d_xyz = nullptr; int* d_vox = nullptr; uint32_t* d_cnt = nullptr;
+    HIP_TRY(hipMalloc(&d_xyz, n * 12));
+    HIP_TRY(hipMalloc(&d_vox, n * stride * 12));
+    HIP_TRY(hipMalloc(&d_cnt, n * 4));
+    HIP_TRY(hipMemcpy(d_xyz, xyz, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_vox, 0, n * stride * 12));
+    const float recip = float(1.0 / double(sdf_res));
+    hipLaunchKernelGGL(k_walk_rays, dim3(unsigned((n + 255) / 256)), dim3(256), 0, 0, d_xyz, uint32_t(n), F3{position[0], position[1], position[2]}, sdf_res, recip,
+                       sdf_trunc, d_vox, d_cnt, uint32_t(stride));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(voxels, d_vox, n * stride * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counts, d_cnt, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_xyz); (void)hipFree(d_vox); (void)hipFree(d_cnt);
+    return CHAD_OK;
+}
+
+chad_status chad_morton_codes(const float* xyz, size_t n, float sdf_res, uint64_t* mc) {
+    if (n && (!xyz || !mc)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (!n) return CHAD_OK;
+    float* d_xyz = nullptr; uint64_t* d_mc = nullptr;
+    HIP_TRY(hipMalloc(&d_xyz, n * 12));
+    HIP_TRY(hipMalloc(&d_mc, n * 8));
+    HIP_TRY(hipMemcpy(d_xyz, xyz, n * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_morton_codes, dim3(unsigned((n + 255) / 256)), dim3(256), 0, 0, d_xyz, uint32_t(n), float(1.0 / double(sdf_res)), d_mc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(mc, d_mc, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_xyz); (void)hipFree(d_mc);
+    return CHAD_OK;
+}
+
+}  // extern "C"

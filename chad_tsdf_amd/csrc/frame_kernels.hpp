@@ -1,0 +1,418 @@
+// frame_kernels.hpp -- per-frame stages ahead of the TSDF update: voxel bounds, sort keys, gather + block
+// segments, and normal estimation (reference: morton.hpp:59-102, normals.hpp:10-148).
+//
+// Processing order.  The reference sorts the whole frame by descending 63-bit Morton code.  Everything that
+// depends on that order is local to a 4x4x4-voxel block (the greedy neighbourhood walk of normals.hpp:94-108
+// never crosses a change of code >> 6, and every block's first neighbourhood starts at the block's first
+// point), except one thing: the globally last point is never absorbed into a neighbourhood (normals.hpp:100).
+// So the device sorts by a SHORT key -- the Morton code of the voxel relative to the frame's bounding box,
+// whose corner is aligned to 4 voxels so that the low 6 code bits (the voxel inside its block) and the block
+// partition are those of the global code -- and finds the reference's "last point" (smallest global code,
+// largest input index among equals) with a reduction.  A room-sized frame needs 3-4 radix passes instead of 8.
+// Inside a block the order is the reference's: descending voxel code, ties by ascending input index.
+#pragma once
+#include "device_math.hpp"
+#include "radix_sort.hpp"
+
+namespace chadhip {
+
+constexpr int kFrameBlocks = 512;     // fixed grid of the bounds / keys / gather kernels (2 workgroups per CU)
+constexpr int kGatherChunk = 2048;    // points per gather step of one workgroup
+constexpr uint32_t kItemPoints = 256; // an update work item never holds more points than this
+
+// Per-frame scalars living in device memory (one per map; rewritten every insert).
+struct FrameHeader {
+    int vmin[3], vmax[3];       // voxel bounds of the usable points
+    uint32_t n_usable;          // points kept (D2 of the oracle header)
+    uint32_t axis_bits;         // bits per axis of the frame-local code
+    uint32_t sort_passes;       // radix passes needed: ceil((3*axis_bits + 1) / 8)
+    uint32_t n_segments;        // point blocks (runs of equal code >> 6) found by k_frame_gather
+    unsigned long long mc_min;  // smallest global Morton code of the frame ...
+    uint32_t last_idx;          // ... and the largest input index among the points having it (normals.hpp:100)
+    uint32_t overflow;          // set when the block pool / hash could not take a new block
+    uint32_t n_items;           // update work items: point blocks cut at every kItemPoints-th point
+    uint32_t item_cursor;       // work counter of the persistent update waves
+    unsigned long long n_updates[32 * 16];  // voxel updates applied by the last insert, striped over 32 cache lines
+};
+
+// Partial results of one workgroup, combined by the NEXT kernel's prologue (no same-address atomics: on gfx950
+// those serialise at ~12 ns each, which for thousands of waves costs more than the whole pass).
+struct FramePartial {
+    int lo[3], hi[3];
+    uint32_t kept, pad;
+    unsigned long long mc_min;
+};
+
+__global__ void k_frame_init(FrameHeader* h) {
+    const uint32_t keep_overflow = h->overflow;
+    for (uint32_t k = threadIdx.x; k < 32 * 16; k += blockDim.x) h->n_updates[k] = 0;
+    if (threadIdx.x == 0) {
+        h->vmin[0] = h->vmin[1] = h->vmin[2] = 0x7fffffff;
+        h->vmax[0] = h->vmax[1] = h->vmax[2] = int(0x80000000);
+        h->n_usable = 0; h->axis_bits = 0; h->sort_passes = 0; h->n_segments = 0;
+        h->mc_min = ~0ull; h->last_idx = 0; h->overflow = keep_overflow; h->n_items = 0; h->item_cursor = 0;
+    }
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ F3 load_point(const float* __restrict__ xyz, size_t i) { return {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}; }
+
+// Stage 1: voxel bounds and the count of usable points, one partial per workgroup.
+__global__ void __launch_bounds__(256)
+k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FramePartial* __restrict__ part) {
+    __shared__ int red[4][7];
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {int(0x80000000), int(0x80000000), int(0x80000000)};
+    uint32_t kept = 0;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const F3 p = load_point(xyz, i);
+        if (point_usable(p, pos, recip)) {
+            const I3 v = voxel_of(p, recip);
+            lo[0] = min(lo[0], v.x); lo[1] = min(lo[1], v.y); lo[2] = min(lo[2], v.z);
+            hi[0] = max(hi[0], v.x); hi[1] = max(hi[1], v.y); hi[2] = max(hi[2], v.z);
+            kept++;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
+    kept = wave_sum(kept);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+        red[wave][6] = int(kept);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FramePartial p;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            p.lo[a] = min(min(red[0][a], red[1][a]), min(red[2][a], red[3][a]));
+            p.hi[a] = max(max(red[0][3 + a], red[1][3 + a]), max(red[2][3 + a], red[3][3 + a]));
+        }
+        p.kept = uint32_t(red[0][6]) + uint32_t(red[1][6]) + uint32_t(red[2][6]) + uint32_t(red[3][6]);
+        p.pad = 0; p.mc_min = ~0ull;
+        part[blockIdx.x].lo[0] = p.lo[0]; part[blockIdx.x].lo[1] = p.lo[1]; part[blockIdx.x].lo[2] = p.lo[2];
+        part[blockIdx.x].hi[0] = p.hi[0]; part[blockIdx.x].hi[1] = p.hi[1]; part[blockIdx.x].hi[2] = p.hi[2];
+        part[blockIdx.x].kept = p.kept;
+    }
+}
+
+struct LocalFrame { int ox, oy, oz; uint32_t bits, kept; int lo[3], hi[3]; };  // frame-local code geometry
+
+// Combine the kFrameBlocks partial bounds (every workgroup of the keys kernel does this redundantly: 512 x 28 B
+// from L2) and derive the frame-local code geometry.
+__device__ __forceinline__ LocalFrame combine_bounds(const FramePartial* __restrict__ part) {
+    __shared__ int red[4][7];
+    __shared__ LocalFrame shared_frame;
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {int(0x80000000), int(0x80000000), int(0x80000000)};
+    uint32_t kept = 0;
+    for (uint32_t k = threadIdx.x; k < kFrameBlocks; k += blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], part[k].lo[a]); hi[a] = max(hi[a], part[k].hi[a]); }
+        kept += part[k].kept;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
+    kept = wave_sum(kept);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+        red[wave][6] = int(kept);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        LocalFrame f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            f.lo[a] = min(min(red[0][a], red[1][a]), min(red[2][a], red[3][a]));
+            f.hi[a] = max(max(red[0][3 + a], red[1][3 + a]), max(red[2][3 + a], red[3][3 + a]));
+        }
+        f.kept = uint32_t(red[0][6]) + uint32_t(red[1][6]) + uint32_t(red[2][6]) + uint32_t(red[3][6]);
+        f.ox = f.lo[0] & ~3; f.oy = f.lo[1] & ~3; f.oz = f.lo[2] & ~3;  // align down to a block corner
+        uint32_t ext = 0;
+        if (f.kept) ext = uint32_t(f.hi[0] - f.ox) | uint32_t(f.hi[1] - f.oy) | uint32_t(f.hi[2] - f.oz);
+        const uint32_t bits = 32 - __clz(ext | 3u);  // at least the 2 in-block bits
+        f.bits = bits > 21 ? 21 : bits;              // beyond 21 bits the reference's code aliases as well (morton.hpp:22)
+        shared_frame = f;
+    }
+    __syncthreads();
+    return shared_frame;
+}
+
+// Stage 2: sort keys.  key = (2^(3b) - 1) - local code (ascending key = descending code); unusable points get
+// 2^(3b), above every usable key, so they end up behind the n_usable usable points.
+__global__ void __launch_bounds__(256)
+k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
+             FramePartial* __restrict__ part, uint64_t* __restrict__ keys) {
+    const LocalFrame f = combine_bounds(part);
+    __shared__ unsigned long long wave_mc[4];
+    const uint64_t top = 1ull << (3 * f.bits);
+    unsigned long long mc_min = ~0ull;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const F3 p = load_point(xyz, i);
+        uint64_t key = top;
+        if (point_usable(p, pos, recip)) {
+            const I3 v = voxel_of(p, recip);
+            const uint64_t local = spread21(uint32_t(v.x - f.ox)) | (spread21(uint32_t(v.y - f.oy)) << 1) | (spread21(uint32_t(v.z - f.oz)) << 2);
+            key = (top - 1) - (local & (top - 1));
+            const unsigned long long mc = morton_encode(v.x, v.y, v.z);
+            mc_min = mc < mc_min ? mc : mc_min;
+        }
+        keys[i] = key;
+    }
+    mc_min = wave_min_u64(mc_min);
+    if ((threadIdx.x & 63) == 0) wave_mc[threadIdx.x >> 6] = mc_min;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wave_mc[0];
+        for (int w = 1; w < 4; w++) m = wave_mc[w] < m ? wave_mc[w] : m;
+        part[blockIdx.x].mc_min = m;
+        if (blockIdx.x == 0) {
+            for (int a = 0; a < 3; a++) { h->vmin[a] = f.lo[a]; h->vmax[a] = f.hi[a]; }
+            h->n_usable = f.kept;
+            h->axis_bits = f.bits;
+            h->sort_passes = (3 * f.bits + 1 + kRadixBits - 1) / kRadixBits;
+        }
+    }
+}
+
+// Stage 3 (after the sort): gather the points into processing order as float4 (x, y, z, input index), recompute
+// their global codes, and list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
+// normal estimation and (b) the update work items in item_start[]: the point blocks cut again at every
+// kItemPoints-th point, so that no item is longer than kItemPoints.  Both lists are unordered; a workgroup
+// collects its entries in LDS and reserves output space with ONE atomic per list and chunk.
+// The sorted (key, idx) pairs are in sort buffer (sort_passes & 1).
+__global__ void __launch_bounds__(256)
+k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
+               const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+               const uint32_t* __restrict__ idx0, const uint32_t* __restrict__ idx1,
+               float4* __restrict__ pts, uint64_t* __restrict__ codes, uint32_t* __restrict__ seg_start, uint32_t* __restrict__ item_start) {
+    __shared__ uint32_t heads[kGatherChunk], marks[kGatherChunk];
+    __shared__ uint32_t n_heads, n_marks, base_heads, base_marks;
+    __shared__ unsigned long long wave_mc[4], block_mc_min;
+    // frame-wide smallest code from the keys kernel's partials
+    {
+        unsigned long long m = ~0ull;
+        for (uint32_t k = threadIdx.x; k < kFrameBlocks; k += blockDim.x) { const unsigned long long t = part[k].mc_min; m = t < m ? t : m; }
+        m = wave_min_u64(m);
+        if ((threadIdx.x & 63) == 0) wave_mc[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = wave_mc[0];
+            for (int w = 1; w < 4; w++) m = wave_mc[w] < m ? wave_mc[w] : m;
+            block_mc_min = m;
+            if (blockIdx.x == 0) h->mc_min = m;
+        }
+        __syncthreads();
+    }
+    const unsigned long long mc_min = block_mc_min;
+    const uint32_t n = h->n_usable;
+    const bool odd = h->sort_passes & 1u;
+    const uint64_t* keys = odd ? keys1 : keys0;
+    const uint32_t* idx = odd ? idx1 : idx0;
+    const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        if (threadIdx.x == 0) { n_heads = 0; n_marks = 0; }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < kGatherChunk / 256; j++) {
+            const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
+            if (i < n) {
+                const uint32_t src = idx[i];
+                const F3 p = load_point(xyz, src);
+                const I3 v = voxel_of(p, recip);
+                const uint64_t mc = morton_encode(v.x, v.y, v.z);
+                pts[i] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
+                codes[i] = mc;
+                const bool head = i == 0 || (keys[i] >> 6) != (keys[i - 1] >> 6);
+                if (head) heads[atomicAdd(&n_heads, 1u)] = i;
+                if (head || (i % kItemPoints) == 0) marks[atomicAdd(&n_marks, 1u)] = i;
+                if (mc == mc_min) atomicMax(&h->last_idx, src);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            base_heads = n_heads ? atomicAdd(&h->n_segments, n_heads) : 0u;
+            base_marks = n_marks ? atomicAdd(&h->n_items, n_marks) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n_heads; k += 256) seg_start[base_heads + k] = heads[k];
+        for (uint32_t k = threadIdx.x; k < n_marks; k += 256) item_start[base_marks + k] = marks[k];
+        __syncthreads();
+    }
+}
+
+// ---- Stage 4: normals (normals.hpp:10-148) -------------------------------------------------------------------
+// One wave per point block.  The block's <= 64 voxel runs are counted into LDS, the greedy neighbourhood walk
+// runs over those 64 counters (not over the points), then lane g fits neighbourhood g with the reference's
+// two-pass f64 "plane from points" in the reference's summation order, and every point picks up its
+// neighbourhood's normal (or the per-point fallback when the neighbourhood has < 8 points).
+
+constexpr uint32_t kMinPoints = 8;  // normals.hpp:88
+
+struct NormalScratch {         // per wave, in LDS
+    uint32_t count[64];        // points per voxel of the block (index = low 6 code bits)
+    uint32_t tail[65];         // tail[v] = points in voxels >= v  (tail[64] = 0)
+    uint32_t group_of[64];     // neighbourhood of voxel v
+    uint32_t g_first[64];      // first point (offset in the segment) of neighbourhood g
+    uint32_t g_size[64];
+    float g_normal[64][4];     // fitted normal; [3] != 0 marks "fit" (else per-point fallback)
+};
+
+__device__ __forceinline__ F3 fit_plane(const float4* __restrict__ pts, uint32_t count) {
+    // normals.hpp:12-17 centroid
+    double cx = 0, cy = 0, cz = 0;
+    for (uint32_t k = 0; k < count; k++) { const float4 q = pts[k]; cx += double(q.x); cy += double(q.y); cz += double(q.z); }
+    const double recip = 1.0 / double(count);
+    cx *= recip; cy *= recip; cz *= recip;
+    // :20-36 covariance
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        const float4 q = pts[k];
+        const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
+        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+    }
+    xx *= recip; xy *= recip; xz *= recip; yy *= recip; yz *= recip; zz *= recip;
+    // :39-76 determinant-weighted axis directions, each aligned with the running sum
+    double wx = 0, wy = 0, wz = 0;
+    {
+        const double det = yy * zz - yz * yz, ax = det, ay = xz * yz - xy * zz, az = xy * yz - xz * yy;
+        double w = det * det;
+        if (wx * ax + wy * ay + wz * az < 0.0) w = -w;
+        wx += ax * w; wy += ay * w; wz += az * w;
+    }
+    {
+        const double det = xx * zz - xz * xz, ax = xz * yz - xy * zz, ay = det, az = xy * xz - yz * xx;
+        double w = det * det;
+        if (wx * ax + wy * ay + wz * az < 0.0) w = -w;
+        wx += ax * w; wy += ay * w; wz += az * w;
+    }
+    {
+        const double det = xx * yy - xy * xy, ax = xy * yz - xz * yy, ay = xy * xz - yz * xx, az = det;
+        double w = det * det;
+        if (wx * ax + wy * ay + wz * az < 0.0) w = -w;
+        wx += ax * w; wy += ay * w; wz += az * w;
+    }
+    const double inv = 1.0 / sqrt(wx * wx + wy * wy + wz * wz);  // :79
+    return {float(wx * inv), float(wy * inv), float(wz * inv)};
+}
+
+constexpr int kNormalWavesPerBlock = 1;  // one wave per workgroup: __syncthreads() is then a wave-local LDS fence
+
+__global__ void __launch_bounds__(64 * kNormalWavesPerBlock)
+k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ seg_start,
+                uint32_t* __restrict__ seg_len, FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals) {
+    __shared__ NormalScratch scratch[kNormalWavesPerBlock];
+    NormalScratch& s = scratch[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = h->n_usable, nseg = h->n_segments;
+    const uint32_t wave_global = blockIdx.x * kNormalWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t wave_total = gridDim.x * kNormalWavesPerBlock;
+    const uint64_t last_block = h->mc_min >> 6;
+
+    for (uint32_t seg = wave_global; seg < nseg; seg += wave_total) {
+        const uint32_t first = seg_start[seg];
+        const uint64_t block = codes[first] >> 6;
+        // length of the segment: scan forward to the first point of another block
+        uint32_t len = 0;
+        for (;;) {
+            const uint32_t i = first + len + lane;
+            const bool same = i < n && (codes[i] >> 6) == block;
+            const uint64_t m = __ballot(same);
+            if (m == ~0ull) { len += 64; continue; }
+            len += uint32_t(__ffsll((unsigned long long)~m)) - 1u;
+            break;
+        }
+        if (lane == 0) seg_len[seg] = len;
+        // normals.hpp:100 -- the frame's last point never joins a neighbourhood; it is the last point of this segment
+        const bool holds_last = block == last_block;
+        const uint32_t grouped = holds_last ? len - 1 : len;
+
+        s.count[lane] = 0;
+        __syncthreads();
+        for (uint32_t k = lane; k < grouped; k += 64) atomicAdd(&s.count[uint32_t(codes[first + k]) & 63u], 1u);
+        __syncthreads();
+        {   // tail[v] = sum of count[v..63]: inclusive scan over lanes holding voxels 63, 62, ...
+            uint32_t c = s.count[63 - lane];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(c, o); if (int(lane) >= o) c += t; }
+            s.tail[63 - lane] = c;
+            if (lane == 0) s.tail[64] = 0;
+        }
+        __syncthreads();
+        // greedy walk (normals.hpp:86-138) over the voxel runs, identical in every lane
+        uint32_t ngroups = 0;
+        for (int v = 63; v >= 0;) {
+            if (s.count[v] == 0) { v--; continue; }
+            const uint32_t start = s.tail[v + 1];  // points in higher voxels come first
+            uint32_t size = s.count[v];
+            int lowest = v;                               // lowest voxel taken into the neighbourhood
+            if (size < kMinPoints) {                      // depth 1: the rest of the 2x2x2 octant
+                lowest = v & ~7;
+                size = s.tail[lowest] - s.tail[v + 1];
+                if (size < kMinPoints) {                  // depth 2: the rest of the block
+                    lowest = 0;
+                    size = s.tail[0] - s.tail[v + 1];
+                }
+            }
+            if (lane == 0) { s.g_first[ngroups] = start; s.g_size[ngroups] = size; }
+            if (int(lane) >= lowest && int(lane) <= v) s.group_of[lane] = ngroups;
+            ngroups++;
+            v = lowest - 1;
+        }
+        __syncthreads();
+        if (lane < ngroups) {
+            const uint32_t g0 = s.g_first[lane], gn = s.g_size[lane];
+            float fit = 0.0f;
+            F3 nrm{0, 0, 0};
+            if (gn >= kMinPoints) {
+                nrm = fit_plane(pts + first + g0, gn);
+                const float4 q = pts[first + g0];
+                const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
+                if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
+                fit = 1.0f;
+            }
+            s.g_normal[lane][0] = nrm.x; s.g_normal[lane][1] = nrm.y; s.g_normal[lane][2] = nrm.z; s.g_normal[lane][3] = fit;
+        }
+        __syncthreads();
+        for (uint32_t k = lane; k < len; k += 64) {
+            const float4 q = pts[first + k];
+            F3 nrm;
+            bool fitted = false;
+            if (k < grouped) {
+                const uint32_t g = s.group_of[uint32_t(codes[first + k]) & 63u];
+                fitted = s.g_normal[g][3] != 0.0f;
+                nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
+            }
+            if (!fitted) nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
+            normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace chadhip

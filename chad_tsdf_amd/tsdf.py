@@ -1,0 +1,178 @@
+"""Host-side mirror of chad::TSDFMap (reference include/chad/tsdf.hpp:21-171) over the C ABI.
+
+Same names and argument meaning as the reference class: TSDFMap(sdf_res=0.05, sdf_trunc=0.1),
+map.insert(points, position), map.save(filename).  Points are accepted as anything numpy can view as
+float32 [N,3] (host memory, copied over PCIe by the library) or as a torch CUDA tensor (device-resident,
+no copy).  All compute happens in the HIP library; nothing here touches the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _np_f32(a, shape_last=3):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.reshape(-1, shape_last) if a.size else a.reshape(0, shape_last)
+
+
+class TSDFMap:
+    def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, device: int = -1, max_blocks: int = 0,
+                 max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, update_mode: int = 0):
+        self._lib = _lib.load()
+        self._sdf_res = float(sdf_res)
+        self._sdf_trunc = float(sdf_trunc)
+        opt = _lib.Options()
+        opt.struct_size = C.sizeof(_lib.Options)
+        opt.device = device
+        opt.max_blocks = max_blocks
+        opt.max_points = max_points
+        opt.stream = stream or None
+        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0)
+        opt.update_mode = update_mode
+        handle = C.c_void_p()
+        _lib.check(self._lib.chad_map_create(sdf_res, sdf_trunc, C.byref(opt), C.byref(handle)), "TSDFMap")
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.chad_map_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- reference API ------------------------------------------------------------------------------
+    def insert(self, points, position):
+        """TSDFMap::insert(points, position) -- tsdf.hpp:48-64."""
+        pos = _np_f32(position).reshape(3)
+        if hasattr(points, "is_cuda") and points.is_cuda:  # torch tensor on the GPU: zero-copy
+            import torch
+
+            t = points.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.to(torch.float32).contiguous()
+            n = t.numel() // 3
+            _lib.check(self._lib.chad_map_insert_device(self._h, t.data_ptr(), n, pos.ctypes.data), "TSDFMap.insert")
+            self._keepalive = t  # the device buffer must outlive the enqueued kernels
+        else:
+            pts = _np_f32(points)
+            _lib.check(self._lib.chad_map_insert(self._h, pts.ctypes.data, pts.shape[0], pos.ctypes.data), "TSDFMap.insert")
+
+    def save(self, filename: str):
+        """TSDFMap::save -- tsdf.cpp:76-86: close the active submap, write the FIRST submap (as PLY voxels here)."""
+        self.close_submap()
+        if self.closed_submaps == 0:
+            raise RuntimeError("TSDFMap.save: nothing was inserted")
+        mc, sd, w = self.export_leaves(0)
+        xyz = decode_morton(mc).astype(np.float32) * np.float32(self._sdf_res)
+        with open(filename, "wb") as f:
+            f.write((f"ply\nformat binary_little_endian 1.0\ncomment chad_tsdf voxels res {self._sdf_res:g} trunc {self._sdf_trunc:g}\n"
+                     f"element vertex {len(mc)}\nproperty float x\nproperty float y\nproperty float z\n"
+                     "property float signed_distance\nproperty uint weight\nend_header\n").encode())
+            rec = np.empty(len(mc), dtype=[("p", "<f4", 3), ("sd", "<f4"), ("w", "<u4")])
+            rec["p"], rec["sd"], rec["w"] = xyz, sd, w
+            f.write(rec.tobytes())
+
+    # ---- extensions ---------------------------------------------------------------------------------
+    def sync(self):
+        _lib.check(self._lib.chad_map_sync(self._h), "TSDFMap.sync")
+
+    def reset(self):
+        _lib.check(self._lib.chad_map_reset(self._h), "TSDFMap.reset")
+
+    def close_submap(self):
+        _lib.check(self._lib.chad_map_close_submap(self._h), "TSDFMap.close_submap")
+
+    def stats(self) -> dict:
+        st = _lib.Stats()
+        _lib.check(self._lib.chad_map_stats(self._h, C.byref(st)), "TSDFMap.stats")
+        return {name: getattr(st, name) for name, _ in _lib.Stats._fields_}
+
+    @property
+    def closed_submaps(self) -> int:
+        return int(self.stats()["closed_submaps"])
+
+    def export_leaves(self, submap: int = -1):
+        """(mc u64, sd f32, w u32) of all voxels with weight > 0, sorted by Morton code."""
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_map_leaf_count(self._h, submap, C.byref(n)), "TSDFMap.export_leaves")
+        mc = np.empty(n.value, dtype=np.uint64)
+        sd = np.empty(n.value, dtype=np.float32)
+        w = np.empty(n.value, dtype=np.uint32)
+        got = C.c_size_t()
+        _lib.check(self._lib.chad_map_export_leaves(self._h, submap, mc.ctypes.data, sd.ctypes.data, w.ctypes.data, n.value, C.byref(got)), "TSDFMap.export_leaves")
+        assert got.value == n.value
+        return mc, sd, w
+
+    def last_frame(self):
+        """(order, codes, normals) of the last insert in the device's processing order (parity tests)."""
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_map_last_frame(self._h, None, None, None, 0, C.byref(n)), "TSDFMap.last_frame")
+        order = np.empty(n.value, dtype=np.uint32)
+        mc = np.empty(n.value, dtype=np.uint64)
+        nrm = np.empty((n.value, 3), dtype=np.float32)
+        _lib.check(self._lib.chad_map_last_frame(self._h, order.ctypes.data, mc.ctypes.data, nrm.ctypes.data, n.value, C.byref(n)), "TSDFMap.last_frame")
+        return order, mc, nrm
+
+    def block_count(self, submap: int = -1) -> int:
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_map_block_count(self._h, submap, C.byref(n)), "TSDFMap.block_count")
+        return n.value
+
+    def export_blocks(self, submap: int = -1):
+        """Per-block partial sums as torch CUDA tensors (keys int64 [B], sum f32 [B,64], cnt int32 [B,64]), sorted by key."""
+        import torch
+
+        b = self.block_count(submap)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        keys = torch.empty(b, dtype=torch.int64, device=dev)
+        s = torch.empty((b, 64), dtype=torch.float32, device=dev)
+        c = torch.empty((b, 64), dtype=torch.int32, device=dev)
+        _lib.check(self._lib.chad_map_export_blocks_device(self._h, submap, keys.data_ptr(), s.data_ptr(), c.data_ptr(), b), "TSDFMap.export_blocks")
+        return keys, s, c
+
+    def close_submap_with_blocks(self, keys, s, c):
+        """Archive (merged) blocks as the closed submap and start a fresh active one."""
+        import torch
+
+        torch.cuda.synchronize()
+        b = int(keys.numel())
+        _lib.check(self._lib.chad_map_close_submap_with_blocks_device(self._h, keys.data_ptr() if b else None, s.data_ptr() if b else None,
+                                                                      c.data_ptr() if b else None, b), "TSDFMap.close_submap_with_blocks")
+
+
+# ---- stage entry points (parity tests call the device through these) ---------------------------------
+def morton_codes(points, sdf_res: float) -> np.ndarray:
+    lib = _lib.load()
+    pts = _np_f32(points)
+    out = np.empty(pts.shape[0], dtype=np.uint64)
+    _lib.check(lib.chad_morton_codes(pts.ctypes.data, pts.shape[0], sdf_res, out.ctypes.data), "morton_codes")
+    return out
+
+
+def walk_rays(points, position, sdf_res: float, sdf_trunc: float, stride: int = 32):
+    lib = _lib.load()
+    pts = _np_f32(points)
+    pos = _np_f32(position).reshape(3)
+    vox = np.zeros((pts.shape[0], stride, 3), dtype=np.int32)
+    cnt = np.zeros(pts.shape[0], dtype=np.uint32)
+    _lib.check(lib.chad_walk_rays(pts.ctypes.data, pts.shape[0], pos.ctypes.data, sdf_res, sdf_trunc, vox.ctypes.data, cnt.ctypes.data, stride), "walk_rays")
+    return vox, cnt
+
+
+def decode_morton(mc: np.ndarray) -> np.ndarray:
+    """MortonCode::decode (morton.hpp:29-37) for an array of codes -> int32 [n,3] (host helper for save())."""
+    def compact(v):
+        v = v & np.uint64(0x1249249249249249)
+        v = (v | (v >> np.uint64(2))) & np.uint64(0x10C30C30C30C30C3)
+        v = (v | (v >> np.uint64(4))) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v >> np.uint64(8))) & np.uint64(0x001F0000FF0000FF)
+        v = (v | (v >> np.uint64(16))) & np.uint64(0x001F00000000FFFF)
+        v = (v | (v >> np.uint64(32))) & np.uint64(0x1FFFFF)
+        return (v.astype(np.int64) - (1 << 20)).astype(np.int32)
+
+    mc = np.asarray(mc, dtype=np.uint64)
+    return np.stack([compact(mc), compact(mc >> np.uint64(1)), compact(mc >> np.uint64(2))], axis=-1)

@@ -1,0 +1,131 @@
+/* chad_hip.h -- C ABI of the MI355X (gfx950) implementation of chad::TSDFMap::insert().
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Each entry point
+ * names the reference interface it replaces (paths relative to M2-TE/chad_tsdf @ 2025-07-25).
+ * The C++ class chad::TSDFMap in include/chad/tsdf.hpp is a thin pImpl over these calls, and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Threading contract (same as the reference: single-threaded, tsdf.hpp:21-171): one host thread per
+ * map at a time; distinct maps are independent.  All entry points return when the device work they
+ * enqueue has been submitted; chad_map_sync / export / stats / destroy are synchronisation points.
+ * No entry point ever calls exit() or abort(); failures come back as a chad_status and a message
+ * retrievable with chad_last_error().
+ */
+#ifndef CHAD_HIP_H
+#define CHAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct chad_map chad_map; /* opaque; replaces TSDFMap's private _active_octree_p/_active_submap_p/_submaps (tsdf.hpp:167-170) */
+
+typedef int32_t chad_status;
+enum {
+    CHAD_OK = 0,
+    CHAD_ERR_INVALID_ARG = 1, /* null handle/pointer, non-positive resolution, bad submap index */
+    CHAD_ERR_NO_DEVICE = 2,   /* no HIP device, or the gfx950 code object cannot be loaded (never falls back to a CPU path) */
+    CHAD_ERR_OUT_OF_MEMORY = 3, /* reference: std::runtime_error from mmap failure, virtual_array.cpp:16-20 */
+    CHAD_ERR_CAPACITY = 4,    /* block pool or block hash of the active submap is full; the frame was partially dropped */
+    CHAD_ERR_HIP = 5          /* any other HIP runtime failure */
+};
+
+/* Optional creation parameters (pass NULL for defaults).  Set struct_size = sizeof(chad_options). */
+typedef struct chad_options {
+    uint32_t struct_size;
+    int32_t device;      /* HIP device ordinal; -1 = the calling thread's current device */
+    uint64_t max_blocks; /* capacity of the active submap in 4x4x4-voxel blocks (520 B of HBM each); 0 = default (1<<21) */
+    uint64_t max_points; /* initial per-frame point capacity (grows on demand); 0 = default (1<<20) */
+    void* stream;        /* hipStream_t to enqueue on; NULL = a stream owned by the map */
+    uint32_t flags;      /* CHAD_FLAG_* */
+    uint32_t update_mode; /* CHAD_UPDATE_*; 0 = default */
+} chad_options;
+
+enum {
+    CHAD_FLAG_VERBOSE = 1u, /* print the reference's five stage-timer lines per insert (morton.hpp:78,100; normals.hpp:146; octree.hpp:169; tsdf.cpp:74) */
+    CHAD_FLAG_TIMING = 2u   /* record per-stage device times with HIP events on the map's stream (no extra synchronisation);
+                               chad_map_stats reports their mean over the inserts since the previous stats call (at most 64) */
+};
+enum {
+    CHAD_UPDATE_DEFAULT = 0,
+    CHAD_UPDATE_SCATTER = 1, /* per-voxel global atomics (general fallback) */
+    CHAD_UPDATE_TILED = 2    /* LDS-staged 12^3-voxel tiles per point block, coalesced flush */
+};
+
+/* Per-frame and per-map counters; filled by chad_map_stats (synchronises). */
+typedef struct chad_stats {
+    uint64_t frames;          /* inserts since creation */
+    uint64_t points_in;       /* points passed to the last insert */
+    uint64_t points_used;     /* of those, points kept (finite, not at the sensor position) */
+    uint64_t updates;         /* voxel updates of the last insert (U) */
+    uint64_t blocks;          /* live 4x4x4 blocks of the active submap (reference: _node_lookup.size(), octree.hpp:187) */
+    uint64_t block_capacity;
+    uint64_t hash_capacity;
+    uint64_t closed_submaps;  /* reference: _submaps.size(), tsdf.cpp:54 */
+    uint32_t sort_passes;     /* radix passes of the last insert */
+    uint32_t overflow;        /* non-zero once a capacity limit dropped updates */
+    /* mean device milliseconds per insert since the previous stats call, by the reference's stage names;
+       zero unless CHAD_FLAG_TIMING / CHAD_FLAG_VERBOSE */
+    float ms_mc_calc, ms_mc_sort, ms_norm_est, ms_oct_upd, ms_total;
+} chad_stats;
+
+/* TSDFMap::TSDFMap(float sdf_res = 0.05f, float sdf_trunc = 0.1f)  -- tsdf.hpp:29, tsdf.cpp:27-31 */
+chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* options, chad_map** out);
+/* TSDFMap::~TSDFMap()  -- tsdf.cpp:32-38 */
+void chad_map_destroy(chad_map* map);
+
+/* TSDFMap::insert(const float* points_p, size_t points_count, const float* position_p)  -- tsdf.hpp:50-57 -> tsdf.cpp:39-75.
+ * xyz: points_count packed x,y,z triples in HOST memory, borrowed for the duration of the call. */
+chad_status chad_map_insert(chad_map* map, const float* xyz, size_t points_count, const float position[3]);
+/* Same, with the points already resident in DEVICE memory of the map's device (no PCIe copy). */
+chad_status chad_map_insert_device(chad_map* map, const float* xyz_device, size_t points_count, const float position[3]);
+
+/* Wait for all enqueued work of this map; reports CHAD_ERR_CAPACITY if any update was dropped. */
+chad_status chad_map_sync(chad_map* map);
+/* Octree::clear() on the active submap and forget its poses and all closed submaps  -- octree.hpp:22-29 */
+chad_status chad_map_reset(chad_map* map);
+
+/* The submap hand-over of TSDFMap::save (tsdf.cpp:78-81): if the active submap holds at least one pose it is
+ * archived as a closed submap and a fresh one is started (same effect as the 5 m roll-over of tsdf.cpp:52-57). */
+chad_status chad_map_close_submap(chad_map* map);
+
+/* Read-back extension (the reference's iterator API is commented out, tsdf.hpp:120-161).
+ * submap < 0: the active submap; 0..closed-1: a submap closed by the 5 m roll-over rule (tsdf.cpp:52-58).
+ * Leaves are the voxels with weight > 0, sorted by Morton code ascending: mc as MortonCode::_value
+ * (morton.hpp:21-28), sd as Leaf::_signed_distance, w as Leaf::_weight (octree.hpp:15). */
+chad_status chad_map_leaf_count(chad_map* map, int32_t submap, size_t* count);
+chad_status chad_map_export_leaves(chad_map* map, int32_t submap, uint64_t* mc, float* sd, uint32_t* w, size_t capacity, size_t* count);
+chad_status chad_map_stats(chad_map* map, chad_stats* out);
+
+/* Multi-GPU merge support: per-block partial sums of a submap, on the DEVICE, sorted by block key
+ * (key = MortonCode & ~63, the reference's lookup key, octree.hpp:33-36).  sum[b*64+v] is the sum of
+ * the clamped signed distances observed by voxel v of block b, cnt[b*64+v] their count, so partials of
+ * different GPUs combine by addition (the reference's update is a mean of unit-weight observations,
+ * octree.hpp:161-163). */
+chad_status chad_map_block_count(chad_map* map, int32_t submap, size_t* blocks);
+chad_status chad_map_export_blocks_device(chad_map* map, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks);
+/* Close the active submap as if a roll-over happened, replacing its content by the given (merged) blocks. */
+chad_status chad_map_close_submap_with_blocks_device(chad_map* map, const uint64_t* keys_device, const float* sum_device, const uint32_t* cnt_device, size_t blocks);
+
+/* Stage read-back for parity tests: intermediates of the LAST insert, copied to host.
+ * order[i]: input index of the i-th point in processing order; mc[i]: its Morton code; normals: 3 floats per point.
+ * Any pointer may be NULL. */
+chad_status chad_map_last_frame(chad_map* map, uint32_t* order, uint64_t* mc, float* normals, size_t capacity, size_t* count);
+/* Stage entry for parity tests: the voxel traversal of octree.hpp:86-152 for n rays (host in/out).
+ * voxels: n*stride*3 int32, counts: n. */
+chad_status chad_walk_rays(const float* xyz, size_t n, const float position[3], float sdf_res, float sdf_trunc, int32_t* voxels, uint32_t* counts, size_t stride);
+/* Stage entry for parity tests: MortonCode::encode of calc_morton_vector (morton.hpp:59-80) for n host points. */
+chad_status chad_morton_codes(const float* xyz, size_t n, float sdf_res, uint64_t* mc);
+
+/* Thread-local message of the last failure on this thread ("" if none). */
+const char* chad_last_error(void);
+/* Library/build identification, e.g. "chad_hip 0.1 gfx950". */
+const char* chad_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHAD_HIP_H */

@@ -22,8 +22,10 @@
 // Deviations from the reference, all where the reference has undefined behaviour:
 //   D1 (Q3) normals.hpp:100-101 reads one element past the end while grouping the last sorted point;
 //      here that comparison counts as a mismatch, so the last point always gets the fallback normal.
-//   D2 (Q5) a point equal to the sensor position, or with a non-finite coordinate, makes
-//      octree.hpp:92-97 convert NaN to int; such points are dropped before Morton encoding.
+//   D2 (Q5) a point whose ray direction normalize(p - position) is not finite (the point equals the sensor
+//      position, has a non-finite coordinate, or overflows) makes octree.hpp:92-97 convert NaN to int, and a
+//      point beyond 2^30 voxels overflows the int conversion of morton.hpp:73; such points are dropped
+//      before Morton encoding.
 //   D3 (Q2) std::sort leaves the order of equal codes unspecified (morton.hpp:89); here ties are
 //      ordered by ascending input index, which is one of the orders std::sort may produce.
 #include <algorithm>
@@ -99,7 +101,12 @@ inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 struct PointMc { V3 p; uint32_t idx; uint64_t mc; };
 static_assert(sizeof(PointMc) == 24, "same footprint as the reference's sort element");
 
-inline bool finite3(const float* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+inline bool point_usable(const float* p, const float* pos, float recip) {  // D2
+    const V3 d = normalize(V3{p[0], p[1], p[2]} - V3{pos[0], pos[1], pos[2]});
+    const float lim = 1073741824.0f;  // 2^30 voxels
+    return std::isfinite(d.x) && std::isfinite(d.y) && std::isfinite(d.z) &&
+           std::fabs(p[0] * recip) < lim && std::fabs(p[1] * recip) < lim && std::fabs(p[2] * recip) < lim;
+}
 
 // morton.hpp:59-80
 void calc_morton_vector(const float* xyz, size_t n, const float pos[3], float sdf_res, std::vector<PointMc>& out) {
@@ -108,7 +115,7 @@ void calc_morton_vector(const float* xyz, size_t n, const float pos[3], float sd
     out.reserve(n);
     for (size_t i = 0; i < n; i++) {
         const float* p = xyz + 3 * i;
-        if (!finite3(p) || (p[0] == pos[0] && p[1] == pos[1] && p[2] == pos[2])) continue;  // D2
+        if (!point_usable(p, pos, recip)) continue;  // D2
         float fx = std::floor(p[0] * recip), fy = std::floor(p[1] * recip), fz = std::floor(p[2] * recip);  // :71
         out.push_back({{p[0], p[1], p[2]}, uint32_t(i), morton_encode(int32_t(fx), int32_t(fy), int32_t(fz))});  // :73
     }

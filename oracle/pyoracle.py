@@ -75,8 +75,8 @@ class OracleMap:
         self.res, self.trunc = res, trunc
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().oracle_map_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oracle_map_destroy(self._h)
             self._h = None
 
     def insert(self, points, position):

@@ -1,0 +1,25 @@
+"""Shared helpers of the parity tests."""
+import numpy as np
+
+SD_TOL = 1e-4  # north_star: per-voxel SDF within 1e-4 relative, with the truncation distance as the scale floor
+
+
+def assert_leaves_match(got, want, trunc, tol=SD_TOL):
+    """Leaf sets (codes) and weights bit-exact; sd within tol * max(|sd_ref|, trunc)."""
+    gmc, gsd, gw = got
+    wmc, wsd, ww = want
+    assert gmc.shape == wmc.shape, f"leaf count {gmc.shape[0]} != {wmc.shape[0]}"
+    assert np.array_equal(gmc, wmc), "Morton codes of the leaf sets differ"
+    assert np.array_equal(gw, ww), f"weights differ at {np.flatnonzero(gw != ww)[:5]}"
+    nan_g, nan_w = np.isnan(gsd), np.isnan(wsd)
+    assert np.array_equal(nan_g, nan_w), "NaN signed distances (degenerate neighbourhoods) differ"
+    ok = ~nan_w
+    err = np.abs(gsd[ok].astype(np.float64) - wsd[ok]) / np.maximum(np.abs(wsd[ok]), trunc)
+    assert err.size == 0 or err.max() <= tol, f"sd error {err.max():.3g} > {tol}"
+    return 0.0 if err.size == 0 else float(err.max())
+
+
+def by_input_index(order, values, n):
+    out = np.full((n,) + values.shape[1:], np.nan, dtype=values.dtype)
+    out[order] = values
+    return out
