@@ -8,6 +8,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -64,6 +65,7 @@ struct chad_map {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint32_t flags = 0, update_mode = CHAD_UPDATE_TILED;
+    uint32_t ablate = 0;  // CHAD_DEBUG_ABLATE: timing experiments only
 
     MapView view{};
     uint32_t hash_capacity = 0, brick_capacity = 0;
@@ -113,7 +115,8 @@ inline dim3 grid_for(size_t n, int threads = 256, int max_blocks = 2048) {
 
 void free_frame_buffers(chad_map* m) {
     (void)hipFree(m->d_xyz); (void)hipFree(m->sort.keys[0]); (void)hipFree(m->sort.keys[1]);
-    (void)hipFree(m->sort.idx[0]); (void)hipFree(m->sort.idx[1]); (void)hipFree(m->sort.tile_hist);
+    (void)hipFree(m->sort.idx[0]); (void)hipFree(m->sort.idx[1]); (void)hipFree(m->sort.hist_part);
+    (void)hipFree(m->sort.digit_base); (void)hipFree(m->sort.tile_status);
     (void)hipFree(m->d_pts); (void)hipFree(m->d_codes); (void)hipFree(m->d_normals); (void)hipFree(m->d_seg);
     m->d_xyz = nullptr; m->sort = RadixSortBuffers{}; m->d_pts = nullptr; m->d_codes = nullptr; m->d_normals = nullptr; m->d_seg = nullptr;
     m->cap_points = 0;
@@ -130,7 +133,10 @@ chad_status ensure_frame_capacity(chad_map* m, size_t n) {
         HIP_TRY(hipMalloc(&m->sort.keys[i], cap * 8));
         HIP_TRY(hipMalloc(&m->sort.idx[i], cap * 4));
     }
-    HIP_TRY(hipMalloc(&m->sort.tile_hist, size_t(kRadix) * radix_tiles(cap) * 4));
+    HIP_TRY(hipMalloc(&m->sort.hist_part, size_t(kHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(hipMalloc(&m->sort.digit_base, size_t(kMaxPasses) * kRadix * 4));
+    HIP_TRY(hipMalloc(&m->sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
+    m->sort.tiles_capacity = radix_tiles(cap);
     HIP_TRY(hipMalloc(&m->d_pts, cap * 16));
     HIP_TRY(hipMalloc(&m->d_codes, cap * 8));
     HIP_TRY(hipMalloc(&m->d_normals, cap * 16));
@@ -248,7 +254,7 @@ void collect_timing(chad_map* m) {
 
 // tsdf.cpp:39-75 with the points already on the device
 chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float position[3]) {
-    if (n > 0xfffffff0ull) return fail(CHAD_ERR_INVALID_ARG, "more than 2^32 points in one frame");
+    if (n >= (1ull << 30)) return fail(CHAD_ERR_INVALID_ARG, "more than 2^30 points in one frame");
     // submap bookkeeping, tsdf.cpp:46-61 (f32 distance in the reference's operation order; this file is built
     // with -ffp-contract=off)
     const std::array<float, 3> pose{position[0], position[1], position[2]};
@@ -272,16 +278,16 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
         hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_part);
         hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0]);
         record(m, T_CALC);
-        radix_sort_enqueue(m->sort, count, 64 / kRadixBits, &m->d_hdr->sort_passes, m->stream);
+        radix_sort_enqueue(m->sort, count, kMaxPasses, &m->d_hdr->sort_passes, m->stream);
         hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, m->recip, m->d_hdr, m->d_part, m->sort.keys[0], m->sort.keys[1],
                            m->sort.idx[0], m->sort.idx[1], m->d_pts, m->d_codes, m->d_seg, item_start);
         record(m, T_SORT);
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * 8), dim3(64 * kNormalWavesPerBlock), 0, m->stream, m->d_pts, m->d_codes, m->d_seg, m->d_seg + m->cap_points, m->d_hdr, pos, m->d_normals);
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * 24), dim3(64 * kNormalWavesPerBlock), 0, m->stream, m->d_pts, m->d_codes, m->d_seg, m->d_seg + m->cap_points, m->d_hdr, pos, m->d_normals, m->ablate);
         record(m, T_NORM);
         if (m->update_mode == CHAD_UPDATE_SCATTER)
             hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, m->d_pts, m->d_normals, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view);
         else
-            tile_update_enqueue(m->d_pts, m->d_normals, m->d_codes, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream);
+            tile_update_enqueue(m->d_pts, m->d_normals, m->d_codes, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, m->ablate);
         record(m, T_UPD);
     } else {
         record(m, T_CALC); record(m, T_SORT); record(m, T_NORM); record(m, T_UPD);
@@ -335,6 +341,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->recip = float(1.0 / double(sdf_res));  // morton.hpp:63, octree.hpp:82
     m->device = dev; m->flags = o.flags;
     m->update_mode = o.update_mode ? o.update_mode : CHAD_UPDATE_TILED;
+    if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
     auto bail = [&](chad_status s) { chad_map_destroy(m); return s; };
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
@@ -503,7 +510,7 @@ chad_status chad_map_export_blocks_device(chad_map* m, int32_t submap, uint64_t*
     TRY(ensure_frame_capacity(m, nb));
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
     hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->sort.keys[0], nb);
-    radix_sort_enqueue(m->sort, nb, 64 / kRadixBits, nullptr, m->stream);
+    radix_sort_enqueue(m->sort, nb, kMaxPasses, nullptr, m->stream);
     hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->sort.idx[0], nb, keys, sum, cnt, keys_device, sum_device, cnt_device);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));

@@ -268,36 +268,27 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
 
 // ---- Stage 4: normals (normals.hpp:10-148) -------------------------------------------------------------------
 // One wave per point block.  The block's <= 64 voxel runs are counted into LDS, the greedy neighbourhood walk
-// runs over those 64 counters (not over the points), then lane g fits neighbourhood g with the reference's
-// two-pass f64 "plane from points" in the reference's summation order, and every point picks up its
-// neighbourhood's normal (or the per-point fallback when the neighbourhood has < 8 points).
+// runs over those 64 counters (not over the points), then the neighbourhoods are fitted with the reference's
+// two-pass f64 "plane from points" -- small ones by one lane each in the reference's summation order, large ones
+// by the whole wave -- and every point picks up its neighbourhood's normal (or the per-point fallback when the
+// neighbourhood has < 8 points).
 
-constexpr uint32_t kMinPoints = 8;  // normals.hpp:88
+constexpr uint32_t kMinPoints = 8;    // normals.hpp:88
+constexpr uint32_t kStagePoints = 256;  // points of a block kept in LDS for the fits (4 KiB)
+constexpr uint32_t kCoopPoints = 48;    // neighbourhoods at least this large are fitted by the whole wave
 
 struct NormalScratch {         // per wave, in LDS
     uint32_t count[64];        // points per voxel of the block (index = low 6 code bits)
-    uint32_t tail[65];         // tail[v] = points in voxels >= v  (tail[64] = 0)
     uint32_t group_of[64];     // neighbourhood of voxel v
     uint32_t g_first[64];      // first point (offset in the segment) of neighbourhood g
     uint32_t g_size[64];
     float g_normal[64][4];     // fitted normal; [3] != 0 marks "fit" (else per-point fallback)
+    float4 stage[kStagePoints];  // the block's first points (x, y, z, input index)
 };
 
-__device__ __forceinline__ F3 fit_plane(const float4* __restrict__ pts, uint32_t count) {
-    // normals.hpp:12-17 centroid
-    double cx = 0, cy = 0, cz = 0;
-    for (uint32_t k = 0; k < count; k++) { const float4 q = pts[k]; cx += double(q.x); cy += double(q.y); cz += double(q.z); }
-    const double recip = 1.0 / double(count);
-    cx *= recip; cy *= recip; cz *= recip;
-    // :20-36 covariance
-    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-    for (uint32_t k = 0; k < count; k++) {
-        const float4 q = pts[k];
-        const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
-        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
-    }
-    xx *= recip; xy *= recip; xz *= recip; yy *= recip; yz *= recip; zz *= recip;
-    // :39-76 determinant-weighted axis directions, each aligned with the running sum
+// normals.hpp:39-79 -- normal from the covariance terms: three determinant-weighted axis directions, each aligned
+// with the running sum, then normalised in f64 and cast to f32.
+__device__ __forceinline__ F3 plane_from_covariance(double xx, double xy, double xz, double yy, double yz, double zz) {
     double wx = 0, wy = 0, wz = 0;
     {
         const double det = yy * zz - yz * yz, ax = det, ay = xz * yz - xy * zz, az = xy * yz - xz * yy;
@@ -321,77 +312,160 @@ __device__ __forceinline__ F3 fit_plane(const float4* __restrict__ pts, uint32_t
     return {float(wx * inv), float(wy * inv), float(wz * inv)};
 }
 
+// One lane fits one neighbourhood, summing in the reference's order (normals.hpp:12-36): bit-identical moments.
+// `pts` may point into LDS (staged block) or HBM.
+template <class Ptr>
+__device__ __forceinline__ F3 fit_plane(Ptr pts, uint32_t count) {
+    double cx = 0, cy = 0, cz = 0;
+    for (uint32_t k = 0; k < count; k++) { const float4 q = pts[k]; cx += double(q.x); cy += double(q.y); cz += double(q.z); }
+    const double recip = 1.0 / double(count);
+    cx *= recip; cy *= recip; cz *= recip;
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        const float4 q = pts[k];
+        const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
+        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+    }
+    return plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// The whole wave fits one LARGE neighbourhood (a dense voxel near the sensor holds hundreds of points): lanes
+// stride over the points with coalesced 16-byte loads and the nine f64 moments are combined by butterfly
+// reductions.  The summation order differs from the reference's sequential loop, i.e. results agree to f64
+// rounding (~1e-16 relative), far inside the 1e-4 bar.  Every lane returns the same normal.
+template <class Ptr>
+__device__ __forceinline__ F3 fit_plane_wave(Ptr pts, uint32_t count, uint32_t lane) {
+    double cx = 0, cy = 0, cz = 0;
+    for (uint32_t k = lane; k < count; k += 64) { const float4 q = pts[k]; cx += double(q.x); cy += double(q.y); cz += double(q.z); }
+    const double recip = 1.0 / double(count);
+    cx = wave_sum_f64(cx) * recip; cy = wave_sum_f64(cy) * recip; cz = wave_sum_f64(cz) * recip;
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (uint32_t k = lane; k < count; k += 64) {
+        const float4 q = pts[k];
+        const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
+        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+    }
+    xx = wave_sum_f64(xx); xy = wave_sum_f64(xy); xz = wave_sum_f64(xz);
+    yy = wave_sum_f64(yy); yz = wave_sum_f64(yz); zz = wave_sum_f64(zz);
+    return plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
+}
+
+// Length of the run of points of `block` starting at `first` (codes sorted by block), capped at `limit`.
+// Two dependent loads instead of one per 64 points: lanes first probe the starts of the next 64 chunks of 64
+// points, then the points of the chunk where the run ends.  Wave-uniform result.
+__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ codes, uint32_t first, uint32_t limit, uint64_t block, uint32_t lane) {
+    uint32_t len = 0;
+    for (;;) {
+        const uint32_t probe = first + len + 64u * (lane + 1u);                 // first point of chunk lane+1
+        const uint64_t more = __ballot(probe < limit && (codes[probe] >> 6) == block);
+        const uint32_t full = more == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~more)) - 1u;  // chunks 1..full start inside the run
+        len += 64u * full;
+        if (full == 64u) continue;                                               // the run is longer than 4160 points: go on
+        const uint32_t i = first + len + lane;                                   // the chunk where the run ends
+        const uint64_t same = __ballot(i < limit && (codes[i] >> 6) == block);
+        return len + (same == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~same)) - 1u);
+    }
+}
+
 constexpr int kNormalWavesPerBlock = 1;  // one wave per workgroup: __syncthreads() is then a wave-local LDS fence
+
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 
 __global__ void __launch_bounds__(64 * kNormalWavesPerBlock)
 k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ seg_start,
-                uint32_t* __restrict__ seg_len, FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals) {
-    __shared__ NormalScratch scratch[kNormalWavesPerBlock];
-    NormalScratch& s = scratch[threadIdx.x >> 6];
+                uint32_t* __restrict__ seg_len, FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
+    __shared__ NormalScratch s;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = h->n_usable, nseg = h->n_segments;
-    const uint32_t wave_global = blockIdx.x * kNormalWavesPerBlock + (threadIdx.x >> 6);
-    const uint32_t wave_total = gridDim.x * kNormalWavesPerBlock;
     const uint64_t last_block = h->mc_min >> 6;
 
-    for (uint32_t seg = wave_global; seg < nseg; seg += wave_total) {
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
         const uint32_t first = seg_start[seg];
         const uint64_t block = codes[first] >> 6;
-        // length of the segment: scan forward to the first point of another block
-        uint32_t len = 0;
-        for (;;) {
-            const uint32_t i = first + len + lane;
-            const bool same = i < n && (codes[i] >> 6) == block;
-            const uint64_t m = __ballot(same);
-            if (m == ~0ull) { len += 64; continue; }
-            len += uint32_t(__ffsll((unsigned long long)~m)) - 1u;
-            break;
-        }
+        const uint32_t len = run_length(codes, first, n, block, lane);
         if (lane == 0) seg_len[seg] = len;
         // normals.hpp:100 -- the frame's last point never joins a neighbourhood; it is the last point of this segment
         const bool holds_last = block == last_block;
         const uint32_t grouped = holds_last ? len - 1 : len;
 
+        // pass 1 over the block: voxel histogram in LDS, first kStagePoints points staged in LDS
         s.count[lane] = 0;
         __syncthreads();
-        for (uint32_t k = lane; k < grouped; k += 64) atomicAdd(&s.count[uint32_t(codes[first + k]) & 63u], 1u);
-        __syncthreads();
-        {   // tail[v] = sum of count[v..63]: inclusive scan over lanes holding voxels 63, 62, ...
-            uint32_t c = s.count[63 - lane];
+        for (uint32_t k0 = 0; k0 < len; k0 += 256) {  // four points per lane and trip: their loads overlap
+            uint32_t v[4];
+            float4 q[4];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(c, o); if (int(lane) >= o) c += t; }
-            s.tail[63 - lane] = c;
-            if (lane == 0) s.tail[64] = 0;
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k = k0 + 64u * u + lane;
+                v[u] = k < grouped ? uint32_t(codes[first + k]) & 63u : 64u;
+                if (k < len && k < kStagePoints) q[u] = pts[first + k];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k = k0 + 64u * u + lane;
+                if (v[u] < 64u) atomicAdd(&s.count[v[u]], 1u);
+                if (k < len && k < kStagePoints) s.stage[k] = q[u];
+            }
         }
         __syncthreads();
-        // greedy walk (normals.hpp:86-138) over the voxel runs, identical in every lane
-        uint32_t ngroups = 0;
-        for (int v = 63; v >= 0;) {
-            if (s.count[v] == 0) { v--; continue; }
-            const uint32_t start = s.tail[v + 1];  // points in higher voxels come first
-            uint32_t size = s.count[v];
-            int lowest = v;                               // lowest voxel taken into the neighbourhood
-            if (size < kMinPoints) {                      // depth 1: the rest of the 2x2x2 octant
-                lowest = v & ~7;
-                size = s.tail[lowest] - s.tail[v + 1];
-                if (size < kMinPoints) {                  // depth 2: the rest of the block
-                    lowest = 0;
-                    size = s.tail[0] - s.tail[v + 1];
+
+        // greedy neighbourhood walk (normals.hpp:86-138) over the voxel runs, in registers: lane l holds voxel 63 - l,
+        // the order the points are in.  before = points in higher voxels, upto = before + own.
+        const uint32_t own = s.count[63 - lane];
+        uint32_t upto = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(upto, o); if (int(lane) >= o) upto += t; }
+        const uint32_t before = upto - own;
+        uint64_t rest = (ablate & 64u) ? 0ull : __ballot(own != 0);  // voxel runs not yet in a neighbourhood
+        uint32_t ngroups = 0, my_group = 0;
+        while (rest) {
+            const uint32_t l = uint32_t(__ffsll((unsigned long long)rest)) - 1u;  // highest remaining voxel
+            const uint32_t start = read_lane(before, l);
+            uint32_t size = read_lane(own, l);
+            uint32_t l_end = l;                            // lane of the lowest voxel taken into the neighbourhood
+            if (size < kMinPoints) {                       // depth 1: the rest of the 2x2x2 octant (voxel & ~7)
+                l_end = l | 7u;
+                size = read_lane(upto, l_end) - start;
+                if (size < kMinPoints) {                   // depth 2: the rest of the block
+                    l_end = 63u;
+                    size = read_lane(upto, 63u) - start;
                 }
             }
             if (lane == 0) { s.g_first[ngroups] = start; s.g_size[ngroups] = size; }
-            if (int(lane) >= lowest && int(lane) <= v) s.group_of[lane] = ngroups;
+            if (lane >= l && lane <= l_end) my_group = ngroups;
             ngroups++;
-            v = lowest - 1;
+            rest = l_end == 63u ? 0ull : rest & ~((2ull << l_end) - 1ull);
         }
+        s.group_of[63 - lane] = my_group;
         __syncthreads();
-        if (lane < ngroups) {
+
+        // large neighbourhoods: the whole wave, one after the other (wave-uniform loop)
+        for (uint32_t g = 0; g < ((ablate & 8u) ? 0u : ngroups); g++) {
+            const uint32_t g0 = s.g_first[g], gn = s.g_size[g];
+            if (gn < kCoopPoints) continue;
+            F3 nrm = g0 + gn <= kStagePoints ? fit_plane_wave(&s.stage[g0], gn, lane) : fit_plane_wave(pts + first + g0, gn, lane);
+            if (lane == 0) {
+                const float4 q = pts[first + g0];
+                const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
+                if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
+                s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
+            }
+        }
+        // small neighbourhoods: one lane each, in the reference's summation order
+        if (lane < ngroups && s.g_size[lane] < kCoopPoints) {
             const uint32_t g0 = s.g_first[lane], gn = s.g_size[lane];
             float fit = 0.0f;
             F3 nrm{0, 0, 0};
-            if (gn >= kMinPoints) {
-                nrm = fit_plane(pts + first + g0, gn);
-                const float4 q = pts[first + g0];
+            if (gn >= kMinPoints && !(ablate & 16u)) {
+                const bool staged = g0 + gn <= kStagePoints;
+                nrm = staged ? fit_plane(&s.stage[g0], gn) : fit_plane(pts + first + g0, gn);
+                const float4 q = staged ? s.stage[g0] : pts[first + g0];
                 const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
                 if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
                 fit = 1.0f;
@@ -399,17 +473,28 @@ k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ cod
             s.g_normal[lane][0] = nrm.x; s.g_normal[lane][1] = nrm.y; s.g_normal[lane][2] = nrm.z; s.g_normal[lane][3] = fit;
         }
         __syncthreads();
-        for (uint32_t k = lane; k < len; k += 64) {
-            const float4 q = pts[first + k];
-            F3 nrm;
-            bool fitted = false;
-            if (k < grouped) {
-                const uint32_t g = s.group_of[uint32_t(codes[first + k]) & 63u];
-                fitted = s.g_normal[g][3] != 0.0f;
-                nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
+        for (uint32_t k0 = 0; k0 < ((ablate & 32u) ? 0u : len); k0 += 256) {  // four points per lane and trip
+            float4 q[4];
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k = k0 + 64u * u + lane;
+                if (k < len) { q[u] = k < kStagePoints ? s.stage[k] : pts[first + k]; v[u] = uint32_t(codes[first + k]) & 63u; }
             }
-            if (!fitted) nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
-            normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k = k0 + 64u * u + lane;
+                if (k >= len) continue;
+                F3 nrm;
+                bool fitted = false;
+                if (k < grouped) {
+                    const uint32_t g = s.group_of[v[u]];
+                    fitted = s.g_normal[g][3] != 0.0f;
+                    nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
+                }
+                if (!fitted) nrm = unit3(sub3(pos, F3{q[u].x, q[u].y, q[u].z}));  // normals.hpp:130
+                normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+            }
         }
         __syncthreads();
     }

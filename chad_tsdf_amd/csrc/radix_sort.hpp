@@ -1,11 +1,17 @@
-// radix_sort.hpp -- stable LSD radix sort of (u64 key, u32 payload) pairs for gfx950, ascending.
+// radix_sort.hpp -- stable LSD radix sort of (u64 key, u32 payload) pairs for gfx950, ascending ("onesweep").
 //
-// Replaces std::sort in sort_morton_vector (morton.hpp:81-102).  Stable, so equal keys keep their input
-// order (the deterministic tie order D3 of the oracle).  8-bit digits; one pass =
-//   tile_histogram (LDS digit histogram per 256-thread tile)
-//   -> scan_histograms (exclusive scan of the digit-major [256][tiles] table)
-//   -> scatter (wave64 ballot ranking inside each wave, per-wave digit counters in LDS across waves).
-// Only the digits that can differ are sorted: the caller passes the number of significant key bits.
+// Replaces std::sort in sort_morton_vector (morton.hpp:81-102).  Stable, so equal keys keep their input order
+// (the deterministic tie order D3 of the oracle).  8-bit digits.  Per sort:
+//   k_radix_histograms  one read of the keys: digit histograms of ALL passes at once (LDS atomics), one partial
+//                       table per workgroup (no global atomics);
+//   k_radix_bases       sums the partials and scans the 256 digits of each pass -> first output slot of each digit;
+//   k_radix_onesweep    ONE kernel per pass: a workgroup ranks its tile (wave64 ballot matching inside a wave,
+//                       per-wave digit counters in LDS across waves), learns how many keys of each digit precede
+//                       its tile from its predecessors' published counts (decoupled look-back over 32-bit
+//                       {flag, count} words, so no separate payload needs release/acquire ordering), reorders the
+//                       tile in LDS and writes runs of equal digits to consecutive addresses.
+// The number of passes is data dependent (key width of the frame) and lives in device memory: the host enqueues
+// the maximum and surplus passes return at once, so no host round trip sits between the stages of a frame.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,10 +20,16 @@ namespace chadhip {
 
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
+constexpr int kMaxPasses = 64 / kRadixBits;
 constexpr int kSortThreads = 256;                       // 4 waves
 constexpr int kSortItems = 8;                           // keys per thread
 constexpr int kSortTile = kSortThreads * kSortItems;    // 2048 keys per workgroup
 constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kHistBlocks = 256;                        // workgroups of the histogram kernel (one partial table each)
+
+constexpr uint32_t kStatusAggregate = 1u << 30;         // the tile's own digit counts are published
+constexpr uint32_t kStatusInclusive = 2u << 30;         // counts of this tile AND all tiles before it
+constexpr uint32_t kStatusValue = (1u << 30) - 1;
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -27,76 +39,105 @@ __device__ __forceinline__ size_t tile_index(uint32_t tile, uint32_t wave, uint3
     return size_t(tile) * kSortTile + wave * (64 * kSortItems) + j * 64 + lane;
 }
 
-// If *pass_limit (device memory) <= pass, the pass is a no-op: lets the host enqueue a fixed number of passes
-// without knowing how many key bits the frame needs.  pass_limit may be null.
+struct RadixSortBuffers {
+    uint64_t* keys[2];
+    uint32_t* idx[2];
+    uint32_t* hist_part;    // [kHistBlocks][kMaxPasses][256] partial digit histograms
+    uint32_t* digit_base;   // [kMaxPasses][256] first output slot of each digit
+    uint32_t* tile_status;  // [kMaxPasses][tiles][256] look-back words, zeroed before every sort
+    uint32_t* tile_ticket;  // [kMaxPasses] next tile to hand out, zeroed with tile_status (stored right behind it)
+    uint32_t tiles_capacity;
+};
+
+inline uint32_t radix_tiles(size_t n) { return uint32_t((n + kSortTile - 1) / kSortTile); }
+inline size_t radix_status_words(uint32_t tiles) { return size_t(kMaxPasses) * tiles * kRadix + 64; }
+
+// pass_limit (device word, may be null): passes >= *pass_limit are skipped by every kernel.
 __global__ void __launch_bounds__(kSortThreads)
-k_radix_tile_histogram(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t ntiles,
-                       uint32_t* __restrict__ tile_hist, const uint32_t* __restrict__ pass_limit, uint32_t pass) {
-    if (pass_limit && pass >= *pass_limit) return;
-    __shared__ uint32_t hist[kRadix];
-    hist[threadIdx.x] = 0;
+k_radix_histograms(const uint64_t* __restrict__ keys, uint32_t n, uint32_t passes, const uint32_t* __restrict__ pass_limit,
+                   uint32_t* __restrict__ hist_part) {
+    __shared__ uint32_t hist[kMaxPasses][kRadix];
+    const uint32_t active = pass_limit ? min(passes, *pass_limit) : passes;
+    for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += kSortThreads) (&hist[0][0])[k] = 0;
     __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (uint32_t j = 0; j < kSortItems; j++) {
-        const size_t i = tile_index(blockIdx.x, wave, j, lane);
-        if (i < n) atomicAdd(&hist[uint32_t(keys[i] >> shift) & (kRadix - 1)], 1u);
+    for (size_t i = size_t(blockIdx.x) * kSortThreads + threadIdx.x; i < n; i += size_t(gridDim.x) * kSortThreads) {
+        const uint64_t key = keys[i];
+        for (uint32_t p = 0; p < active; p++) atomicAdd(&hist[p][uint32_t(key >> (p * kRadixBits)) & (kRadix - 1)], 1u);
     }
     __syncthreads();
-    tile_hist[size_t(threadIdx.x) * ntiles + blockIdx.x] = hist[threadIdx.x];  // digit-major
+    for (uint32_t p = 0; p < active; p++) hist_part[(size_t(blockIdx.x) * kMaxPasses + p) * kRadix + threadIdx.x] = hist[p][threadIdx.x];
 }
 
-// Exclusive scan of `count` counters in place by ONE workgroup of 1024 threads (count = 256 * tiles).
-__global__ void __launch_bounds__(1024)
-k_radix_scan(uint32_t* __restrict__ data, uint32_t count, const uint32_t* __restrict__ pass_limit, uint32_t pass) {
-    if (pass_limit && pass >= *pass_limit) return;
-    __shared__ uint32_t partial[1024];
-    const uint32_t per = (count + 1023) / 1024;
-    const uint32_t beg = threadIdx.x * per;
-    const uint32_t end = beg + per < count ? beg + per : count;
-    uint32_t sum = 0;
-    for (uint32_t i = beg; i < end; i++) sum += data[i];
-    partial[threadIdx.x] = sum;
+// One workgroup per pass: digit_base[p][d] = number of keys whose digit of pass p is < d.  1024 threads: four
+// slices of the kHistBlocks partial tables per digit, so the loads (independent, coalesced over digits) overlap.
+__global__ void __launch_bounds__(4 * kRadix)
+k_radix_bases(const uint32_t* __restrict__ hist_part, uint32_t hist_blocks, uint32_t passes, const uint32_t* __restrict__ pass_limit,
+              uint32_t* __restrict__ digit_base) {
+    const uint32_t p = blockIdx.x;
+    const uint32_t active = pass_limit ? min(passes, *pass_limit) : passes;
+    if (p >= active) return;
+    __shared__ uint32_t slice_sum[4][kRadix];
+    __shared__ uint32_t wave_total[kRadix / 64];
+    const uint32_t d = threadIdx.x & (kRadix - 1), slice = threadIdx.x >> kRadixBits;
+    uint32_t count = 0;
+    const uint32_t per = (hist_blocks + 3) / 4;
+    const uint32_t b0 = slice * per, b1 = min(hist_blocks, b0 + per);
+#pragma unroll 8
+    for (uint32_t b = b0; b < b1; b++) count += hist_part[(size_t(b) * kMaxPasses + p) * kRadix + d];
+    slice_sum[slice][d] = count;
     __syncthreads();
-    // Hillis-Steele over the 1024 partials
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = partial[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
-    for (uint32_t i = beg; i < end; i++) {
-        const uint32_t v = data[i];
-        data[i] = run;
-        run += v;
-    }
+    if (slice != 0) return;
+    count = slice_sum[0][d] + slice_sum[1][d] + slice_sum[2][d] + slice_sum[3][d];
+    const uint32_t lane = d & 63, wave = d >> 6;
+    uint32_t incl = count;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (int(lane) >= o) incl += t; }
+    if (lane == 63) wave_total[wave] = incl;
+    // only the first four waves (slice 0) are left: a named barrier is not needed, they sync through LDS after the
+    // other waves have exited (exited waves do not take part in s_barrier)
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; w++) before += wave_total[w];
+    digit_base[p * kRadix + d] = before + incl - count;
 }
 
 // idx_in may be null: the payload is then the element's own position (first pass).
 __global__ void __launch_bounds__(kSortThreads)
-k_radix_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
-                uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
-                uint32_t n, uint32_t shift, uint32_t ntiles, const uint32_t* __restrict__ tile_offset,
-                const uint32_t* __restrict__ pass_limit, uint32_t pass) {
+k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                 uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                 uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
+                 uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit) {
     if (pass_limit && pass >= *pass_limit) return;
-    __shared__ uint32_t wave_count[kSortWaves][kRadix];  // then: exclusive base of (wave, digit) in the output
-    for (uint32_t k = threadIdx.x; k < kSortWaves * kRadix; k += kSortThreads) (&wave_count[0][0])[k] = 0;
-    __syncthreads();
+    __shared__ uint32_t wave_count[kSortWaves][kRadix];  // per-wave digit counts, then the wave's base inside the tile
+    __shared__ int offset[kRadix];                       // global slot of local sorted position s is offset[digit] + s
+    __shared__ uint32_t wave_total[kSortWaves];
+    __shared__ uint32_t my_tile;
+    __shared__ uint64_t sorted_key[kSortTile];
+    __shared__ uint32_t sorted_val[kSortTile];
 
+    for (uint32_t k = threadIdx.x; k < kSortWaves * kRadix; k += kSortThreads) (&wave_count[0][0])[k] = 0;
+    // tiles are handed out in launch order, so every tile this one will wait for has already started
+    if (threadIdx.x == 0) my_tile = atomicAdd(&tile_ticket[pass], 1u);
+    __syncthreads();
+    const uint32_t tile = my_tile;
+    const uint32_t shift = pass * kRadixBits;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
+
     uint64_t key[kSortItems];
     uint32_t val[kSortItems], rank[kSortItems];
 #pragma unroll
     for (uint32_t j = 0; j < kSortItems; j++) {
-        const size_t i = tile_index(blockIdx.x, wave, j, lane);
+        const size_t i = tile_index(tile, wave, j, lane);
         const bool live = i < n;
         key[j] = live ? keys_in[i] : ~0ull;
         val[j] = live ? (idx_in ? idx_in[i] : uint32_t(i)) : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kSortItems; j++) {
+        const bool live = tile_index(tile, wave, j, lane) < n;
         const uint32_t digit = uint32_t(key[j] >> shift) & (kRadix - 1);
-        // lanes of this wave holding the same digit (ballot per digit bit)
-        uint64_t same = __ballot(live);
+        uint64_t same = __ballot(live);  // lanes of this wave holding the same digit (one ballot per digit bit)
 #pragma unroll
         for (uint32_t b = 0; b < kRadixBits; b++) {
             const bool bit = (digit >> b) & 1u;
@@ -114,49 +155,76 @@ k_radix_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict
         rank[j] = before;  // rank among this wave's keys of the same digit, in (j, lane) order
     }
     __syncthreads();
-    {   // digit d: turn the per-wave counts into output bases (tile offset + counts of earlier waves)
-        const uint32_t d = threadIdx.x;
-        uint32_t run = tile_offset[size_t(d) * ntiles + blockIdx.x];
+
+    // thread d owns digit d from here on
+    const uint32_t d = threadIdx.x;
+    uint32_t count = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < kSortWaves; w++) {
-            const uint32_t c = wave_count[w][d];
-            wave_count[w][d] = run;
-            run += c;
+    for (uint32_t w = 0; w < kSortWaves; w++) { const uint32_t c = wave_count[w][d]; wave_count[w][d] = count; count += c; }
+    uint32_t* status = tile_status + (size_t(pass) * tiles + tile) * kRadix;
+    __hip_atomic_store(&status[d], (tile == 0 ? kStatusInclusive : kStatusAggregate) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // exclusive scan of the tile's digit counts (position of digit d's run in the locally sorted tile)
+    uint32_t incl = count;
+    {
+        const uint32_t l = d & 63;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (int(l) >= o) incl += t; }
+        if (l == 63) wave_total[d >> 6] = incl;
+    }
+    __syncthreads();
+    uint32_t local_excl = incl - count;
+    for (uint32_t w = 0; w < (d >> 6); w++) local_excl += wave_total[w];
+
+    // decoupled look-back: keys of digit d in all earlier tiles
+    uint32_t earlier = 0;
+    for (int t = int(tile) - 1; t >= 0; t--) {
+        const uint32_t* prev = tile_status + (size_t(pass) * tiles + uint32_t(t)) * kRadix + d;
+        uint32_t word;
+        do { word = __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((word & ~kStatusValue) == 0);
+        earlier += word & kStatusValue;
+        if (word & kStatusInclusive) break;
+    }
+    if (tile != 0) __hip_atomic_store(&status[d], kStatusInclusive | (earlier + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    offset[d] = int(digit_base[pass * kRadix + d] + earlier) - int(local_excl);
+    // wave_count[w][d] becomes the local sorted position of wave w's first key of digit d
+#pragma unroll
+    for (uint32_t w = 0; w < kSortWaves; w++) wave_count[w][d] += local_excl;
+    __syncthreads();
+
+#pragma unroll
+    for (uint32_t j = 0; j < kSortItems; j++) {
+        if (tile_index(tile, wave, j, lane) < n) {
+            const uint32_t digit = uint32_t(key[j] >> shift) & (kRadix - 1);
+            const uint32_t s = wave_count[wave][digit] + rank[j];
+            sorted_key[s] = key[j];
+            sorted_val[s] = val[j];
         }
     }
     __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < kSortItems; j++) {
-        const size_t i = tile_index(blockIdx.x, wave, j, lane);
-        if (i < n) {
-            const uint32_t digit = uint32_t(key[j] >> shift) & (kRadix - 1);
-            const uint32_t pos = wave_count[wave][digit] + rank[j];
-            keys_out[pos] = key[j];
-            idx_out[pos] = val[j];
-        }
+    const uint32_t live_keys = min(uint32_t(kSortTile), n - min(n, tile * uint32_t(kSortTile)));
+    for (uint32_t s = threadIdx.x; s < live_keys; s += kSortThreads) {
+        const uint64_t k = sorted_key[s];
+        const uint32_t slot = uint32_t(offset[uint32_t(k >> shift) & (kRadix - 1)] + int(s));
+        keys_out[slot] = k;
+        idx_out[slot] = sorted_val[s];
     }
 }
 
-struct RadixSortBuffers {
-    uint64_t* keys[2];
-    uint32_t* idx[2];
-    uint32_t* tile_hist;  // 256 * ceil(capacity / kSortTile) counters
-};
-
-inline uint32_t radix_tiles(size_t n) { return uint32_t((n + kSortTile - 1) / kSortTile); }
-
-// Enqueue `passes` passes over key bits [0, 8*passes).  Input in keys[0] (idx[0] unused on the first pass);
-// the result of pass p lands in buffer (p+1)&1.  pass_limit: optional device word; passes >= *pass_limit do nothing,
-// so the sorted data is in buffer (*pass_limit & 1).
+// Enqueue a sort of n pairs over key bits [0, 8*passes).  Input in keys[0] (idx[0] unused: the payload of the
+// first pass is the position); the result of pass p lands in buffer (p+1)&1, so with *pass_limit = L <= passes
+// active passes the sorted data is in buffer (L & 1).
 inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream) {
     if (n == 0) return;
-    const uint32_t ntiles = radix_tiles(n);
+    const uint32_t tiles = radix_tiles(n);
+    (void)hipMemsetAsync(b.tile_status, 0, radix_status_words(tiles) * 4, stream);
+    uint32_t* ticket = b.tile_status + size_t(kMaxPasses) * tiles * kRadix;
+    hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part);
+    hipLaunchKernelGGL(k_radix_bases, dim3(passes), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
     for (uint32_t p = 0; p < passes; p++) {
         const int src = p & 1, dst = src ^ 1;
-        hipLaunchKernelGGL(k_radix_tile_histogram, dim3(ntiles), dim3(kSortThreads), 0, stream, b.keys[src], n, p * kRadixBits, ntiles, b.tile_hist, pass_limit, p);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, b.tile_hist, uint32_t(kRadix) * ntiles, pass_limit, p);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kSortThreads), 0, stream, b.keys[src], p == 0 ? nullptr : b.idx[src], b.keys[dst], b.idx[dst], n,
-                           p * kRadixBits, ntiles, b.tile_hist, pass_limit, p);
+        hipLaunchKernelGGL(k_radix_onesweep, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[src], p == 0 ? nullptr : b.idx[src], b.keys[dst], b.idx[dst], n, p,
+                           tiles, b.digit_base, b.tile_status, ticket, pass_limit);
     }
 }
 
