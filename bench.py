@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000, help="points per scan (BASELINE config: 1 M)")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic scans cycled through per rank")
-    ap.add_argument("--update-mode", type=int, default=0, help="0 default, 1 scatter, 2 LDS-tiled")
+    ap.add_argument("--update-mode", type=int, default=0, help="0 auto, 1 scatter, 2 LDS-tiled")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -131,7 +131,7 @@ def main():
             "points_per_frame": args.points,
             "frames_per_step_per_gpu": 1,
             "parallelism": f"frames round-robin over {world} GPU(s); one RCCL block-partial merge per timed region" if world > 1 else "1 GPU",
-            "update_kernel": {0: "tiled", 1: "scatter", 2: "tiled"}[args.update_mode],
+            "update_kernel": {0: "auto (tiled for this dense frame)", 1: "scatter", 2: "tiled"}[args.update_mode],
         },
         "stage_ms": {k: round(float(st[k]), 4) for k in ("ms_mc_calc", "ms_mc_sort", "ms_norm_est", "ms_oct_upd", "ms_total")},
         "frame": {"updates": int(st["updates"]), "voxels": n_voxels, "blocks": int(st["blocks"]), "sort_passes": int(st["sort_passes"]),

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libchad_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_CAPACITY, ERR_HIP = range(6)
 FLAG_VERBOSE, FLAG_TIMING = 1, 2
-UPDATE_DEFAULT, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
+UPDATE_AUTO, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
 
 
 class ChadError(RuntimeError):

@@ -64,8 +64,9 @@ struct chad_map {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    uint32_t flags = 0, update_mode = CHAD_UPDATE_TILED;
+    uint32_t flags = 0, update_mode = CHAD_UPDATE_AUTO;
     uint32_t ablate = 0;  // CHAD_DEBUG_ABLATE: timing experiments only
+    unsigned long long* d_stamps = nullptr;  // CHAD_DEBUG_STAMPS: per-phase cycle stamps of the update kernel
 
     MapView view{};
     uint32_t hash_capacity = 0, brick_capacity = 0;
@@ -145,18 +146,13 @@ chad_status ensure_frame_capacity(chad_map* m, size_t n) {
     return CHAD_OK;
 }
 
-// Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  `blocks` = bricks in use.
-chad_status clear_active(chad_map* m, uint32_t blocks, bool whole_table) {
+// Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  Fully asynchronous.
+chad_status clear_active(chad_map* m, bool whole_table) {
     if (whole_table) {
         hipLaunchKernelGGL(k_fill_u64, grid_for(m->hash_capacity), dim3(256), 0, m->stream, m->view.hash_keys, size_t(m->hash_capacity), kEmptyKey);
         hipLaunchKernelGGL(k_fill_u32, grid_for(m->hash_capacity), dim3(256), 0, m->stream, m->view.hash_vals, size_t(m->hash_capacity), kPending);
-    } else if (blocks) {
-        hipLaunchKernelGGL(k_release_slots, grid_for(blocks), dim3(256), 0, m->stream, m->view.brick_slot, blocks, m->view.hash_keys, m->view.hash_vals);
     }
-    if (blocks) {
-        HIP_TRY(hipMemsetAsync(m->view.brick_sum, 0, size_t(blocks) * 64 * 4, m->stream));
-        HIP_TRY(hipMemsetAsync(m->view.brick_cnt, 0, size_t(blocks) * 64 * 4, m->stream));
-    }
+    hipLaunchKernelGGL(k_clear_bricks, dim3(1024), dim3(256), 0, m->stream, m->view);
     HIP_TRY(hipMemsetAsync(m->view.brick_count, 0, 4, m->stream));
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
@@ -194,7 +190,7 @@ chad_status close_active(chad_map* m) {
         hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(blocks) * 64), dim3(256), 0, m->stream, (const uint32_t*)nullptr, blocks, m->view.brick_key,
                            m->view.brick_sum, m->view.brick_cnt, s.keys, s.sum, s.cnt);
     m->closed.push_back(s);
-    return clear_active(m, blocks, false);
+    return clear_active(m, false);
 }
 
 chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const uint64_t** keys, const float** sum, const uint32_t** cnt) {
@@ -284,10 +280,13 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
         record(m, T_SORT);
         hipLaunchKernelGGL(k_frame_normals, dim3(256 * 24), dim3(64 * kNormalWavesPerBlock), 0, m->stream, m->d_pts, m->d_codes, m->d_seg, m->d_seg + m->cap_points, m->d_hdr, pos, m->d_normals, m->ablate);
         record(m, T_NORM);
-        if (m->update_mode == CHAD_UPDATE_SCATTER)
-            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, m->d_pts, m->d_normals, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view);
-        else
-            tile_update_enqueue(m->d_pts, m->d_normals, m->d_codes, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, m->ablate);
+        // CHAD_UPDATE_AUTO enqueues both forms; each looks at the frame's points-per-block ratio (device memory)
+        // and exactly one of them does the work
+        const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
+        if (m->update_mode != CHAD_UPDATE_TILED)
+            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, m->d_pts, m->d_normals, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
+        if (m->update_mode != CHAD_UPDATE_SCATTER)
+            tile_update_enqueue(m->d_pts, m->d_normals, m->d_codes, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->ablate, m->d_stamps);
         record(m, T_UPD);
     } else {
         record(m, T_CALC); record(m, T_SORT); record(m, T_NORM); record(m, T_UPD);
@@ -340,8 +339,9 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->res = sdf_res; m->trunc = sdf_trunc;
     m->recip = float(1.0 / double(sdf_res));  // morton.hpp:63, octree.hpp:82
     m->device = dev; m->flags = o.flags;
-    m->update_mode = o.update_mode ? o.update_mode : CHAD_UPDATE_TILED;
+    m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
+    if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)hipMalloc(&m->d_stamps, 8192 * 8 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 8 * 8); }
     auto bail = [&](chad_status s) { chad_map_destroy(m); return s; };
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
@@ -369,7 +369,8 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipMemsetAsync(m->view.brick_cnt, 0, blocks * 256, m->stream));
     if (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
-    if (clear_active(m, 0, true) != CHAD_OK) return bail(CHAD_ERR_HIP);
+    CREATE_TRY(hipMemsetAsync(m->view.brick_count, 0, 4, m->stream));
+    if (clear_active(m, true) != CHAD_OK) return bail(CHAD_ERR_HIP);
     if (ensure_frame_capacity(m, o.max_points ? o.max_points : (1u << 20)) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     CREATE_TRY(hipStreamSynchronize(m->stream));
 #undef CREATE_TRY
@@ -381,6 +382,15 @@ void chad_map_destroy(chad_map* m) {
     if (!m) return;
     DeviceGuard guard(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->d_stamps) {  // diagnostic: mean cycles per phase over the waves of the last update launch
+        std::vector<unsigned long long> st(8192 * 8);
+        (void)hipMemcpy(st.data(), m->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+        double sum[8] = {}; unsigned long long life_max = 0; int waves = 0;
+        for (int w = 0; w < 8192; w++) { if (!st[w * 8 + 5]) continue; waves++; for (int k = 0; k < 8; k++) sum[k] += double(st[w * 8 + k]); life_max = std::max(life_max, st[w * 8 + 5]); }
+        if (waves) std::fprintf(stderr, "stamps: waves %d  dequeue+meta %.0f  load %.0f  begin %.0f  walk %.0f  readback %.0f  lookup %.0f  flushloop %.0f  life %.0f (max %llu)\n", waves, sum[0] / waves,
+                                sum[1] / waves, sum[2] / waves, sum[3] / waves, sum[6] / waves, sum[7] / waves, sum[4] / waves, sum[5] / waves, life_max);
+        (void)hipFree(m->d_stamps);
+    }
     free_frame_buffers(m);
     for (auto& s : m->closed) free_submap(s);
     (void)hipFree(m->view.hash_keys); (void)hipFree(m->view.hash_vals); (void)hipFree(m->view.brick_key);
@@ -424,13 +434,14 @@ chad_status chad_map_sync(chad_map* m) {
 chad_status chad_map_reset(chad_map* m) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
-    uint32_t blocks = 0;
-    TRY(read_block_count(m, &blocks));
-    for (auto& s : m->closed) free_submap(s);
-    m->closed.clear();
+    if (!m->closed.empty()) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        for (auto& s : m->closed) free_submap(s);
+        m->closed.clear();
+    }
     m->positions.clear();
     HIP_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
-    return clear_active(m, blocks, false);
+    return clear_active(m, false);
 }
 
 chad_status chad_map_close_submap(chad_map* m) {
@@ -521,8 +532,6 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
     if (!m || (blocks && (!keys_device || !sum_device || !cnt_device))) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     if (blocks > 0xffffffffull) return fail(CHAD_ERR_INVALID_ARG, "too many blocks");
     DeviceGuard guard(m->device);
-    uint32_t live = 0;
-    TRY(read_block_count(m, &live));
     Submap s;
     TRY(alloc_submap(s, uint32_t(blocks)));
     if (blocks) {
@@ -532,7 +541,7 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
     }
     m->closed.push_back(s);
     m->positions.clear();
-    TRY(clear_active(m, live, false));
+    TRY(clear_active(m, false));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHAD_OK;
 }

@@ -19,6 +19,7 @@ namespace chadhip {
 constexpr int kFrameBlocks = 512;     // fixed grid of the bounds / keys / gather kernels (2 workgroups per CU)
 constexpr int kGatherChunk = 2048;    // points per gather step of one workgroup
 constexpr uint32_t kItemPoints = 256; // an update work item never holds more points than this
+constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of this many counters (blockIdx % kWorkGroups)
 
 // Per-frame scalars living in device memory (one per map; rewritten every insert).
 struct FrameHeader {
@@ -33,7 +34,13 @@ struct FrameHeader {
     uint32_t n_items;           // update work items: point blocks cut at every kItemPoints-th point
     uint32_t item_cursor;       // work counter of the persistent update waves
     unsigned long long n_updates[32 * 16];  // voxel updates applied by the last insert, striped over 32 cache lines
+    uint32_t work_cursor[kWorkGroups * 16];  // per-group work counters of the update kernel, one per 64-byte line
 };
+
+// Sparse frames (few points per 4x4x4 block, e.g. 2 cm voxels outdoors) take the scatter form of the update: with about
+// one point per block, staging a voxel tile in LDS per block is pure overhead.  Decided on the device, per frame.
+constexpr uint32_t kSparsePointsPerBlock = 6;
+__device__ __forceinline__ bool frame_is_sparse(const FrameHeader* h) { return h->n_usable < kSparsePointsPerBlock * h->n_segments; }
 
 // Partial results of one workgroup, combined by the NEXT kernel's prologue (no same-address atomics: on gfx950
 // those serialise at ~12 ns each, which for thousands of waves costs more than the whole pass).
@@ -46,6 +53,7 @@ struct FramePartial {
 __global__ void k_frame_init(FrameHeader* h) {
     const uint32_t keep_overflow = h->overflow;
     for (uint32_t k = threadIdx.x; k < 32 * 16; k += blockDim.x) h->n_updates[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kWorkGroups * 16; k += blockDim.x) h->work_cursor[k] = 0;
     if (threadIdx.x == 0) {
         h->vmin[0] = h->vmin[1] = h->vmin[2] = 0x7fffffff;
         h->vmax[0] = h->vmax[1] = h->vmax[2] = int(0x80000000);
@@ -270,12 +278,13 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
 // One wave per point block.  The block's <= 64 voxel runs are counted into LDS, the greedy neighbourhood walk
 // runs over those 64 counters (not over the points), then the neighbourhoods are fitted with the reference's
 // two-pass f64 "plane from points" -- small ones by one lane each in the reference's summation order, large ones
-// by the whole wave -- and every point picks up its neighbourhood's normal (or the per-point fallback when the
+// by 16-lane teams or the whole wave -- and every point picks up its neighbourhood's normal (or the per-point fallback when the
 // neighbourhood has < 8 points).
 
 constexpr uint32_t kMinPoints = 8;    // normals.hpp:88
 constexpr uint32_t kStagePoints = 256;  // points of a block kept in LDS for the fits (4 KiB)
-constexpr uint32_t kCoopPoints = 48;    // neighbourhoods at least this large are fitted by the whole wave
+constexpr uint32_t kTeamPoints = 16;    // neighbourhoods of 16..255 points are fitted by a 16-lane team (4 at a time)
+constexpr uint32_t kCoopPoints = 256;   // neighbourhoods at least this large are fitted by the whole wave
 
 struct NormalScratch {         // per wave, in LDS
     uint32_t count[64];        // points per voxel of the block (index = low 6 code bits)
@@ -283,6 +292,7 @@ struct NormalScratch {         // per wave, in LDS
     uint32_t g_first[64];      // first point (offset in the segment) of neighbourhood g
     uint32_t g_size[64];
     float g_normal[64][4];     // fitted normal; [3] != 0 marks "fit" (else per-point fallback)
+    uint32_t team_list[64];    // neighbourhoods fitted by 16-lane teams
     float4 stage[kStagePoints];  // the block's first points (x, y, z, input index)
 };
 
@@ -356,6 +366,22 @@ __device__ __forceinline__ F3 fit_plane_wave(Ptr pts, uint32_t count, uint32_t l
     return plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
 }
 
+// Sum over the 16 lanes of a DPP row, result in every lane of the row: four rotate-and-add steps on the VALU
+// (row_ror:8,4,2,1), no LDS round trip.  Must be executed by all 64 lanes.
+template <int kCtrl>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double team_sum_f64(double v) {
+    v += dpp_move_f64<0x128>(v);  // row_ror:8
+    v += dpp_move_f64<0x124>(v);  // row_ror:4
+    v += dpp_move_f64<0x122>(v);  // row_ror:2
+    v += dpp_move_f64<0x121>(v);  // row_ror:1
+    return v;
+}
+
 // Length of the run of points of `block` starting at `first` (codes sorted by block), capped at `limit`.
 // Two dependent loads instead of one per 64 points: lanes first probe the starts of the next 64 chunks of 64
 // points, then the points of the chunk where the run ends.  Wave-uniform result.
@@ -397,21 +423,10 @@ k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ cod
         // pass 1 over the block: voxel histogram in LDS, first kStagePoints points staged in LDS
         s.count[lane] = 0;
         __syncthreads();
-        for (uint32_t k0 = 0; k0 < len; k0 += 256) {  // four points per lane and trip: their loads overlap
-            uint32_t v[4];
-            float4 q[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t k = k0 + 64u * u + lane;
-                v[u] = k < grouped ? uint32_t(codes[first + k]) & 63u : 64u;
-                if (k < len && k < kStagePoints) q[u] = pts[first + k];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t k = k0 + 64u * u + lane;
-                if (v[u] < 64u) atomicAdd(&s.count[v[u]], 1u);
-                if (k < len && k < kStagePoints) s.stage[k] = q[u];
-            }
+        for (uint32_t k = lane; k < len; k += 64) {
+            const uint32_t v = uint32_t(codes[first + k]) & 63u;
+            if (k < kStagePoints) s.stage[k] = pts[first + k];
+            if (k < grouped) atomicAdd(&s.count[v], 1u);
         }
         __syncthreads();
 
@@ -423,7 +438,7 @@ k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ cod
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(upto, o); if (int(lane) >= o) upto += t; }
         const uint32_t before = upto - own;
         uint64_t rest = (ablate & 64u) ? 0ull : __ballot(own != 0);  // voxel runs not yet in a neighbourhood
-        uint32_t ngroups = 0, my_group = 0;
+        uint32_t ngroups = 0, my_group = 0, nteams = 0;
         while (rest) {
             const uint32_t l = uint32_t(__ffsll((unsigned long long)rest)) - 1u;  // highest remaining voxel
             const uint32_t start = read_lane(before, l);
@@ -437,7 +452,11 @@ k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ cod
                     size = read_lane(upto, 63u) - start;
                 }
             }
-            if (lane == 0) { s.g_first[ngroups] = start; s.g_size[ngroups] = size; }
+            if (lane == 0) {
+                s.g_first[ngroups] = start; s.g_size[ngroups] = size;
+                if (size >= kTeamPoints && size < kCoopPoints) s.team_list[nteams] = ngroups;
+            }
+            if (size >= kTeamPoints && size < kCoopPoints) nteams++;
             if (lane >= l && lane <= l_end) my_group = ngroups;
             ngroups++;
             rest = l_end == 63u ? 0ull : rest & ~((2ull << l_end) - 1ull);
@@ -457,8 +476,40 @@ k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ cod
                 s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
             }
         }
-        // small neighbourhoods: one lane each, in the reference's summation order
-        if (lane < ngroups && s.g_size[lane] < kCoopPoints) {
+        // medium neighbourhoods: four 16-lane teams at a time; a team strides over its points (first from the
+        // staged LDS copy, the rest from HBM) and combines the moments with DPP row reductions
+        {
+            const uint32_t team = lane >> 4, tl = lane & 15u;
+            for (uint32_t r = 0; r * 4u < ((ablate & 8u) ? 0u : nteams); r++) {
+                const uint32_t tg = r * 4u + team;
+                const bool on = tg < nteams;
+                const uint32_t g = on ? s.team_list[tg] : 0u;
+                const uint32_t g0 = s.g_first[g], gn = on ? s.g_size[g] : 0u;
+                auto point = [&](uint32_t k) { const uint32_t at = g0 + k; return at < kStagePoints ? s.stage[at] : pts[first + at]; };
+                double cx = 0, cy = 0, cz = 0;
+                for (uint32_t k = tl; k < gn; k += 16) { const float4 q = point(k); cx += double(q.x); cy += double(q.y); cz += double(q.z); }
+                const double recip = 1.0 / double(gn);
+                cx = team_sum_f64(cx) * recip; cy = team_sum_f64(cy) * recip; cz = team_sum_f64(cz) * recip;
+                double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+                for (uint32_t k = tl; k < gn; k += 16) {
+                    const float4 q = point(k);
+                    const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
+                    xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+                }
+                xx = team_sum_f64(xx); xy = team_sum_f64(xy); xz = team_sum_f64(xz);
+                yy = team_sum_f64(yy); yz = team_sum_f64(yz); zz = team_sum_f64(zz);
+                if (on && tl == 0) {
+                    F3 nrm = plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
+                    const float4 q = point(0);
+                    const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
+                    if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
+                    s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
+                }
+            }
+        }
+        // small neighbourhoods (8..15 points): one lane each, in the reference's summation order; and the
+        // neighbourhoods below 8 points, which only get their "no fit" mark here
+        if (lane < ngroups && s.g_size[lane] < kTeamPoints) {
             const uint32_t g0 = s.g_first[lane], gn = s.g_size[lane];
             float fit = 0.0f;
             F3 nrm{0, 0, 0};
@@ -473,28 +524,19 @@ k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ cod
             s.g_normal[lane][0] = nrm.x; s.g_normal[lane][1] = nrm.y; s.g_normal[lane][2] = nrm.z; s.g_normal[lane][3] = fit;
         }
         __syncthreads();
-        for (uint32_t k0 = 0; k0 < ((ablate & 32u) ? 0u : len); k0 += 256) {  // four points per lane and trip
-            float4 q[4];
-            uint32_t v[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t k = k0 + 64u * u + lane;
-                if (k < len) { q[u] = k < kStagePoints ? s.stage[k] : pts[first + k]; v[u] = uint32_t(codes[first + k]) & 63u; }
+        for (uint32_t k = lane; k < ((ablate & 32u) ? 0u : len); k += 64) {
+            F3 nrm;
+            bool fitted = false;
+            if (k < grouped) {
+                const uint32_t g = s.group_of[uint32_t(codes[first + k]) & 63u];
+                fitted = s.g_normal[g][3] != 0.0f;
+                nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
             }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t k = k0 + 64u * u + lane;
-                if (k >= len) continue;
-                F3 nrm;
-                bool fitted = false;
-                if (k < grouped) {
-                    const uint32_t g = s.group_of[v[u]];
-                    fitted = s.g_normal[g][3] != 0.0f;
-                    nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
-                }
-                if (!fitted) nrm = unit3(sub3(pos, F3{q[u].x, q[u].y, q[u].z}));  // normals.hpp:130
-                normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+            if (!fitted) {
+                const float4 q = k < kStagePoints ? s.stage[k] : pts[first + k];
+                nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
             }
+            normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
         }
         __syncthreads();
     }

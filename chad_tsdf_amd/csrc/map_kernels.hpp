@@ -83,7 +83,8 @@ __device__ __forceinline__ uint32_t find_brick(const MapView& m, uint64_t key) {
 // ---- update, general form: one lane per point, global atomics per observation (octree.hpp:86-164) -----------
 __global__ void __launch_bounds__(256)
 k_update_scatter(const float4* __restrict__ pts, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
-                 F3 pos, float res, float recip, float trunc, MapView m) {
+                 F3 pos, float res, float recip, float trunc, MapView m, uint32_t adaptive) {
+    if (adaptive && !frame_is_sparse(h)) return;  // dense frame: k_update_tiled handles it
     const uint32_t n = h->n_usable;
     unsigned long long applied = 0;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -177,12 +178,23 @@ k_import_bricks(const uint64_t* __restrict__ keys, const float* __restrict__ sum
     }
 }
 
-// Octree::clear() (octree.hpp:22-29) in O(bricks): release exactly the slots the live bricks occupy.
-__global__ void k_release_slots(const uint32_t* __restrict__ brick_slot, uint32_t blocks, uint64_t* __restrict__ hash_keys, uint32_t* __restrict__ hash_vals) {
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < blocks; i += size_t(gridDim.x) * blockDim.x) {
-        const uint32_t slot = brick_slot[i];
-        hash_keys[slot] = kEmptyKey;
-        hash_vals[slot] = kPending;
+// Octree::clear() (octree.hpp:22-29) in O(bricks) and without a host round trip: the number of live bricks is read
+// from device memory; one wave per brick releases its hash slot and zeroes its two 256-byte rows.
+// (The counter itself is reset by a memset enqueued behind this kernel.)
+__global__ void __launch_bounds__(256)
+k_clear_bricks(MapView m) {
+    const uint32_t blocks = min(*m.brick_count, m.brick_capacity);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t b = wave; b < blocks; b += waves) {
+        if (lane == 0) {
+            const uint32_t slot = m.brick_slot[b];
+            m.hash_keys[slot] = kEmptyKey;
+            m.hash_vals[slot] = kPending;
+        }
+        m.brick_sum[size_t(b) * 64 + lane] = 0.0f;
+        m.brick_cnt[size_t(b) * 64 + lane] = 0u;
     }
 }
 

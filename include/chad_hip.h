@@ -41,7 +41,7 @@ typedef struct chad_options {
     uint64_t max_points; /* initial per-frame point capacity (grows on demand); 0 = default (1<<20) */
     void* stream;        /* hipStream_t to enqueue on; NULL = a stream owned by the map */
     uint32_t flags;      /* CHAD_FLAG_* */
-    uint32_t update_mode; /* CHAD_UPDATE_*; 0 = default */
+    uint32_t update_mode; /* CHAD_UPDATE_* */
 } chad_options;
 
 enum {
@@ -50,9 +50,9 @@ enum {
                                chad_map_stats reports their mean over the inserts since the previous stats call (at most 64) */
 };
 enum {
-    CHAD_UPDATE_DEFAULT = 0,
-    CHAD_UPDATE_SCATTER = 1, /* per-voxel global atomics (general fallback) */
-    CHAD_UPDATE_TILED = 2    /* LDS-staged 12^3-voxel tiles per point block, coalesced flush */
+    CHAD_UPDATE_AUTO = 0,    /* chosen per frame on the device from its points-per-block ratio (default) */
+    CHAD_UPDATE_SCATTER = 1, /* per-voxel global atomics: the general form, best for sparse frames */
+    CHAD_UPDATE_TILED = 2    /* LDS-staged voxel tile per point block, coalesced flush: best for dense frames */
 };
 
 /* Per-frame and per-map counters; filled by chad_map_stats (synchronises). */

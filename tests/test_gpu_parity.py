@@ -11,7 +11,7 @@ from tests.util import SD_TOL, assert_leaves_match, by_input_index
 
 pytestmark = pytest.mark.gpu
 
-MODES = [1, 2]  # CHAD_UPDATE_SCATTER, CHAD_UPDATE_TILED
+MODES = [0, 1, 2]  # CHAD_UPDATE_AUTO, _SCATTER, _TILED
 
 
 @pytest.fixture(scope="module")
