@@ -5,10 +5,10 @@
 // depends on that order is local to a 4x4x4-voxel block (the greedy neighbourhood walk of normals.hpp:94-108
 // never crosses a change of code >> 6, and every block's first neighbourhood starts at the block's first
 // point), except one thing: the globally last point is never absorbed into a neighbourhood (normals.hpp:100).
-// So the device sorts by a SHORT key -- the Morton code of the voxel relative to the frame's bounding box,
-// whose corner is aligned to 4 voxels so that the low 6 code bits (the voxel inside its block) and the block
-// partition are those of the global code -- and finds the reference's "last point" (smallest global code,
-// largest input index among equals) with a reduction.  A room-sized frame needs 3-4 radix passes instead of 8.
+// So the device sorts by a SHORT key -- the position of the voxel's block inside the frame's bounding box (whose
+// corner is aligned to 4 voxels, so the block partition is that of the global code) followed by the voxel's low
+// 6 code bits -- and finds the reference's "last point" (smallest global code, largest input index among equals)
+// with a reduction.  A room-sized frame needs 3 radix passes instead of 8.
 // Inside a block the order is the reference's: descending voxel code, ties by ascending input index.
 #pragma once
 #include "device_math.hpp"
@@ -25,8 +25,8 @@ constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of thi
 struct FrameHeader {
     int vmin[3], vmax[3];       // voxel bounds of the usable points
     uint32_t n_usable;          // points kept (D2 of the oracle header)
-    uint32_t axis_bits;         // bits per axis of the frame-local code
-    uint32_t sort_passes;       // radix passes needed: ceil((3*axis_bits + 1) / 8)
+    uint32_t axis_bits;         // bits of a usable sort key
+    uint32_t sort_passes;       // radix passes needed: ceil((axis_bits + 1 if any point is unusable) / 8)
     uint32_t n_segments;        // point blocks (runs of equal code >> 6) found by k_frame_gather
     unsigned long long mc_min;  // smallest global Morton code of the frame ...
     uint32_t last_idx;          // ... and the largest input index among the points having it (normals.hpp:100)
@@ -128,7 +128,12 @@ k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, F
     }
 }
 
-struct LocalFrame { int ox, oy, oz; uint32_t bits, kept; int lo[3], hi[3]; };  // frame-local code geometry
+struct LocalFrame {  // geometry of the frame-local sort key
+    int ox, oy, oz;          // block-aligned corner of the frame's voxel bounds
+    uint32_t wx, wy, wz;     // bits needed for the block index along each axis
+    uint32_t bits, kept;     // bits of a usable key; usable points
+    int lo[3], hi[3];
+};
 
 // Combine the kFrameBlocks partial bounds (every workgroup of the keys kernel does this redundantly: 512 x 28 B
 // from L2) and derive the frame-local code geometry.
@@ -161,33 +166,39 @@ __device__ __forceinline__ LocalFrame combine_bounds(const FramePartial* __restr
         }
         f.kept = uint32_t(red[0][6]) + uint32_t(red[1][6]) + uint32_t(red[2][6]) + uint32_t(red[3][6]);
         f.ox = f.lo[0] & ~3; f.oy = f.lo[1] & ~3; f.oz = f.lo[2] & ~3;  // align down to a block corner
-        uint32_t ext = 0;
-        if (f.kept) ext = uint32_t(f.hi[0] - f.ox) | uint32_t(f.hi[1] - f.oy) | uint32_t(f.hi[2] - f.oz);
-        const uint32_t bits = 32 - __clz(ext | 3u);  // at least the 2 in-block bits
-        f.bits = bits > 21 ? 21 : bits;              // beyond 21 bits the reference's code aliases as well (morton.hpp:22)
+        // block index widths: blocks 0 .. (hi - o) >> 2 along each axis; at most 19 bits (beyond 2^21 voxels the
+        // reference's code aliases as well, morton.hpp:22)
+        auto width = [](int span_voxels) { const uint32_t last = uint32_t(span_voxels) >> 2; return last ? min(19u, 32u - uint32_t(__clz(last))) : 0u; };
+        f.wx = f.kept ? width(f.hi[0] - f.ox) : 0u; f.wy = f.kept ? width(f.hi[1] - f.oy) : 0u; f.wz = f.kept ? width(f.hi[2] - f.oz) : 0u;
+        f.bits = f.wx + f.wy + f.wz + 6u;
         shared_frame = f;
     }
     __syncthreads();
     return shared_frame;
 }
 
-// Stage 2: sort keys.  key = (2^(3b) - 1) - local code (ascending key = descending code); unusable points get
-// 2^(3b), above every usable key, so they end up behind the n_usable usable points.
+// Stage 2: sort keys.  key = [block index : wx + wy + wz bits][63 - voxel in block : 6 bits], the block index being
+// the block's x | y << wx | z << (wx + wy) position inside the frame's bounds.  Ascending keys therefore group the
+// points by block and order them by descending voxel code inside a block (ties keep input order: the sort is
+// stable); the order of the blocks themselves is irrelevant (see the header of this file), so it need not be
+// Morton order -- and a room-sized frame needs 22 key bits (3 radix passes) instead of 3*8 + 1.  Unusable points
+// get 2^bits, above every usable key, so they end up behind the n_usable usable points.
 __global__ void __launch_bounds__(256)
 k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
              FramePartial* __restrict__ part, uint64_t* __restrict__ keys) {
     const LocalFrame f = combine_bounds(part);
     __shared__ unsigned long long wave_mc[4];
-    const uint64_t top = 1ull << (3 * f.bits);
+    const uint64_t top = 1ull << f.bits;
+    const uint32_t mask_x = (1u << f.wx) - 1u, mask_y = (1u << f.wy) - 1u, mask_z = (1u << f.wz) - 1u;
     unsigned long long mc_min = ~0ull;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const F3 p = load_point(xyz, i);
         uint64_t key = top;
         if (point_usable(p, pos, recip)) {
             const I3 v = voxel_of(p, recip);
-            const uint64_t local = spread21(uint32_t(v.x - f.ox)) | (spread21(uint32_t(v.y - f.oy)) << 1) | (spread21(uint32_t(v.z - f.oz)) << 2);
-            key = (top - 1) - (local & (top - 1));
             const unsigned long long mc = morton_encode(v.x, v.y, v.z);
+            const uint64_t bx = (uint32_t(v.x - f.ox) >> 2) & mask_x, by = (uint32_t(v.y - f.oy) >> 2) & mask_y, bz = (uint32_t(v.z - f.oz) >> 2) & mask_z;
+            key = ((bx | (by << f.wx) | (bz << (f.wx + f.wy))) << 6) | (63u - (uint32_t(mc) & 63u));
             mc_min = mc < mc_min ? mc : mc_min;
         }
         keys[i] = key;
@@ -203,7 +214,8 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             for (int a = 0; a < 3; a++) { h->vmin[a] = f.lo[a]; h->vmax[a] = f.hi[a]; }
             h->n_usable = f.kept;
             h->axis_bits = f.bits;
-            h->sort_passes = (3 * f.bits + 1 + kRadixBits - 1) / kRadixBits;
+            // the extra top bit is only needed when some point is unusable
+            h->sort_passes = (f.bits + (f.kept < n ? 1u : 0u) + kRadixBits - 1) / kRadixBits;
         }
     }
 }

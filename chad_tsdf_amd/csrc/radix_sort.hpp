@@ -25,6 +25,8 @@ constexpr int kSortThreads = 256;                       // 4 waves
 constexpr int kSortItems = 8;                           // keys per thread
 constexpr int kSortTile = kSortThreads * kSortItems;    // 2048 keys per workgroup
 constexpr int kSortWaves = kSortThreads / 64;
+constexpr uint32_t kResidentTiles = 1024;               // 4 workgroups of the pass kernel per CU (it fits 5)
+constexpr int kLookback = 8;                            // predecessor tiles read per round trip of the look-back
 constexpr int kHistBlocks = 256;                        // workgroups of the histogram kernel (one partial table each)
 
 constexpr uint32_t kStatusAggregate = 1u << 30;         // the tile's own digit counts are published
@@ -116,10 +118,12 @@ k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
     __shared__ uint32_t sorted_val[kSortTile];
 
     for (uint32_t k = threadIdx.x; k < kSortWaves * kRadix; k += kSortThreads) (&wave_count[0][0])[k] = 0;
-    // tiles are handed out in launch order, so every tile this one will wait for has already started
-    if (threadIdx.x == 0) my_tile = atomicAdd(&tile_ticket[pass], 1u);
+    // A tile waits for the tiles before it.  With at most kResidentTiles tiles every workgroup of the grid is
+    // resident at the same time, so nobody waits for a workgroup that cannot start, whatever the dispatch order;
+    // larger grids hand tiles out in start order through a ticket counter (one serialising atomic per tile).
+    if (tiles > kResidentTiles && threadIdx.x == 0) my_tile = atomicAdd(&tile_ticket[pass], 1u);
     __syncthreads();
-    const uint32_t tile = my_tile;
+    const uint32_t tile = tiles > kResidentTiles ? my_tile : blockIdx.x;
     const uint32_t shift = pass * kRadixBits;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -176,14 +180,28 @@ k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
     uint32_t local_excl = incl - count;
     for (uint32_t w = 0; w < (d >> 6); w++) local_excl += wave_total[w];
 
-    // decoupled look-back: keys of digit d in all earlier tiles
+    // decoupled look-back: keys of digit d in all earlier tiles.  kLookback predecessors are read per round trip
+    // (independent loads), then consumed nearest first; a word that is not published yet is re-polled alone.
     uint32_t earlier = 0;
-    for (int t = int(tile) - 1; t >= 0; t--) {
-        const uint32_t* prev = tile_status + (size_t(pass) * tiles + uint32_t(t)) * kRadix + d;
-        uint32_t word;
-        do { word = __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((word & ~kStatusValue) == 0);
-        earlier += word & kStatusValue;
-        if (word & kStatusInclusive) break;
+    for (int t = int(tile) - 1; t >= 0;) {
+        uint32_t word[kLookback];
+#pragma unroll
+        for (int k = 0; k < kLookback; k++) {
+            const int tk = t - k;
+            word[k] = tk >= 0 ? __hip_atomic_load(tile_status + (size_t(pass) * tiles + uint32_t(tk)) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusInclusive;
+        }
+        bool done = false;
+#pragma unroll
+        for (int k = 0; k < kLookback; k++) {
+            if (done) continue;
+            uint32_t w = word[k];
+            while ((w & ~kStatusValue) == 0)
+                w = __hip_atomic_load(tile_status + (size_t(pass) * tiles + uint32_t(t - k)) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            earlier += w & kStatusValue;
+            done = (w & kStatusInclusive) != 0;
+        }
+        if (done) break;
+        t -= kLookback;
     }
     if (tile != 0) __hip_atomic_store(&status[d], kStatusInclusive | (earlier + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     offset[d] = int(digit_base[pass * kRadix + d] + earlier) - int(local_excl);
