@@ -1,0 +1,144 @@
+"""Size-independent properties of the path, checked at BASELINE.json's full sizes where the oracle would be slow."""
+import numpy as np
+import pytest
+
+from chad_tsdf_amd import synth
+from tests.util import SD_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def chad():
+    import chad_tsdf_amd
+
+    chad_tsdf_amd._lib.load()
+    return chad_tsdf_amd
+
+
+def rel_err(a, b, trunc):
+    return float((np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), trunc)).max())
+
+
+def test_weights_sum_to_update_count_full_cfg2(chad):
+    pts, pos = synth.cfg2_frame()
+    m = chad.TSDFMap(0.05, 0.10)
+    m.insert(pts, pos)
+    mc, sd, w = m.export_leaves()
+    st = m.stats()
+    assert int(w.sum()) == st["updates"] == 6_720_936
+    assert np.all(mc[1:] > mc[:-1]), "leaves are sorted by code and unique"
+    assert np.all(np.abs(sd) <= 0.10 * (1 + 1e-6))
+    assert st["blocks"] == len(np.unique(mc >> np.uint64(6))) == 9_409
+    m.close()
+
+
+def test_same_scan_twice_doubles_weights_keeps_mean(chad):
+    pts, pos = synth.cfg2_frame()
+    m = chad.TSDFMap(0.05, 0.10)
+    m.insert(pts, pos)
+    a = m.export_leaves()
+    m.insert(pts, pos)
+    b = m.export_leaves()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(2 * a[2], b[2])
+    assert rel_err(b[1], a[1], 0.10) <= SD_TOL
+    m.close()
+
+
+def test_point_order_does_not_matter(chad):
+    """The reference sorts the scan first (morton.hpp:81-102), so a permuted scan gives the same map: leaf set and
+    weights exactly; sd up to the tie order of equal codes (f64 summation order in the plane fits)."""
+    pts, pos = synth.cfg2_frame(400_000, seed=12)
+    perm = np.random.default_rng(1).permutation(len(pts))
+    a = chad.TSDFMap(0.05, 0.10)
+    b = chad.TSDFMap(0.05, 0.10)
+    a.insert(pts, pos)
+    b.insert(pts[perm], pos)
+    ga, gb = a.export_leaves(), b.export_leaves()
+    assert np.array_equal(ga[0], gb[0]) and np.array_equal(ga[2], gb[2])
+    # a different tie order changes which point is "last" (normals.hpp:100) and which is first of its neighbourhood
+    # (the flip test, normals.hpp:117): a handful of voxels may differ, the rest agrees to rounding
+    err = np.abs(ga[1] - gb[1]) / np.maximum(np.abs(gb[1]), 0.10)
+    assert (err > SD_TOL).mean() < 1e-3
+    a.close(); b.close()
+
+
+def test_partial_maps_add_up(chad):
+    """Linearity (what the multi-GPU merge relies on): blocks(A) + blocks(B) == blocks(A then B)."""
+    import torch
+
+    from chad_tsdf_amd.sharded import merge_blocks
+
+    (pa, pos_a), (pb, pos_b) = synth.cfg2_frame(500_000, seed=21), synth.cfg2_frame(500_000, seed=22, sensor=(0.8, 0.3, -0.2))
+    both = chad.TSDFMap(0.05, 0.10)
+    both.insert(pa, pos_a)
+    both.insert(pb, pos_b)
+    ma, mb = chad.TSDFMap(0.05, 0.10), chad.TSDFMap(0.05, 0.10)
+    ma.insert(pa, pos_a)
+    mb.insert(pb, pos_b)
+    ka, sa, ca = ma.export_blocks()
+    kb, sb, cb = mb.export_blocks()
+    assert torch.all(ka[1:] > ka[:-1]), "export_blocks is sorted by block key"
+    union = torch.unique(torch.cat([ka, kb]))
+    s = torch.zeros((len(union), 64), device=ka.device)
+    c = torch.zeros((len(union), 64), dtype=torch.int32, device=ka.device)
+    for k, ss, cc in ((ka, sa, ca), (kb, sb, cb)):
+        at = torch.searchsorted(union, k)
+        s[at] += ss
+        c[at] += cc
+    kk, ks, kc = both.export_blocks()
+    assert torch.equal(kk, union) and torch.equal(kc, c)
+    assert float(((ks - s).abs() / (kc.clamp(min=1) * 0.10)).max()) <= SD_TOL
+    # and the archived (merged) submap reads back as leaves
+    ma.close_submap_with_blocks(union, s, c)
+    mc, sd, w = ma.export_leaves(0)
+    bmc, bsd, bw = both.export_leaves(-1)
+    assert np.array_equal(mc, bmc) and np.array_equal(w, bw) and rel_err(sd, bsd, 0.10) <= SD_TOL
+    assert merge_blocks(ka, sa, ca)[0] is ka  # single process: identity
+    for m in (both, ma, mb):
+        m.close()
+
+
+def test_update_kernels_agree_at_full_size(chad):
+    pts, pos = synth.cfg2_frame()
+    out = []
+    for mode in (1, 2):
+        m = chad.TSDFMap(0.05, 0.10, update_mode=mode)
+        m.insert(pts, pos)
+        out.append(m.export_leaves())
+        m.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    assert rel_err(out[0][1], out[1][1], 0.10) <= SD_TOL
+
+
+def test_stream_rollovers_at_expected_frames(chad):
+    """cfg3 poses (0.05 m per frame): the 5 m rule closes submaps when frames 101 and 202 arrive."""
+    m = chad.TSDFMap(0.05, 0.10, max_blocks=1 << 18)
+    total = 0
+    closed_at = []
+    for k in range(205):
+        pts, pos = synth.cfg3_frame(k, 20_000)
+        before = m.closed_submaps if k in (100, 101, 201, 202) else None
+        m.insert(pts, pos)
+        total += m.stats()["updates"]
+        if before is not None and m.closed_submaps != before:
+            closed_at.append(k)
+    assert closed_at == [101, 202]
+    w_all = sum(int(m.export_leaves(s)[2].sum()) for s in (0, 1, -1))
+    assert w_all == total
+    m.close()
+
+
+def test_sparse_outdoor_frame_and_hash_occupancy(chad):
+    """cfg5: 200 k points at 0.02 m -> ~1.6 M voxels in ~330 k blocks, about one point per block: the auto mode takes
+    the scatter kernel; the block hash stays at load <= 0.5."""
+    pts, pos = synth.cfg5_frame(0)
+    m = chad.TSDFMap(0.02, 0.06)
+    m.insert(pts, pos)
+    mc, sd, w = m.export_leaves()
+    st = m.stats()
+    assert st["overflow"] == 0 and int(w.sum()) == st["updates"]
+    assert st["blocks"] == len(np.unique(mc >> np.uint64(6)))
+    assert st["blocks"] / st["hash_capacity"] <= 0.5
+    assert 1_500_000 < len(mc) < 1_700_000
+    m.close()

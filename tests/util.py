@@ -20,6 +20,6 @@ def assert_leaves_match(got, want, trunc, tol=SD_TOL):
 
 
 def by_input_index(order, values, n):
-    out = np.full((n,) + values.shape[1:], np.nan, dtype=values.dtype)
+    out = np.zeros((n,) + values.shape[1:], dtype=values.dtype)
     out[order] = values
     return out
