@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of scripts/collect_profiles.sh into the committed summaries under profiles/:
+  profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 3`
+  profiles/<tag>_pmc_per_kernel.json   FETCH_SIZE / WRITE_SIZE / TCC counters, mean per launch
+  profiles/pmc_update_kernel.json      HBM traffic per launch of the update kernel (read by bench.py -> roofline.traffic)
+HBM correction (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
+the bytes of a wide (16 B/lane) coalesced stream, so reads are doubled; WRITE_SIZE is exact for 16-B stores and float
+atomics.  The update kernel's reads are float4 streams (points, normals) -> doubled."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "profiles")
+os.makedirs(prof, exist_ok=True)
+
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True))[-1]
+shutil.copy(stats, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+
+per_kernel = collections.defaultdict(dict)
+for group in ("fetch", "write", "tcc"):
+    f = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))[-1]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("chadhip::", "").replace("void ", "")
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for name, counters in acc.items():
+        for c, vals in counters.items():
+            per_kernel[name][c] = sum(vals) / len(vals)
+            per_kernel[name]["launches_sampled"] = len(vals)
+json.dump(per_kernel, open(os.path.join(prof, f"{tag}_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
+
+durations = {}
+for r in csv.DictReader(open(stats)):
+    durations[r["Name"].split("(")[0].replace("chadhip::", "").replace("void ", "")] = float(r["AverageNs"])
+upd = "k_update_tiled<false>"
+u = per_kernel[upd]
+traffic = (2.0 * u["FETCH_SIZE"] + u["WRITE_SIZE"]) * 1024.0
+json.dump({
+    "kernel": upd, "tag": tag,
+    "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum (separate passes) --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0",
+    "fetch_size_kib_raw": u["FETCH_SIZE"], "write_size_kib": u["WRITE_SIZE"],
+    "correction": "reads doubled (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane streams); writes as reported",
+    "hbm_bytes_per_launch": round(traffic),
+    "atomic_requests_per_launch": u.get("TCC_EA0_ATOMIC_sum"),
+    "l2_hit_rate": u["TCC_HIT_sum"] / (u["TCC_HIT_sum"] + u["TCC_MISS_sum"]),
+    "kernel_trace_avg_us": durations.get(upd, 0) / 1e3,
+}, open(os.path.join(prof, "pmc_update_kernel.json"), "w"), indent=1)
+print(open(os.path.join(prof, "pmc_update_kernel.json")).read())
+for k, v in sorted(durations.items(), key=lambda kv: -kv[1])[:8]:
+    print(f"{k:32s} {v / 1e3:8.2f} us")
