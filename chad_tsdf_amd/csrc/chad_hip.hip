@@ -134,7 +134,7 @@ chad_status ensure_frame_capacity(chad_map* m, size_t n) {
         HIP_TRY(hipMalloc(&m->sort.keys[i], cap * 8));
         HIP_TRY(hipMalloc(&m->sort.idx[i], cap * 4));
     }
-    HIP_TRY(hipMalloc(&m->sort.hist_part, size_t(kHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(hipMalloc(&m->sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&m->sort.digit_base, size_t(kMaxPasses) * kRadix * 4));
     HIP_TRY(hipMalloc(&m->sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     m->sort.tiles_capacity = radix_tiles(cap);
@@ -226,19 +226,28 @@ chad_status fetch_bricks(chad_map* m, int32_t submap, HostBricks& hb) {
     return CHAD_OK;
 }
 
+inline bool times_stages(const chad_map* m) { return (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0; }
+inline bool times_anything(const chad_map* m) { return (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE | CHAD_FLAG_TIME_UPDATE)) != 0; }
+
+// Every hipEventRecord costs ~6 us of stream idle time, so CHAD_FLAG_TIME_UPDATE brackets only the update kernel.
 void record(chad_map* m, Stage s) {
-    if (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) (void)hipEventRecord(m->ev[m->timed_end % chad_map::kTimingRing][s], m->stream);
+    if (times_stages(m) || ((m->flags & CHAD_FLAG_TIME_UPDATE) && (s == T_NORM || s == T_UPD)))
+        (void)hipEventRecord(m->ev[m->timed_end % chad_map::kTimingRing][s], m->stream);
 }
 
 // mean stage times over the inserts whose event sets have not been read yet (the stream must be idle)
 void collect_timing(chad_map* m) {
-    if (!(m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) || m->timed_end == m->timed_begin) return;
+    if (!times_anything(m) || m->timed_end == m->timed_begin) return;
     double sum[T_COUNT] = {};
     int count = 0;
     for (uint64_t f = m->timed_begin; f < m->timed_end; f++) {
         hipEvent_t* e = m->ev[f % chad_map::kTimingRing];
         float t = 0;
         bool ok = true;
+        if (!times_stages(m)) {  // update kernel only
+            if (hipEventElapsedTime(&t, e[T_NORM], e[T_UPD]) == hipSuccess) { sum[T_UPD] += t; count++; } else (void)hipGetLastError();
+            continue;
+        }
         for (int s = T_CALC; s < T_COUNT; s++) { if (hipEventElapsedTime(&t, e[s - 1], e[s]) != hipSuccess) { ok = false; break; } sum[s] += t; }
         if (!ok || hipEventElapsedTime(&t, e[T_BEGIN], e[T_UPD]) != hipSuccess) { (void)hipGetLastError(); continue; }
         sum[T_BEGIN] += t;
@@ -268,23 +277,28 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
     const F3 pos{position[0], position[1], position[2]};
     const uint32_t count = uint32_t(n);
     record(m, T_BEGIN);
-    hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, m->stream, m->d_hdr);
+    if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, m->stream, m->d_hdr);
     if (count) {
         uint32_t* item_start = m->d_seg + 2 * m->cap_points;
         hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_part);
-        hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0]);
+        hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0],
+                           m->sort.hist_part, m->sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))));
         record(m, T_CALC);
-        radix_sort_enqueue(m->sort, count, kMaxPasses, &m->d_hdr->sort_passes, m->stream);
+        radix_sort_enqueue(m->sort, count, kMaxPasses, &m->d_hdr->sort_passes, m->stream, kFrameBlocks);
         hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, m->recip, m->d_hdr, m->d_part, m->sort.keys[0], m->sort.keys[1],
                            m->sort.idx[0], m->sort.idx[1], m->d_pts, m->d_codes, m->d_seg, item_start);
         record(m, T_SORT);
         hipLaunchKernelGGL(k_frame_normals, dim3(256 * 24), dim3(64 * kNormalWavesPerBlock), 0, m->stream, m->d_pts, m->d_codes, m->d_seg, m->d_seg + m->cap_points, m->d_hdr, pos, m->d_normals, m->ablate);
-        record(m, T_NORM);
+        if (times_stages(m)) record(m, T_NORM);
         // CHAD_UPDATE_AUTO enqueues both forms; each looks at the frame's points-per-block ratio (device memory)
         // and exactly one of them does the work
         const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
+        if (!times_stages(m) && m->update_mode == CHAD_UPDATE_SCATTER) record(m, T_NORM);
         if (m->update_mode != CHAD_UPDATE_TILED)
             hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, m->d_pts, m->d_normals, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
+        // CHAD_FLAG_TIME_UPDATE brackets the dominant kernel alone: in auto mode the scatter launch (which returns at
+        // once for a dense frame) stays outside the bracket
+        if (!times_stages(m) && m->update_mode != CHAD_UPDATE_SCATTER) record(m, T_NORM);
         if (m->update_mode != CHAD_UPDATE_SCATTER)
             tile_update_enqueue(m->d_pts, m->d_normals, m->d_codes, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->ablate, m->d_stamps);
         record(m, T_UPD);
@@ -294,7 +308,7 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
     HIP_TRY(hipGetLastError());
     m->frames++;
     m->last_points_in = n;
-    if (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) {
+    if (times_anything(m)) {
         m->timed_end++;
         if (m->timed_end - m->timed_begin > chad_map::kTimingRing) m->timed_begin = m->timed_end - chad_map::kTimingRing;
         if (m->flags & CHAD_FLAG_VERBOSE) {  // the reference prints its five stage lines on every insert
@@ -367,7 +381,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
     CREATE_TRY(hipMemsetAsync(m->view.brick_sum, 0, blocks * 256, m->stream));
     CREATE_TRY(hipMemsetAsync(m->view.brick_cnt, 0, blocks * 256, m->stream));
-    if (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE))
+    if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
     CREATE_TRY(hipMemsetAsync(m->view.brick_count, 0, 4, m->stream));
     if (clear_active(m, true) != CHAD_OK) return bail(CHAD_ERR_HIP);

@@ -50,7 +50,9 @@ struct FramePartial {
     unsigned long long mc_min;
 };
 
-__global__ void k_frame_init(FrameHeader* h) {
+// Per-frame reset of the header (everything except the sticky overflow flag).  Runs as its own kernel only for
+// empty frames; otherwise workgroup 0 of k_frame_keys does it (nothing before k_frame_gather reads the header).
+__device__ __forceinline__ void frame_header_reset(FrameHeader* h) {
     const uint32_t keep_overflow = h->overflow;
     for (uint32_t k = threadIdx.x; k < 32 * 16; k += blockDim.x) h->n_updates[k] = 0;
     for (uint32_t k = threadIdx.x; k < kWorkGroups * 16; k += blockDim.x) h->work_cursor[k] = 0;
@@ -61,6 +63,7 @@ __global__ void k_frame_init(FrameHeader* h) {
         h->mc_min = ~0ull; h->last_idx = 0; h->overflow = keep_overflow; h->n_items = 0; h->item_cursor = 0;
     }
 }
+__global__ void k_frame_init(FrameHeader* h) { frame_header_reset(h); }
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -185,9 +188,18 @@ __device__ __forceinline__ LocalFrame combine_bounds(const FramePartial* __restr
 // get 2^bits, above every usable key, so they end up behind the n_usable usable points.
 __global__ void __launch_bounds__(256)
 k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
-             FramePartial* __restrict__ part, uint64_t* __restrict__ keys) {
+             FramePartial* __restrict__ part, uint64_t* __restrict__ keys,
+             uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words) {
+    if (blockIdx.x == 0) frame_header_reset(h);
+    // clear the radix sort's look-back table for this frame (saves a memset launch)
+    for (size_t k = size_t(blockIdx.x) * blockDim.x + threadIdx.x; k < status_words; k += size_t(gridDim.x) * blockDim.x) tile_status[k] = 0u;
     const LocalFrame f = combine_bounds(part);
     __shared__ unsigned long long wave_mc[4];
+    // digit histograms of all radix passes, taken while the key is in a register (radix_sort.hpp)
+    __shared__ uint32_t hist[kMaxPasses][kRadix];
+    const uint32_t passes = (f.bits + (f.kept < n ? 1u : 0u) + kRadixBits - 1) / kRadixBits;
+    for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += blockDim.x) (&hist[0][0])[k] = 0;
+    __syncthreads();
     const uint64_t top = 1ull << f.bits;
     const uint32_t mask_x = (1u << f.wx) - 1u, mask_y = (1u << f.wy) - 1u, mask_z = (1u << f.wz) - 1u;
     unsigned long long mc_min = ~0ull;
@@ -202,7 +214,10 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             mc_min = mc < mc_min ? mc : mc_min;
         }
         keys[i] = key;
+        for (uint32_t p = 0; p < passes; p++) atomicAdd(&hist[p][uint32_t(key >> (p * kRadixBits)) & (kRadix - 1)], 1u);
     }
+    __syncthreads();
+    for (uint32_t p = 0; p < passes; p++) hist_part[(size_t(blockIdx.x) * kMaxPasses + p) * kRadix + threadIdx.x] = hist[p][threadIdx.x];
     mc_min = wave_min_u64(mc_min);
     if ((threadIdx.x & 63) == 0) wave_mc[threadIdx.x >> 6] = mc_min;
     __syncthreads();
@@ -214,8 +229,7 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             for (int a = 0; a < 3; a++) { h->vmin[a] = f.lo[a]; h->vmax[a] = f.hi[a]; }
             h->n_usable = f.kept;
             h->axis_bits = f.bits;
-            // the extra top bit is only needed when some point is unusable
-            h->sort_passes = (f.bits + (f.kept < n ? 1u : 0u) + kRadixBits - 1) / kRadixBits;
+            h->sort_passes = passes;  // the extra top bit is only needed when some point is unusable
         }
     }
 }

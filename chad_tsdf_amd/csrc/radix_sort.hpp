@@ -28,6 +28,7 @@ constexpr int kSortWaves = kSortThreads / 64;
 constexpr uint32_t kResidentTiles = 1024;               // 4 workgroups of the pass kernel per CU (it fits 5)
 constexpr int kLookback = 8;                            // predecessor tiles read per round trip of the look-back
 constexpr int kHistBlocks = 256;                        // workgroups of the histogram kernel (one partial table each)
+constexpr int kMaxHistBlocks = 512;                     // partial tables the buffers have room for
 
 constexpr uint32_t kStatusAggregate = 1u << 30;         // the tile's own digit counts are published
 constexpr uint32_t kStatusInclusive = 2u << 30;         // counts of this tile AND all tiles before it
@@ -55,11 +56,13 @@ inline uint32_t radix_tiles(size_t n) { return uint32_t((n + kSortTile - 1) / kS
 inline size_t radix_status_words(uint32_t tiles) { return size_t(kMaxPasses) * tiles * kRadix + 64; }
 
 // pass_limit (device word, may be null): passes >= *pass_limit are skipped by every kernel.
+// Also clears the look-back table of the coming passes (saves a memset launch).
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_histograms(const uint64_t* __restrict__ keys, uint32_t n, uint32_t passes, const uint32_t* __restrict__ pass_limit,
-                   uint32_t* __restrict__ hist_part) {
+                   uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words) {
     __shared__ uint32_t hist[kMaxPasses][kRadix];
     const uint32_t active = pass_limit ? min(passes, *pass_limit) : passes;
+    for (size_t k = size_t(blockIdx.x) * kSortThreads + threadIdx.x; k < status_words; k += size_t(gridDim.x) * kSortThreads) tile_status[k] = 0u;
     for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += kSortThreads) (&hist[0][0])[k] = 0;
     __syncthreads();
     for (size_t i = size_t(blockIdx.x) * kSortThreads + threadIdx.x; i < n; i += size_t(gridDim.x) * kSortThreads) {
@@ -232,13 +235,19 @@ k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
 // Enqueue a sort of n pairs over key bits [0, 8*passes).  Input in keys[0] (idx[0] unused: the payload of the
 // first pass is the position); the result of pass p lands in buffer (p+1)&1, so with *pass_limit = L <= passes
 // active passes the sorted data is in buffer (L & 1).
-inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream) {
+// hist_blocks == 0: the digit histograms are computed here (k_radix_histograms, which also clears the look-back
+// table); otherwise the caller's key-producing kernel has already written hist_blocks partial tables into
+// b.hist_part AND cleared b.tile_status (k_frame_keys does both while it still holds the keys in registers).
+inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
-    (void)hipMemsetAsync(b.tile_status, 0, radix_status_words(tiles) * 4, stream);
     uint32_t* ticket = b.tile_status + size_t(kMaxPasses) * tiles * kRadix;
-    hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part);
-    hipLaunchKernelGGL(k_radix_bases, dim3(passes), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
+    if (hist_blocks == 0) {
+        hist_blocks = kHistBlocks;
+        hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part, b.tile_status,
+                           uint32_t(radix_status_words(tiles)));
+    }
+    hipLaunchKernelGGL(k_radix_bases, dim3(passes), dim3(4 * kRadix), 0, stream, b.hist_part, hist_blocks, passes, pass_limit, b.digit_base);
     for (uint32_t p = 0; p < passes; p++) {
         const int src = p & 1, dst = src ^ 1;
         hipLaunchKernelGGL(k_radix_onesweep, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[src], p == 0 ? nullptr : b.idx[src], b.keys[dst], b.idx[dst], n, p,

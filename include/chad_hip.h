@@ -46,8 +46,10 @@ typedef struct chad_options {
 
 enum {
     CHAD_FLAG_VERBOSE = 1u, /* print the reference's five stage-timer lines per insert (morton.hpp:78,100; normals.hpp:146; octree.hpp:169; tsdf.cpp:74) */
-    CHAD_FLAG_TIMING = 2u   /* record per-stage device times with HIP events on the map's stream (no extra synchronisation);
-                               chad_map_stats reports their mean over the inserts since the previous stats call (at most 64) */
+    CHAD_FLAG_TIMING = 2u,  /* record per-stage device times with HIP events on the map's stream (no extra synchronisation);
+                               chad_map_stats reports their mean over the inserts since the previous stats call (at most 64).
+                               Each event costs ~6 us of stream time: five per insert */
+    CHAD_FLAG_TIME_UPDATE = 4u /* as CHAD_FLAG_TIMING, but only the TSDF-update kernel is bracketed (ms_oct_upd): two events per insert */
 };
 enum {
     CHAD_UPDATE_AUTO = 0,    /* chosen per frame on the device from its points-per-block ratio (default) */
