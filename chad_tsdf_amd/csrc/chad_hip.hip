@@ -73,6 +73,9 @@ struct chad_map {
     FrameHeader* d_hdr = nullptr;
     FrameHeader* h_hdr = nullptr;  // pinned
     FramePartial* d_part = nullptr;  // kFrameBlocks partial reductions of the frame kernels
+    volatile uint32_t* h_live_blocks = nullptr;  // host-mapped word the device mirrors the live block count into each frame
+    uint32_t* d_live_blocks = nullptr;           // (its device address): lets the host grow the pools without a round trip
+    bool fixed_capacity = false;
 
     size_t cap_points = 0;
     float* d_xyz = nullptr;  // staging for host inserts
@@ -146,12 +149,37 @@ chad_status ensure_frame_capacity(chad_map* m, size_t n) {
     return CHAD_OK;
 }
 
+void free_map_storage(MapView& v) {
+    (void)hipFree(v.hash_keys); (void)hipFree(v.hash_vals); (void)hipFree(v.brick_key); (void)hipFree(v.brick_slot);
+    (void)hipFree(v.brick_sum); (void)hipFree(v.brick_cnt); (void)hipFree(v.brick_count);
+    v = MapView{};
+}
+
+// Hash table + brick pools for `blocks` bricks, empty (keys EMPTY, values PENDING, sums and counts zero).
+chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream) {
+    uint64_t hcap = 1024;
+    while (hcap < blocks * 2) hcap <<= 1;  // load factor <= 0.5
+    v = MapView{};
+    HIP_TRY(hipMalloc(&v.hash_keys, hcap * 8));
+    HIP_TRY(hipMalloc(&v.hash_vals, hcap * 4));
+    HIP_TRY(hipMalloc(&v.brick_key, blocks * 8));
+    HIP_TRY(hipMalloc(&v.brick_slot, blocks * 4));
+    HIP_TRY(hipMalloc(&v.brick_sum, blocks * 256));
+    HIP_TRY(hipMalloc(&v.brick_cnt, blocks * 256));
+    HIP_TRY(hipMalloc(&v.brick_count, 4));
+    v.hash_mask = uint32_t(hcap - 1);
+    v.brick_capacity = uint32_t(blocks);
+    hipLaunchKernelGGL(k_fill_u64, grid_for(hcap), dim3(256), 0, stream, v.hash_keys, size_t(hcap), kEmptyKey);
+    hipLaunchKernelGGL(k_fill_u32, grid_for(hcap), dim3(256), 0, stream, v.hash_vals, size_t(hcap), kPending);
+    HIP_TRY(hipMemsetAsync(v.brick_sum, 0, blocks * 256, stream));
+    HIP_TRY(hipMemsetAsync(v.brick_cnt, 0, blocks * 256, stream));
+    HIP_TRY(hipMemsetAsync(v.brick_count, 0, 4, stream));
+    HIP_TRY(hipGetLastError());
+    return CHAD_OK;
+}
+
 // Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  Fully asynchronous.
-chad_status clear_active(chad_map* m, bool whole_table) {
-    if (whole_table) {
-        hipLaunchKernelGGL(k_fill_u64, grid_for(m->hash_capacity), dim3(256), 0, m->stream, m->view.hash_keys, size_t(m->hash_capacity), kEmptyKey);
-        hipLaunchKernelGGL(k_fill_u32, grid_for(m->hash_capacity), dim3(256), 0, m->stream, m->view.hash_vals, size_t(m->hash_capacity), kPending);
-    }
+chad_status clear_active(chad_map* m) {
     hipLaunchKernelGGL(k_clear_bricks, dim3(1024), dim3(256), 0, m->stream, m->view);
     HIP_TRY(hipMemsetAsync(m->view.brick_count, 0, 4, m->stream));
     HIP_TRY(hipGetLastError());
@@ -190,7 +218,7 @@ chad_status close_active(chad_map* m) {
         hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(blocks) * 64), dim3(256), 0, m->stream, (const uint32_t*)nullptr, blocks, m->view.brick_key,
                            m->view.brick_sum, m->view.brick_cnt, s.keys, s.sum, s.cnt);
     m->closed.push_back(s);
-    return clear_active(m, false);
+    return clear_active(m);
 }
 
 chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const uint64_t** keys, const float** sum, const uint32_t** cnt) {
@@ -230,6 +258,33 @@ inline bool times_stages(const chad_map* m) { return (m->flags & (CHAD_FLAG_TIMI
 inline bool times_anything(const chad_map* m) { return (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE | CHAD_FLAG_TIME_UPDATE)) != 0; }
 
 // Every hipEventRecord costs ~6 us of stream idle time, so CHAD_FLAG_TIME_UPDATE brackets only the update kernel.
+// The reference's storage is effectively unbounded (VirtualArray reserves 4 GiB of address space per octree,
+// virtual_array.hpp:16-19).  Here the pools double when the live block count -- mirrored by the device into host-mapped
+// memory once per frame -- passes half the capacity: new pools, device-to-device copy of the bricks, re-insertion of
+// the keys into a new hash.  Happens between frames; a single frame that outruns the remaining half still reports
+// CHAD_ERR_CAPACITY.
+chad_status grow_if_needed(chad_map* m) {
+    if (m->fixed_capacity || *m->h_live_blocks < m->brick_capacity / 2 || m->brick_capacity >= (1u << 30)) return CHAD_OK;
+    uint32_t live = 0;
+    TRY(read_block_count(m, &live));
+    if (live < m->brick_capacity / 2) return CHAD_OK;
+    MapView bigger;
+    const uint64_t blocks = std::min<uint64_t>(uint64_t(m->brick_capacity) * 2, 1ull << 30);
+    const chad_status s = alloc_map_storage(bigger, blocks, m->stream);
+    if (s != CHAD_OK) { free_map_storage(bigger); m->fixed_capacity = true; g_error.clear(); return CHAD_OK; }  // keep going at the old size
+    HIP_TRY(hipMemcpyAsync(bigger.brick_key, m->view.brick_key, size_t(live) * 8, hipMemcpyDeviceToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(bigger.brick_sum, m->view.brick_sum, size_t(live) * 256, hipMemcpyDeviceToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(bigger.brick_cnt, m->view.brick_cnt, size_t(live) * 256, hipMemcpyDeviceToDevice, m->stream));
+    if (live) hipLaunchKernelGGL(k_rehash_bricks, grid_for(live), dim3(256), 0, m->stream, bigger, live, m->d_hdr);
+    HIP_TRY(hipMemcpyAsync(bigger.brick_count, &live, 4, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    free_map_storage(m->view);
+    m->view = bigger;
+    m->brick_capacity = bigger.brick_capacity; m->hash_capacity = bigger.hash_mask + 1;
+    *m->h_live_blocks = live;
+    return CHAD_OK;
+}
+
 void record(chad_map* m, Stage s) {
     if (times_stages(m) || ((m->flags & CHAD_FLAG_TIME_UPDATE) && (s == T_NORM || s == T_UPD)))
         (void)hipEventRecord(m->ev[m->timed_end % chad_map::kTimingRing][s], m->stream);
@@ -274,6 +329,7 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
         } else m->positions.push_back(pose);
     }
 
+    TRY(grow_if_needed(m));
     const F3 pos{position[0], position[1], position[2]};
     const uint32_t count = uint32_t(n);
     record(m, T_BEGIN);
@@ -282,7 +338,7 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
         uint32_t* item_start = m->d_seg + 2 * m->cap_points;
         hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_part);
         hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0],
-                           m->sort.hist_part, m->sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))));
+                           m->sort.hist_part, m->sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
         record(m, T_CALC);
         radix_sort_enqueue(m->sort, count, kMaxPasses, &m->d_hdr->sort_passes, m->stream, kFrameBlocks);
         hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, m->recip, m->d_hdr, m->d_part, m->sort.keys[0], m->sort.keys[1],
@@ -354,6 +410,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->recip = float(1.0 / double(sdf_res));  // morton.hpp:63, octree.hpp:82
     m->device = dev; m->flags = o.flags;
     m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
+    m->fixed_capacity = (o.flags & CHAD_FLAG_FIXED_CAPACITY) != 0;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
     if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)hipMalloc(&m->d_stamps, 8192 * 8 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 8 * 8); }
     auto bail = [&](chad_status s) { chad_map_destroy(m); return s; };
@@ -364,27 +421,17 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
 
     uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
     if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
-    uint64_t hcap = 1024;
-    while (hcap < blocks * 2) hcap <<= 1;  // load factor <= 0.5
-    m->brick_capacity = uint32_t(blocks); m->hash_capacity = uint32_t(hcap);
-    CREATE_TRY(hipMalloc(&m->view.hash_keys, hcap * 8));
-    CREATE_TRY(hipMalloc(&m->view.hash_vals, hcap * 4));
-    CREATE_TRY(hipMalloc(&m->view.brick_key, blocks * 8));
-    CREATE_TRY(hipMalloc(&m->view.brick_sum, blocks * 256));
-    CREATE_TRY(hipMalloc(&m->view.brick_cnt, blocks * 256));
-    CREATE_TRY(hipMalloc(&m->view.brick_slot, blocks * 4));
-    CREATE_TRY(hipMalloc(&m->view.brick_count, 4));
+    if (alloc_map_storage(m->view, blocks, m->stream) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
+    m->brick_capacity = m->view.brick_capacity; m->hash_capacity = m->view.hash_mask + 1;
     CREATE_TRY(hipMalloc(&m->d_hdr, sizeof(FrameHeader)));
     CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
+    CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
+    *m->h_live_blocks = 0;
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
     CREATE_TRY(hipMalloc(&m->d_part, sizeof(FramePartial) * kFrameBlocks));
-    m->view.hash_mask = uint32_t(hcap - 1); m->view.brick_capacity = uint32_t(blocks);
     CREATE_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
-    CREATE_TRY(hipMemsetAsync(m->view.brick_sum, 0, blocks * 256, m->stream));
-    CREATE_TRY(hipMemsetAsync(m->view.brick_cnt, 0, blocks * 256, m->stream));
     if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
-    CREATE_TRY(hipMemsetAsync(m->view.brick_count, 0, 4, m->stream));
-    if (clear_active(m, true) != CHAD_OK) return bail(CHAD_ERR_HIP);
     if (ensure_frame_capacity(m, o.max_points ? o.max_points : (1u << 20)) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     CREATE_TRY(hipStreamSynchronize(m->stream));
 #undef CREATE_TRY
@@ -407,9 +454,9 @@ void chad_map_destroy(chad_map* m) {
     }
     free_frame_buffers(m);
     for (auto& s : m->closed) free_submap(s);
-    (void)hipFree(m->view.hash_keys); (void)hipFree(m->view.hash_vals); (void)hipFree(m->view.brick_key);
-    (void)hipFree(m->view.brick_sum); (void)hipFree(m->view.brick_cnt); (void)hipFree(m->view.brick_count);
-    (void)hipFree(m->view.brick_slot); (void)hipFree(m->d_hdr); (void)hipFree(m->d_part);
+    free_map_storage(m->view);
+    (void)hipFree(m->d_hdr); (void)hipFree(m->d_part);
+    if (m->h_live_blocks) (void)hipHostFree(const_cast<uint32_t*>(m->h_live_blocks));
     if (m->h_hdr) (void)hipHostFree(m->h_hdr);
     for (auto& set : m->ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
@@ -455,7 +502,7 @@ chad_status chad_map_reset(chad_map* m) {
     }
     m->positions.clear();
     HIP_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
-    return clear_active(m, false);
+    return clear_active(m);
 }
 
 chad_status chad_map_close_submap(chad_map* m) {
@@ -555,7 +602,7 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
     }
     m->closed.push_back(s);
     m->positions.clear();
-    TRY(clear_active(m, false));
+    TRY(clear_active(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHAD_OK;
 }

@@ -189,8 +189,10 @@ __device__ __forceinline__ LocalFrame combine_bounds(const FramePartial* __restr
 __global__ void __launch_bounds__(256)
 k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
              FramePartial* __restrict__ part, uint64_t* __restrict__ keys,
-             uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words) {
+             uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words,
+             const uint32_t* __restrict__ live_blocks, uint32_t* __restrict__ live_blocks_host) {
     if (blockIdx.x == 0) frame_header_reset(h);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *live_blocks_host = *live_blocks;  // host-mapped: capacity growth hint
     // clear the radix sort's look-back table for this frame (saves a memset launch)
     for (size_t k = size_t(blockIdx.x) * blockDim.x + threadIdx.x; k < status_words; k += size_t(gridDim.x) * blockDim.x) tile_status[k] = 0u;
     const LocalFrame f = combine_bounds(part);
@@ -429,7 +431,7 @@ constexpr int kNormalWavesPerBlock = 1;  // one wave per workgroup: __syncthread
 
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 
-__global__ void __launch_bounds__(64 * kNormalWavesPerBlock)
+__global__ void __launch_bounds__(64 * kNormalWavesPerBlock, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
 k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ seg_start,
                 uint32_t* __restrict__ seg_len, FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
     __shared__ NormalScratch s;

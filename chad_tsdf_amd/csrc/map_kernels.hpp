@@ -198,6 +198,23 @@ k_clear_bricks(MapView m) {
     }
 }
 
+// Rebuild the hash of a grown map: brick b (key already copied) takes a slot of the new, larger table.
+__global__ void k_rehash_bricks(MapView m, uint32_t blocks, FrameHeader* __restrict__ h) {
+    for (size_t b = size_t(blockIdx.x) * blockDim.x + threadIdx.x; b < blocks; b += size_t(gridDim.x) * blockDim.x) {
+        const uint64_t key = m.brick_key[b];
+        uint32_t slot = hash_block(key, m.hash_mask);
+        for (uint32_t probes = 0; probes <= m.hash_mask; probes++) {
+            if (atomicCAS((unsigned long long*)&m.hash_keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key) == kEmptyKey) {
+                m.hash_vals[slot] = uint32_t(b);
+                m.brick_slot[b] = slot;
+                break;
+            }
+            slot = (slot + 1) & m.hash_mask;
+        }
+    }
+    (void)h;
+}
+
 // keys for sorting bricks by block key: key' = brick_key (ascending), payload = brick index (implicit)
 __global__ void k_copy_u64(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t n) {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) dst[i] = src[i];

@@ -31,6 +31,10 @@ def merge_blocks(keys: torch.Tensor, sums: torch.Tensor, cnts: torch.Tensor, gro
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return keys, sums, cnts
+    home = keys.device
+    if keys.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal of the GPU path over gloo: collectives on host copies
+        merged = merge_blocks(keys.cpu(), sums.cpu(), cnts.cpu(), group)
+        return tuple(t.to(home) for t in merged)
     dev = keys.device
     n_local = torch.tensor([keys.numel()], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n_local) for _ in range(world)]

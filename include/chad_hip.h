@@ -29,7 +29,7 @@ enum {
     CHAD_ERR_INVALID_ARG = 1, /* null handle/pointer, non-positive resolution, bad submap index */
     CHAD_ERR_NO_DEVICE = 2,   /* no HIP device, or the gfx950 code object cannot be loaded (never falls back to a CPU path) */
     CHAD_ERR_OUT_OF_MEMORY = 3, /* reference: std::runtime_error from mmap failure, virtual_array.cpp:16-20 */
-    CHAD_ERR_CAPACITY = 4,    /* block pool or block hash of the active submap is full; the frame was partially dropped */
+    CHAD_ERR_CAPACITY = 4,    /* a single frame outran the block pool (growth happens between frames); that frame was partially dropped */
     CHAD_ERR_HIP = 5          /* any other HIP runtime failure */
 };
 
@@ -37,7 +37,8 @@ enum {
 typedef struct chad_options {
     uint32_t struct_size;
     int32_t device;      /* HIP device ordinal; -1 = the calling thread's current device */
-    uint64_t max_blocks; /* capacity of the active submap in 4x4x4-voxel blocks (520 B of HBM each); 0 = default (1<<21) */
+    uint64_t max_blocks; /* initial capacity of the active submap in 4x4x4-voxel blocks (532 B of HBM each); 0 = default (1<<21).
+                            Doubles automatically between frames when half full, unless CHAD_FLAG_FIXED_CAPACITY */
     uint64_t max_points; /* initial per-frame point capacity (grows on demand); 0 = default (1<<20) */
     void* stream;        /* hipStream_t to enqueue on; NULL = a stream owned by the map */
     uint32_t flags;      /* CHAD_FLAG_* */
@@ -49,7 +50,8 @@ enum {
     CHAD_FLAG_TIMING = 2u,  /* record per-stage device times with HIP events on the map's stream (no extra synchronisation);
                                chad_map_stats reports their mean over the inserts since the previous stats call (at most 64).
                                Each event costs ~6 us of stream time: five per insert */
-    CHAD_FLAG_TIME_UPDATE = 4u /* as CHAD_FLAG_TIMING, but only the TSDF-update kernel is bracketed (ms_oct_upd): two events per insert */
+    CHAD_FLAG_TIME_UPDATE = 4u, /* as CHAD_FLAG_TIMING, but only the TSDF-update kernel is bracketed (ms_oct_upd): two events per insert */
+    CHAD_FLAG_FIXED_CAPACITY = 8u /* never grow the block pool beyond max_blocks (default: it doubles between frames when half full) */
 };
 enum {
     CHAD_UPDATE_AUTO = 0,    /* chosen per frame on the device from its points-per-block ratio (default) */

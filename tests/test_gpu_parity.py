@@ -204,7 +204,7 @@ def test_last_point_rule(chad, oracle):
 
 def test_capacity_overflow_is_reported(chad):
     pts, pos = synth.cfg2_frame(50_000)
-    m = chad.TSDFMap(0.05, 0.10, max_blocks=1000)  # the frame touches ~9 k blocks
+    m = chad.TSDFMap(0.05, 0.10, max_blocks=1000)  # one frame touches ~9 k blocks: growth happens between frames, so this overflows
     m.insert(pts, pos)
     with pytest.raises(chad._lib.ChadError) as err:
         m.sync()
@@ -237,4 +237,21 @@ def test_save_writes_first_submap(chad, tmp_path):
     head = path.read_bytes()[:400].decode(errors="replace")
     n = len(m.export_leaves(0)[0])
     assert f"element vertex {n}" in head
+    m.close()
+
+
+def test_block_pool_grows_between_frames(chad, oracle):
+    """A stream that outgrows the initial pool: capacity doubles between frames (the reference's storage is unbounded),
+    and the result still matches the oracle."""
+    m = chad.TSDFMap(0.05, 0.10, max_blocks=20_000)
+    o = oracle.OracleMap(0.05, 0.10)
+    for k in range(12):  # 8.7 k blocks after the first frame, 10.7 k (> half) after the second, 17.9 k at the end
+        pts, _ = synth.cfg3_frame(8 * k, 20_000)
+        pos = np.array([-12.0 + 0.3 * k, 0.1, 0.0], dtype=np.float32)
+        m.insert(pts, pos)
+        o.insert(pts, pos)
+    m.sync()
+    st = m.stats()
+    assert st["overflow"] == 0 and st["block_capacity"] == 40_000 and st["blocks"] == int(o.stats()["blocks"])
+    assert_leaves_match(m.export_leaves(), o.export_leaves(), 0.10)
     m.close()
