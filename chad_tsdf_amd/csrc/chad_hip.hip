@@ -78,7 +78,10 @@ struct chad_map {
     bool fixed_capacity = false;
 
     size_t cap_points = 0;
-    float* d_xyz = nullptr;  // staging for host inserts
+    float* d_xyz = nullptr;  // device copy of a host frame
+    float* h_stage[2] = {nullptr, nullptr};  // pinned staging ring for chad_map_insert (host points), cap_points * 12 bytes each
+    hipEvent_t stage_done[2] = {nullptr, nullptr};  // the H2D copies out of h_stage[i] have completed
+    uint32_t stage_turn = 0;
     RadixSortBuffers sort{};
     float4* d_pts = nullptr;
     uint64_t* d_codes = nullptr;
@@ -118,6 +121,7 @@ inline dim3 grid_for(size_t n, int threads = 256, int max_blocks = 2048) {
 }
 
 void free_frame_buffers(chad_map* m) {
+    for (int i = 0; i < 2; i++) { if (m->h_stage[i]) (void)hipHostFree(m->h_stage[i]); m->h_stage[i] = nullptr; }
     (void)hipFree(m->d_xyz); (void)hipFree(m->sort.keys[0]); (void)hipFree(m->sort.keys[1]);
     (void)hipFree(m->sort.idx[0]); (void)hipFree(m->sort.idx[1]); (void)hipFree(m->sort.hist_part);
     (void)hipFree(m->sort.digit_base); (void)hipFree(m->sort.tile_status);
@@ -459,6 +463,7 @@ void chad_map_destroy(chad_map* m) {
     if (m->h_live_blocks) (void)hipHostFree(const_cast<uint32_t*>(m->h_live_blocks));
     if (m->h_hdr) (void)hipHostFree(m->h_hdr);
     for (auto& set : m->ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->stage_done) if (e) (void)hipEventDestroy(e);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -475,10 +480,22 @@ chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float
     DeviceGuard guard(m->device);
     TRY(ensure_frame_capacity(m, n));
     if (n) {
-        HIP_TRY(hipMemcpyAsync(m->d_xyz, xyz, n * 12, hipMemcpyHostToDevice, m->stream));
-        // the caller's buffer is only borrowed for the duration of the call (pageable memory: the copy has been
-        // staged when hipMemcpyAsync returns; pinned memory: wait for it)
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        // The caller's buffer is borrowed for the duration of the call only: copy it into a pinned staging buffer
+        // (two of them, alternating, so the next frame can be staged while this one is still in flight) in chunks,
+        // each chunk's DMA overlapping the CPU copy of the next.  No device synchronisation: insert() returns as soon
+        // as the last chunk is staged, and the host copy of frame k+1 overlaps the kernels of frame k.
+        const uint32_t turn = m->stage_turn++ & 1u;
+        if (!m->h_stage[turn]) {
+            HIP_TRY(hipHostMalloc(&m->h_stage[turn], m->cap_points * 12, hipHostMallocDefault));
+            if (!m->stage_done[turn]) HIP_TRY(hipEventCreateWithFlags(&m->stage_done[turn], hipEventDisableTiming));
+        } else HIP_TRY(hipEventSynchronize(m->stage_done[turn]));  // its previous frame (two inserts ago) has left the buffer
+        const size_t chunk = size_t(1) << 18;  // points per chunk (3 MiB)
+        for (size_t at = 0; at < n; at += chunk) {
+            const size_t len = std::min(chunk, n - at);
+            std::memcpy(m->h_stage[turn] + 3 * at, xyz + 3 * at, len * 12);
+            HIP_TRY(hipMemcpyAsync(m->d_xyz + 3 * at, m->h_stage[turn] + 3 * at, len * 12, hipMemcpyHostToDevice, m->stream));
+        }
+        HIP_TRY(hipEventRecord(m->stage_done[turn], m->stream));
     }
     return insert_device(m, m->d_xyz, n, position);
 }
