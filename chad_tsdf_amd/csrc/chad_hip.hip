@@ -450,10 +450,15 @@ void chad_map_destroy(chad_map* m) {
     if (m->d_stamps) {  // diagnostic: mean cycles per phase over the waves of the last update launch
         std::vector<unsigned long long> st(8192 * 8);
         (void)hipMemcpy(st.data(), m->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
-        double sum[8] = {}; unsigned long long life_max = 0; int waves = 0;
-        for (int w = 0; w < 8192; w++) { if (!st[w * 8 + 5]) continue; waves++; for (int k = 0; k < 8; k++) sum[k] += double(st[w * 8 + k]); life_max = std::max(life_max, st[w * 8 + 5]); }
-        if (waves) std::fprintf(stderr, "stamps: waves %d  dequeue+meta %.0f  load %.0f  begin %.0f  walk %.0f  readback %.0f  lookup %.0f  flushloop %.0f  life %.0f (max %llu)\n", waves, sum[0] / waves,
-                                sum[1] / waves, sum[2] / waves, sum[3] / waves, sum[6] / waves, sum[7] / waves, sum[4] / waves, sum[5] / waves, life_max);
+        std::vector<unsigned long long> life, start, items;
+        for (int w = 0; w < 8192; w++) { if (!st[w * 8 + 5]) continue; life.push_back(st[w * 8 + 5]); start.push_back(st[w * 8 + 1]); items.push_back(st[w * 8 + 2]); }
+        if (!life.empty()) {
+            auto pct = [](std::vector<unsigned long long> v, double p) { std::sort(v.begin(), v.end()); return v[size_t(p * (v.size() - 1))]; };
+            const unsigned long long s0 = pct(start, 0.0);
+            std::fprintf(stderr, "stamps: waves %zu  life p10 %llu p50 %llu p90 %llu max %llu | start p50 +%llu p90 +%llu max +%llu | items p10 %llu p50 %llu p90 %llu max %llu\n", life.size(),
+                         pct(life, 0.1), pct(life, 0.5), pct(life, 0.9), pct(life, 1.0), pct(start, 0.5) - s0, pct(start, 0.9) - s0, pct(start, 1.0) - s0,
+                         pct(items, 0.1), pct(items, 0.5), pct(items, 0.9), pct(items, 1.0));
+        }
         (void)hipFree(m->d_stamps);
     }
     free_frame_buffers(m);

@@ -103,7 +103,7 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
     // group while no counter sees more than a few dozen atomics.
     const uint32_t wave_global = blockIdx.x * kTileWaves + wave_in_group;
     const uint32_t group = wave_global % kWorkGroups;
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t_begin = 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t_begin = 0, items_done = 0;
     if (kStamps) t_begin = stamp_now();
     auto take_ticket = [&]() {  // one returning atomic per wave and item, broadcast through an SGPR
         uint32_t v = 0;
@@ -116,6 +116,7 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
         const uint32_t item = group + kWorkGroups * turn;
         if (item >= nitems) break;
         turn = take_ticket();  // the next item's ticket is fetched while this one is processed
+        if (kStamps) items_done++;
         const uint32_t first = item_start[item];
         const uint64_t block = codes[first] >> 6;
         // the item ends at the next point block, at the next multiple of kItemPoints, or at the frame's end
@@ -179,7 +180,7 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
             return in ? tx + D * ty + D * D * tz : -1;
         };
         uint32_t touched = 0;
-#pragma unroll
+#pragma unroll 1
         for (int b = 0; b < 27; b++) {
             const int at = cell_of(b);
             const unsigned long long cell = at >= 0 ? tile[at] : 0ull;
@@ -215,6 +216,8 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
     }
     if (kStamps && lane == 0) {
         ph[5] = stamp_now() - t_begin;
+        ph[1] = t_begin;        // diagnostic build only: start time and items done replace the load/begin slots
+        ph[2] = items_done;
         for (int k = 0; k < 8; k++) stamps[size_t(wave_global) * 8 + k] = ph[k];
     }
 #pragma unroll
