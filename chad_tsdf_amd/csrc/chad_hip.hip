@@ -148,7 +148,7 @@ chad_status ensure_frame_capacity(chad_map* m, size_t n) {
     HIP_TRY(hipMalloc(&m->d_pts, cap * 16));
     HIP_TRY(hipMalloc(&m->d_codes, cap * 8));
     HIP_TRY(hipMalloc(&m->d_normals, cap * 16));
-    HIP_TRY(hipMalloc(&m->d_seg, cap * 16));  // point-block starts [cap], lengths [cap], update work items [2*cap]
+    HIP_TRY(hipMalloc(&m->d_seg, cap * 24));  // point-block starts [cap], lengths [cap], update work items (start, length) [2*cap]
     m->cap_points = cap;
     return CHAD_OK;
 }
@@ -183,9 +183,9 @@ chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream) {
 }
 
 // Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  Fully asynchronous.
-chad_status clear_active(chad_map* m) {
+chad_status clear_active(chad_map* m, bool clear_overflow = false) {
     hipLaunchKernelGGL(k_clear_bricks, dim3(1024), dim3(256), 0, m->stream, m->view);
-    HIP_TRY(hipMemsetAsync(m->view.brick_count, 0, 4, m->stream));
+    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, m->stream, m->view.brick_count, m->d_hdr, clear_overflow ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
 }
@@ -339,7 +339,7 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
     record(m, T_BEGIN);
     if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, m->stream, m->d_hdr);
     if (count) {
-        uint32_t* item_start = m->d_seg + 2 * m->cap_points;
+        uint2* item_start = reinterpret_cast<uint2*>(m->d_seg + 2 * m->cap_points);
         hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_part);
         hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0],
                            m->sort.hist_part, m->sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
@@ -523,8 +523,7 @@ chad_status chad_map_reset(chad_map* m) {
         m->closed.clear();
     }
     m->positions.clear();
-    HIP_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
-    return clear_active(m);
+    return clear_active(m, true);
 }
 
 chad_status chad_map_close_submap(chad_map* m) {

@@ -238,17 +238,20 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
 
 // Stage 3 (after the sort): gather the points into processing order as float4 (x, y, z, input index), recompute
 // their global codes, and list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
-// normal estimation and (b) the update work items in item_start[]: the point blocks cut again at every
-// kItemPoints-th point, so that no item is longer than kItemPoints.  Both lists are unordered; a workgroup
-// collects its entries in LDS and reserves output space with ONE atomic per list and chunk.
+// normal estimation and (b) the update work items (start, length) in items[]: the point blocks cut again at
+// every kItemPoints-th point, so that no item is longer than kItemPoints.  A workgroup collects its entries in
+// LDS (block heads as a list, item starts as a 2048-bit mask whose next set bit gives an item's length) and
+// reserves output space with ONE atomic per list and chunk; the lists are in no particular order.
 // The sorted (key, idx) pairs are in sort buffer (sort_passes & 1).
 __global__ void __launch_bounds__(256)
 k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const uint32_t* __restrict__ idx0, const uint32_t* __restrict__ idx1,
-               float4* __restrict__ pts, uint64_t* __restrict__ codes, uint32_t* __restrict__ seg_start, uint32_t* __restrict__ item_start) {
-    __shared__ uint32_t heads[kGatherChunk], marks[kGatherChunk];
-    __shared__ uint32_t n_heads, n_marks, base_heads, base_marks;
+               float4* __restrict__ pts, uint64_t* __restrict__ codes, uint32_t* __restrict__ seg_start, uint2* __restrict__ items) {
+    __shared__ uint32_t heads[kGatherChunk];
+    __shared__ uint32_t mark_bits[kGatherChunk / 32];  // bit k: point k of the chunk starts a work item
+    __shared__ uint32_t word_rank[kGatherChunk / 32], word_next[kGatherChunk / 32];
+    __shared__ uint32_t n_heads, base_heads, base_marks;
     __shared__ unsigned long long wave_mc[4], block_mc_min;
     // frame-wide smallest code from the keys kernel's partials
     {
@@ -272,7 +275,8 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
     const uint32_t* idx = odd ? idx1 : idx0;
     const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        if (threadIdx.x == 0) { n_heads = 0; n_marks = 0; }
+        if (threadIdx.x == 0) n_heads = 0;
+        if (threadIdx.x < kGatherChunk / 32) mark_bits[threadIdx.x] = 0u;
         __syncthreads();
 #pragma unroll
         for (uint32_t j = 0; j < kGatherChunk / 256; j++) {
@@ -286,18 +290,34 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
                 codes[i] = mc;
                 const bool head = i == 0 || (keys[i] >> 6) != (keys[i - 1] >> 6);
                 if (head) heads[atomicAdd(&n_heads, 1u)] = i;
-                if (head || (i % kItemPoints) == 0) marks[atomicAdd(&n_marks, 1u)] = i;
+                if (head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (mc == mc_min) atomicMax(&h->last_idx, src);
             }
         }
         __syncthreads();
+        // work items: every mark opens an item that runs to the next mark, or to the end of the chunk (chunks start at a
+        // multiple of kItemPoints, i.e. at a mark, so items never span chunks)
+        const uint32_t chunk_len = min(uint32_t(kGatherChunk), n - c * kGatherChunk);
         if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t w = 0; w < kGatherChunk / 32; w++) { word_rank[w] = run; run += __popc(mark_bits[w]); }
+            uint32_t later = chunk_len;  // position of the first mark in a later word
+            for (int w = kGatherChunk / 32 - 1; w >= 0; w--) { word_next[w] = later; if (mark_bits[w]) later = uint32_t(w) * 32u + uint32_t(__ffs(int(mark_bits[w])) - 1); }
             base_heads = n_heads ? atomicAdd(&h->n_segments, n_heads) : 0u;
-            base_marks = n_marks ? atomicAdd(&h->n_items, n_marks) : 0u;
+            base_marks = run ? atomicAdd(&h->n_items, run) : 0u;
         }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n_heads; k += 256) seg_start[base_heads + k] = heads[k];
-        for (uint32_t k = threadIdx.x; k < n_marks; k += 256) item_start[base_marks + k] = marks[k];
+#pragma unroll
+        for (uint32_t j = 0; j < kGatherChunk / 256; j++) {
+            const uint32_t k = j * 256 + threadIdx.x, word = mark_bits[k >> 5], bit = k & 31u;
+            if (k < chunk_len && ((word >> bit) & 1u)) {
+                const uint32_t rank = word_rank[k >> 5] + __popc(word & ((1u << bit) - 1u));
+                const uint32_t higher = bit == 31u ? 0u : word >> (bit + 1u);
+                const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[k >> 5];
+                items[base_marks + rank] = make_uint2(c * kGatherChunk + k, min(next, chunk_len) - k);
+            }
+        }
         __syncthreads();
     }
 }

@@ -180,7 +180,7 @@ k_import_bricks(const uint64_t* __restrict__ keys, const float* __restrict__ sum
 
 // Octree::clear() (octree.hpp:22-29) in O(bricks) and without a host round trip: the number of live bricks is read
 // from device memory; one wave per brick releases its hash slot and zeroes its two 256-byte rows.
-// (The counter itself is reset by a memset enqueued behind this kernel.)
+// (The counter itself is reset by k_reset_counters enqueued behind this kernel.)
 __global__ void __launch_bounds__(256)
 k_clear_bricks(MapView m) {
     const uint32_t blocks = min(*m.brick_count, m.brick_capacity);
@@ -196,6 +196,11 @@ k_clear_bricks(MapView m) {
         m.brick_sum[size_t(b) * 64 + lane] = 0.0f;
         m.brick_cnt[size_t(b) * 64 + lane] = 0u;
     }
+}
+
+__global__ void k_reset_counters(uint32_t* brick_count, FrameHeader* h, uint32_t clear_overflow) {
+    *brick_count = 0u;
+    if (clear_overflow) h->overflow = 0u;
 }
 
 // Rebuild the hash of a grown map: brick b (key already copied) takes a slot of the new, larger table.

@@ -82,7 +82,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 template <bool kStamps>
 __global__ void __launch_bounds__(kTileThreads)
 k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normals, const uint64_t* __restrict__ codes,
-               const uint32_t* __restrict__ item_start, FrameHeader* __restrict__ h,
+               const uint2* __restrict__ items, FrameHeader* __restrict__ h,
                F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t ablate, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
     if (adaptive && frame_is_sparse(h)) return;
@@ -92,7 +92,7 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
     unsigned long long* tile = reinterpret_cast<unsigned long long*>(tile_raw) + size_t(wave_in_group) * cells;
     const float to_fixed = 1073741824.0f / trunc, from_fixed = trunc / 1073741824.0f;  // 2^30 / trunc
     for (uint32_t k = lane; k < cells; k += 64) tile[k] = 0ull;
-    const uint32_t n = h->n_usable, nitems = h->n_items;
+    const uint32_t nitems = h->n_items;
     unsigned long long applied = 0;
     // lane = voxel v of a brick: its offset inside the brick (Morton order of the low 6 code bits)
     const int vx = int((lane & 1u) | ((lane >> 2) & 2u)), vy = int(((lane >> 1) & 1u) | ((lane >> 3) & 2u)), vz = int(((lane >> 2) & 1u) | ((lane >> 4) & 2u));
@@ -117,11 +117,9 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
         if (item >= nitems) break;
         turn = take_ticket();  // the next item's ticket is fetched while this one is processed
         if (kStamps) items_done++;
-        const uint32_t first = item_start[item];
+        const uint2 record = items[item];  // (first point, number of points <= kItemPoints), from k_frame_gather
+        const uint32_t first = record.x, len = record.y;
         const uint64_t block = codes[first] >> 6;
-        // the item ends at the next point block, at the next multiple of kItemPoints, or at the frame's end
-        const uint32_t limit = min(n, (first / kItemPoints + 1u) * kItemPoints);
-        const uint32_t len = run_length(codes, first, limit, block, lane);
         const I3 corner = morton_decode(block << 6);                          // lowest voxel of the point block
         const int ox = corner.x - R, oy = corner.y - R, oz = corner.z - R;    // tile origin
         if (kStamps) { const unsigned long long t1 = stamp_now(); ph[0] += t1 - t0; t0 = t1; }
@@ -230,7 +228,7 @@ inline uint32_t tile_reach(float res, float trunc) {
     return r < 1.0f ? 1u : (r > float(kMaxReach) ? kMaxReach : uint32_t(r));
 }
 
-inline void tile_update_enqueue(const float4* pts, const float4* normals, const uint64_t* codes, const uint32_t* item_start,
+inline void tile_update_enqueue(const float4* pts, const float4* normals, const uint64_t* codes, const uint2* items,
                                 FrameHeader* h, F3 pos, float res, float recip, float trunc, const MapView& m, hipStream_t stream, bool adaptive, uint32_t ablate = 0,
                                 unsigned long long* stamps = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
@@ -239,9 +237,9 @@ inline void tile_update_enqueue(const float4* pts, const float4* normals, const 
     uint32_t per_cu = uint32_t(std::min<size_t>(6, (160 * 1024) / (lds + 64)));  // persistent workgroups (of 4 waves) per CU
     if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::atoi(e));
     if (stamps)
-        hipLaunchKernelGGL(k_update_tiled<true>, dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, codes, item_start, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, ablate, stamps);
+        hipLaunchKernelGGL(k_update_tiled<true>, dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, codes, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, ablate, stamps);
     else
-        hipLaunchKernelGGL(k_update_tiled<false>, dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, codes, item_start, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, ablate, stamps);
+        hipLaunchKernelGGL(k_update_tiled<false>, dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, codes, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, ablate, stamps);
 }
 
 }  // namespace chadhip
