@@ -4,4 +4,4 @@ The package holds the HIP kernels + C ABI (csrc/, built into lib/libchad_hip.so)
 reference's TSDFMap class (tsdf.py), the frame-sharded multi-GPU map (sharded.py) and the synthetic scan
 generators of the BASELINE configurations (synth.py).
 """
-from .tsdf import TSDFMap, morton_codes, walk_rays  # noqa: F401
+from .tsdf import TSDFMap, morton_codes, sort_pairs, walk_rays  # noqa: F401

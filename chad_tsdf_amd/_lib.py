@@ -75,6 +75,7 @@ SYMBOLS = {
     "chad_map_last_frame": (_i32, [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_walk_rays": (_i32, [_vp, _sz, _vp, _f32, _f32, _vp, _vp, _sz]),
     "chad_morton_codes": (_i32, [_vp, _sz, _f32, _vp]),
+    "chad_sort_pairs": (_i32, [_vp, _sz, C.c_uint32, _vp, _vp]),
     "chad_last_error": (C.c_char_p, []),
     "chad_version": (C.c_char_p, []),
 }

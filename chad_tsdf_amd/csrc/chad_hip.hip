@@ -669,6 +669,41 @@ chad_status chad_walk_rays(const float* xyz, size_t n, const float position[3], 
     return CHAD_OK;
 }
 
+chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, uint64_t* keys_out, uint32_t* order_out) {
+    if (n && !keys) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (n >= (1ull << 30) || key_bits > 64) return fail(CHAD_ERR_INVALID_ARG, "n or key_bits out of range");
+    if (!n) return CHAD_OK;
+    RadixSortBuffers b{};
+    const uint32_t tiles = radix_tiles(n);
+    const size_t cap = size_t(tiles) * kSortTile;
+    for (int i = 0; i < 2; i++) { HIP_TRY(hipMalloc(&b.keys[i], cap * 8)); HIP_TRY(hipMalloc(&b.idx[i], cap * 4)); }
+    HIP_TRY(hipMalloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(hipMalloc(&b.digit_base, size_t(kMaxPasses) * kRadix * 4));
+    HIP_TRY(hipMalloc(&b.tile_status, radix_status_words(tiles) * 4));
+    HIP_TRY(hipMemcpy(b.keys[0], keys, n * 8, hipMemcpyHostToDevice));
+    const uint32_t passes = std::max(1u, (key_bits + kRadixBits - 1) / kRadixBits);
+    int reps = 1;
+    if (const char* r = std::getenv("CHAD_DEBUG_SORT_REPS")) reps = std::max(1, std::atoi(r));  // timing experiments
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    for (int r = 0; r < reps; r++) {
+        if (r == reps - 1) HIP_TRY(hipEventRecord(e0, nullptr));
+        if (r) HIP_TRY(hipMemcpyAsync(b.keys[0], keys, n * 8, hipMemcpyHostToDevice, nullptr));
+        radix_sort_enqueue(b, uint32_t(n), passes, nullptr, nullptr);
+        if (r == reps - 1) HIP_TRY(hipEventRecord(e1, nullptr));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (reps > 1) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); std::fprintf(stderr, "chad_sort_pairs: n %zu passes %u: %.3f ms (incl. one H2D of the keys)\n", n, passes, ms); }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const int out = passes & 1;
+    if (keys_out) HIP_TRY(hipMemcpy(keys_out, b.keys[out], n * 8, hipMemcpyDeviceToHost));
+    if (order_out) HIP_TRY(hipMemcpy(order_out, b.idx[out], n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 2; i++) { (void)hipFree(b.keys[i]); (void)hipFree(b.idx[i]); }
+    (void)hipFree(b.hist_part); (void)hipFree(b.digit_base); (void)hipFree(b.tile_status);
+    return CHAD_OK;
+}
+
 chad_status chad_morton_codes(const float* xyz, size_t n, float sdf_res, uint64_t* mc) {
     if (n && (!xyz || !mc)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     if (!n) return CHAD_OK;

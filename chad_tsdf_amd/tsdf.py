@@ -163,6 +163,16 @@ def walk_rays(points, position, sdf_res: float, sdf_trunc: float, stride: int = 
     return vox, cnt
 
 
+def sort_pairs(keys, key_bits: int = 64):
+    """Stable ascending radix sort of u64 keys on the device: (sorted keys, input positions)."""
+    lib = _lib.load()
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    out = np.empty_like(k)
+    order = np.empty(k.shape[0], dtype=np.uint32)
+    _lib.check(lib.chad_sort_pairs(k.ctypes.data, k.shape[0], key_bits, out.ctypes.data, order.ctypes.data), "sort_pairs")
+    return out, order
+
+
 def decode_morton(mc: np.ndarray) -> np.ndarray:
     """MortonCode::decode (morton.hpp:29-37) for an array of codes -> int32 [n,3] (host helper for save())."""
     def compact(v):

@@ -124,6 +124,11 @@ chad_status chad_walk_rays(const float* xyz, size_t n, const float position[3], 
 /* Stage entry for parity tests: MortonCode::encode of calc_morton_vector (morton.hpp:59-80) for n host points. */
 chad_status chad_morton_codes(const float* xyz, size_t n, float sdf_res, uint64_t* mc);
 
+/* Stage entry for parity tests: the stable ascending radix sort that replaces std::sort in sort_morton_vector
+ * (morton.hpp:81-102).  Sorts n host keys by their low key_bits bits; keys_out[i] is the i-th smallest key and
+ * order_out[i] its position in the input (equal keys keep input order).  Either output may be NULL. */
+chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, uint64_t* keys_out, uint32_t* order_out);
+
 /* Thread-local message of the last failure on this thread ("" if none). */
 const char* chad_last_error(void);
 /* Library/build identification, e.g. "chad_hip 0.1 gfx950". */

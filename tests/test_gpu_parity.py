@@ -39,6 +39,23 @@ def test_morton_codes_bit_exact(chad, oracle):
         assert np.array_equal(chad.morton_codes(pts, res), oracle.morton_codes(pts, res))
 
 
+# ---- a5: the sort ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,bits", [(1, 8), (63, 16), (2048, 24), (2049, 40), (100_003, 64), (1_000_000, 22), (3_000_000, 33)])
+def test_radix_sort_is_a_stable_sort(chad, n, bits):
+    """Replaces std::sort of morton.hpp:85-89 (stable here, so equal codes keep input order: deviation D3).
+    3 M keys exceed the resident-grid limit and exercise the ticketed tile assignment."""
+    rng = np.random.default_rng(n)
+    mask = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    keys &= mask
+    if n > 1000:
+        keys[rng.integers(0, n, size=n // 3)] = keys[rng.integers(0, n, size=n // 3)]  # plenty of duplicates
+    out, order = chad.sort_pairs(keys, bits)
+    want = np.argsort(keys, kind="stable")
+    assert np.array_equal(order, want.astype(np.uint32))
+    assert np.array_equal(out, keys[want])
+
+
 # ---- a8: voxel traversal ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("res,trunc", [(0.05, 0.10), (0.02, 0.06), (0.10, 0.20), (0.05, 0.5), (0.07, 0.01)])
 def test_ray_walk_voxel_lists_bit_exact(chad, oracle, res, trunc):
