@@ -90,6 +90,8 @@ struct chad_map {
 
     std::vector<std::array<float, 3>> positions;  // poses of the active submap (submap.hpp:110)
     std::vector<Submap> closed;                   // tsdf.cpp:54
+    Submap active_copy;                           // dense snapshot of the active submap made for the last export call
+    uint32_t* d_cursor = nullptr;                 // output cursor of k_compact_bricks
     uint64_t frames = 0, last_points_in = 0;
     // stage timing (CHAD_FLAG_TIMING): a ring of event sets, one per insert, read back lazily by chad_map_stats so
     // that timing adds no synchronisation to insert()
@@ -148,13 +150,13 @@ chad_status ensure_frame_capacity(chad_map* m, size_t n) {
     HIP_TRY(hipMalloc(&m->d_pts, cap * 16));
     HIP_TRY(hipMalloc(&m->d_codes, cap * 8));
     HIP_TRY(hipMalloc(&m->d_normals, cap * 16));
-    HIP_TRY(hipMalloc(&m->d_seg, cap * 24));  // point-block starts [cap], lengths [cap], update work items (start, length) [2*cap]
+    HIP_TRY(hipMalloc(&m->d_seg, cap * 24));  // point-block starts u32 [cap], lengths u32 [cap], update work items uint4 [cap] (start, length, block key)
     m->cap_points = cap;
     return CHAD_OK;
 }
 
 void free_map_storage(MapView& v) {
-    (void)hipFree(v.hash_keys); (void)hipFree(v.hash_vals); (void)hipFree(v.brick_key); (void)hipFree(v.brick_slot);
+    (void)hipFree(v.hash_keys); (void)hipFree(v.live_bits);
     (void)hipFree(v.brick_sum); (void)hipFree(v.brick_cnt); (void)hipFree(v.brick_count);
     v = MapView{};
 }
@@ -165,36 +167,35 @@ chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream) {
     while (hcap < blocks * 2) hcap <<= 1;  // load factor <= 0.5
     v = MapView{};
     HIP_TRY(hipMalloc(&v.hash_keys, hcap * 8));
-    HIP_TRY(hipMalloc(&v.hash_vals, hcap * 4));
-    HIP_TRY(hipMalloc(&v.brick_key, blocks * 8));
-    HIP_TRY(hipMalloc(&v.brick_slot, blocks * 4));
-    HIP_TRY(hipMalloc(&v.brick_sum, blocks * 256));
-    HIP_TRY(hipMalloc(&v.brick_cnt, blocks * 256));
-    HIP_TRY(hipMalloc(&v.brick_count, 4));
+    HIP_TRY(hipMalloc(&v.live_bits, hcap / 8));
+    HIP_TRY(hipMalloc(&v.brick_sum, hcap * 256));   // a brick lives at its hash slot (map_kernels.hpp)
+    HIP_TRY(hipMalloc(&v.brick_cnt, hcap * 256));
+    HIP_TRY(hipMalloc(&v.brick_count, kCountStripes * 64));
     v.hash_mask = uint32_t(hcap - 1);
     v.brick_capacity = uint32_t(blocks);
     hipLaunchKernelGGL(k_fill_u64, grid_for(hcap), dim3(256), 0, stream, v.hash_keys, size_t(hcap), kEmptyKey);
-    hipLaunchKernelGGL(k_fill_u32, grid_for(hcap), dim3(256), 0, stream, v.hash_vals, size_t(hcap), kPending);
-    HIP_TRY(hipMemsetAsync(v.brick_sum, 0, blocks * 256, stream));
-    HIP_TRY(hipMemsetAsync(v.brick_cnt, 0, blocks * 256, stream));
-    HIP_TRY(hipMemsetAsync(v.brick_count, 0, 4, stream));
+    HIP_TRY(hipMemsetAsync(v.live_bits, 0, hcap / 8, stream));
+    HIP_TRY(hipMemsetAsync(v.brick_sum, 0, hcap * 256, stream));
+    HIP_TRY(hipMemsetAsync(v.brick_cnt, 0, hcap * 256, stream));
+    HIP_TRY(hipMemsetAsync(v.brick_count, 0, kCountStripes * 64, stream));
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
 }
 
 // Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  Fully asynchronous.
 chad_status clear_active(chad_map* m, bool clear_overflow = false) {
-    hipLaunchKernelGGL(k_clear_bricks, dim3(1024), dim3(256), 0, m->stream, m->view);
-    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, m->stream, m->view.brick_count, m->d_hdr, clear_overflow ? 1u : 0u);
+    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_hdr, clear_overflow ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
 }
 
 chad_status read_block_count(chad_map* m, uint32_t* blocks) {
-    uint32_t v = 0;
-    HIP_TRY(hipMemcpyAsync(&v, m->view.brick_count, 4, hipMemcpyDeviceToHost, m->stream));
+    uint32_t stripes[kCountStripes * 16];
+    HIP_TRY(hipMemcpyAsync(stripes, m->view.brick_count, sizeof(stripes), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    *blocks = std::min(v, m->brick_capacity);
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < kCountStripes; k++) v += stripes[k * 16];
+    *blocks = v;
     return CHAD_OK;
 }
 
@@ -212,23 +213,33 @@ chad_status alloc_submap(Submap& s, uint32_t blocks) {
     return CHAD_OK;
 }
 
+// Dense copy of the active submap's bricks (they live scattered over the hash slots), in no particular order.
+chad_status compact_active(chad_map* m, Submap& s, uint32_t blocks) {
+    TRY(alloc_submap(s, blocks));
+    if (!blocks) return CHAD_OK;
+    HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
+    hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, blocks, s.keys, s.sum, s.cnt);
+    HIP_TRY(hipGetLastError());
+    return CHAD_OK;
+}
+
 // Submap roll-over (tsdf.cpp:52-57): archive the active submap's bricks and start an empty one.
 chad_status close_active(chad_map* m) {
     uint32_t blocks = 0;
     TRY(read_block_count(m, &blocks));
     Submap s;
-    TRY(alloc_submap(s, blocks));
-    if (blocks)
-        hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(blocks) * 64), dim3(256), 0, m->stream, (const uint32_t*)nullptr, blocks, m->view.brick_key,
-                           m->view.brick_sum, m->view.brick_cnt, s.keys, s.sum, s.cnt);
+    TRY(compact_active(m, s, blocks));
     m->closed.push_back(s);
     return clear_active(m);
 }
 
 chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const uint64_t** keys, const float** sum, const uint32_t** cnt) {
-    if (submap < 0) {
+    if (submap < 0) {  // the active submap: a dense snapshot, kept until the next call
         TRY(read_block_count(m, blocks));
-        *keys = m->view.brick_key; *sum = m->view.brick_sum; *cnt = m->view.brick_cnt;
+        free_submap(m->active_copy);
+        TRY(compact_active(m, m->active_copy, *blocks));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        *keys = m->active_copy.keys; *sum = m->active_copy.sum; *cnt = m->active_copy.cnt;
         return CHAD_OK;
     }
     if (size_t(submap) >= m->closed.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
@@ -264,8 +275,7 @@ inline bool times_anything(const chad_map* m) { return (m->flags & (CHAD_FLAG_TI
 // Every hipEventRecord costs ~6 us of stream idle time, so CHAD_FLAG_TIME_UPDATE brackets only the update kernel.
 // The reference's storage is effectively unbounded (VirtualArray reserves 4 GiB of address space per octree,
 // virtual_array.hpp:16-19).  Here the pools double when the live block count -- mirrored by the device into host-mapped
-// memory once per frame -- passes half the capacity: new pools, device-to-device copy of the bricks, re-insertion of
-// the keys into a new hash.  Happens between frames; a single frame that outruns the remaining half still reports
+// memory once per frame -- passes half the capacity: a new table twice the size, every brick re-inserted and moved.  Happens between frames; a single frame that outruns the remaining half still reports
 // CHAD_ERR_CAPACITY.
 chad_status grow_if_needed(chad_map* m) {
     if (m->fixed_capacity || *m->h_live_blocks < m->brick_capacity / 2 || m->brick_capacity >= (1u << 30)) return CHAD_OK;
@@ -276,11 +286,8 @@ chad_status grow_if_needed(chad_map* m) {
     const uint64_t blocks = std::min<uint64_t>(uint64_t(m->brick_capacity) * 2, 1ull << 30);
     const chad_status s = alloc_map_storage(bigger, blocks, m->stream);
     if (s != CHAD_OK) { free_map_storage(bigger); m->fixed_capacity = true; g_error.clear(); return CHAD_OK; }  // keep going at the old size
-    HIP_TRY(hipMemcpyAsync(bigger.brick_key, m->view.brick_key, size_t(live) * 8, hipMemcpyDeviceToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(bigger.brick_sum, m->view.brick_sum, size_t(live) * 256, hipMemcpyDeviceToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(bigger.brick_cnt, m->view.brick_cnt, size_t(live) * 256, hipMemcpyDeviceToDevice, m->stream));
-    if (live) hipLaunchKernelGGL(k_rehash_bricks, grid_for(live), dim3(256), 0, m->stream, bigger, live, m->d_hdr);
-    HIP_TRY(hipMemcpyAsync(bigger.brick_count, &live, 4, hipMemcpyHostToDevice, m->stream));
+    if (live) hipLaunchKernelGGL(k_rehash_bricks, dim3(512), dim3(256), 0, m->stream, m->view, bigger, m->d_hdr);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     free_map_storage(m->view);
     m->view = bigger;
@@ -339,7 +346,7 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
     record(m, T_BEGIN);
     if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, m->stream, m->d_hdr);
     if (count) {
-        uint2* item_start = reinterpret_cast<uint2*>(m->d_seg + 2 * m->cap_points);
+        uint4* item_start = reinterpret_cast<uint4*>(m->d_seg + 2 * m->cap_points);
         hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_part);
         hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0],
                            m->sort.hist_part, m->sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
@@ -360,7 +367,7 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
         // once for a dense frame) stays outside the bracket
         if (!times_stages(m) && m->update_mode != CHAD_UPDATE_SCATTER) record(m, T_NORM);
         if (m->update_mode != CHAD_UPDATE_SCATTER)
-            tile_update_enqueue(m->d_pts, m->d_normals, m->d_codes, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->ablate, m->d_stamps);
+            tile_update_enqueue(m->d_pts, m->d_normals, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->d_stamps);
         record(m, T_UPD);
     } else {
         record(m, T_CALC); record(m, T_SORT); record(m, T_NORM); record(m, T_UPD);
@@ -433,6 +440,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     *m->h_live_blocks = 0;
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
     CREATE_TRY(hipMalloc(&m->d_part, sizeof(FramePartial) * kFrameBlocks));
+    CREATE_TRY(hipMalloc(&m->d_cursor, 4));
     CREATE_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
     if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
@@ -458,13 +466,18 @@ void chad_map_destroy(chad_map* m) {
             std::fprintf(stderr, "stamps: waves %zu  life p10 %llu p50 %llu p90 %llu max %llu | start p50 +%llu p90 +%llu max +%llu | items p10 %llu p50 %llu p90 %llu max %llu\n", life.size(),
                          pct(life, 0.1), pct(life, 0.5), pct(life, 0.9), pct(life, 1.0), pct(start, 0.5) - s0, pct(start, 0.9) - s0, pct(start, 1.0) - s0,
                          pct(items, 0.1), pct(items, 0.5), pct(items, 0.9), pct(items, 1.0));
+            double sum[8] = {};
+            for (int w = 0; w < 8192; w++) if (st[w * 8 + 5]) for (int k = 0; k < 8; k++) sum[k] += double(st[w * 8 + k]);
+            std::fprintf(stderr, "stamps: mean cycles per wave: fetch %.0f walk %.0f readback %.0f hash %.0f flush %.0f life %.0f\n", sum[0] / life.size(), sum[3] / life.size(),
+                         sum[6] / life.size(), sum[7] / life.size(), sum[4] / life.size(), sum[5] / life.size());
         }
         (void)hipFree(m->d_stamps);
     }
     free_frame_buffers(m);
     for (auto& s : m->closed) free_submap(s);
+    free_submap(m->active_copy);
     free_map_storage(m->view);
-    (void)hipFree(m->d_hdr); (void)hipFree(m->d_part);
+    (void)hipFree(m->d_hdr); (void)hipFree(m->d_part); (void)hipFree(m->d_cursor);
     if (m->h_live_blocks) (void)hipHostFree(const_cast<uint32_t*>(m->h_live_blocks));
     if (m->h_hdr) (void)hipHostFree(m->h_hdr);
     for (auto& set : m->ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
@@ -585,8 +598,11 @@ chad_status chad_map_block_count(chad_map* m, int32_t submap, size_t* blocks) {
     if (!m || !blocks) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
     uint32_t nb = 0;
-    const uint64_t* k; const float* s; const uint32_t* c;
-    TRY(select_submap(m, submap, &nb, &k, &s, &c));
+    if (submap < 0) TRY(read_block_count(m, &nb));
+    else {
+        if (size_t(submap) >= m->closed.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
+        nb = m->closed[size_t(submap)].blocks;
+    }
     *blocks = nb;
     return CHAD_OK;
 }

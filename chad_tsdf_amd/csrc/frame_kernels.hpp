@@ -192,7 +192,11 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
              uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words,
              const uint32_t* __restrict__ live_blocks, uint32_t* __restrict__ live_blocks_host) {
     if (blockIdx.x == 0) frame_header_reset(h);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *live_blocks_host = *live_blocks;  // host-mapped: capacity growth hint
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // host-mapped: capacity growth hint (the counter is striped over 32 lines)
+        uint32_t live = 0;
+        for (uint32_t k = 0; k < 32; k++) live += live_blocks[k * 16];
+        *live_blocks_host = live;
+    }
     // clear the radix sort's look-back table for this frame (saves a memset launch)
     for (size_t k = size_t(blockIdx.x) * blockDim.x + threadIdx.x; k < status_words; k += size_t(gridDim.x) * blockDim.x) tile_status[k] = 0u;
     const LocalFrame f = combine_bounds(part);
@@ -238,7 +242,7 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
 
 // Stage 3 (after the sort): gather the points into processing order as float4 (x, y, z, input index), recompute
 // their global codes, and list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
-// normal estimation and (b) the update work items (start, length) in items[]: the point blocks cut again at
+// normal estimation and (b) the update work items (start, length, block key) in items[]: the point blocks cut again at
 // every kItemPoints-th point, so that no item is longer than kItemPoints.  A workgroup collects its entries in
 // LDS (block heads as a list, item starts as a 2048-bit mask whose next set bit gives an item's length) and
 // reserves output space with ONE atomic per list and chunk; the lists are in no particular order.
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(256)
 k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const uint32_t* __restrict__ idx0, const uint32_t* __restrict__ idx1,
-               float4* __restrict__ pts, uint64_t* __restrict__ codes, uint32_t* __restrict__ seg_start, uint2* __restrict__ items) {
+               float4* __restrict__ pts, uint64_t* codes, uint32_t* __restrict__ seg_start, uint4* __restrict__ items) {
     __shared__ uint32_t heads[kGatherChunk];
     __shared__ uint32_t mark_bits[kGatherChunk / 32];  // bit k: point k of the chunk starts a work item
     __shared__ uint32_t word_rank[kGatherChunk / 32], word_next[kGatherChunk / 32];
@@ -315,7 +319,8 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
                 const uint32_t rank = word_rank[k >> 5] + __popc(word & ((1u << bit) - 1u));
                 const uint32_t higher = bit == 31u ? 0u : word >> (bit + 1u);
                 const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[k >> 5];
-                items[base_marks + rank] = make_uint2(c * kGatherChunk + k, min(next, chunk_len) - k);
+                const uint64_t block_key = codes[c * kGatherChunk + k] & kBlockMask;  // written by this very thread above
+                items[base_marks + rank] = make_uint4(c * kGatherChunk + k, min(next, chunk_len) - k, uint32_t(block_key), uint32_t(block_key >> 32));
             }
         }
         __syncthreads();

@@ -3,13 +3,20 @@
 // Replaces Octree::insert(MortonCode) + _node_lookup (octree.hpp:31-78,187) and the weighted update of
 // octree.hpp:153-164.
 //
-// Layout in HBM (structure of arrays, one "brick" per 4x4x4-voxel block, voxel index = low 6 code bits):
-//   hash_keys[H]  u64   open-addressed table of block keys (code & ~63); EMPTY = ~0; linear probing, so a probe
-//                       sequence walks consecutive 8-byte keys of one 128-byte line before touching the next
-//   hash_vals[H]  u32   brick index of the key in the same slot (PENDING until the claiming lane has allocated)
-//   brick_key[B]  u64   key of brick b (for export); brick_slot[B] u32 its hash slot (for O(bricks) clearing)
-//   brick_sum[B*64] f32 sum of the clamped signed distances observed by each voxel
-//   brick_cnt[B*64] u32 number of observations (the reference's Leaf::_weight)
+// Layout in HBM (structure of arrays, one "brick" per 4x4x4-voxel block, voxel index = low 6 code bits).  A brick
+// lives AT its hash slot -- there is no separate brick pool -- so that finding or creating a block is ONE
+// compare-and-swap on its key (one memory round trip; the first version needed four dependent ones: key load,
+// CAS, pool counter, index publish/wait -- 17 us of the update kernel):
+//   hash_keys[H]     u64  open-addressed table of block keys (code & ~63); EMPTY = ~0; linear probing, so a probe
+//                         sequence walks consecutive 8-byte keys of one 128-byte line before touching the next
+//   brick_sum[H*64]  f32  sum of the clamped signed distances observed by each voxel of the brick in slot s
+//   brick_cnt[H*64]  u32  number of observations (the reference's Leaf::_weight)
+//   live_bits[H/32]  u32  bit s set: slot s holds a brick (set fire-and-forget by the claiming lane); clearing,
+//                         export and growth walk this bitmap -- O(H/32 + bricks), not O(table)
+//   brick_count[32*16] u32  number of bricks, striped over 32 cache lines (no same-address atomics)
+// H = 2 * capacity rounded up to a power of two, i.e. the table -- and with it the brick storage, 512 B per slot --
+// is at most half full at the nominal capacity; 288 GB of HBM make that trade (2 x 520 B per block) a cheap one.
+// Slots that hold no brick keep all-zero rows (zeroed at allocation and again whenever a brick is released).
 // The reference keeps a running mean sd and a count w per leaf, with unit weight per observation
 // (octree.hpp:161-163); (sum, cnt) is the same information with sd = sum / cnt, and it is what makes the update a
 // commutative reduction: LDS partial sums, atomics across workgroups and an all-reduce across GPUs all combine
@@ -21,63 +28,49 @@
 namespace chadhip {
 
 constexpr uint64_t kEmptyKey = ~0ull;
-constexpr uint32_t kPending = 0xffffffffu;   // slot claimed, brick index not yet published
-constexpr uint32_t kNoBrick = 0xfffffffeu;   // pool exhausted: updates to this block are dropped (overflow flag set)
+constexpr uint32_t kNoBrick = 0xfffffffeu;   // table too full: updates to this block are dropped (overflow flag set)
+constexpr uint32_t kMaxProbes = 256;         // at load <= 0.5 probe sequences are a handful of slots long
+constexpr uint32_t kCountStripes = 32;       // brick_count[k * 16], k < kCountStripes
 
 struct MapView {
     uint64_t* hash_keys;
-    uint32_t* hash_vals;
-    uint32_t hash_mask;      // H - 1 (H a power of two)
-    uint64_t* brick_key;
-    uint32_t* brick_slot;    // hash slot of brick b, so that clearing the map costs O(bricks), not O(table)
     float* brick_sum;
     uint32_t* brick_cnt;
-    uint32_t* brick_count;   // device counter of allocated bricks
-    uint32_t brick_capacity;
+    uint32_t* live_bits;
+    uint32_t* brick_count;   // striped device counter of live bricks
+    uint32_t hash_mask;      // H - 1 (H a power of two)
+    uint32_t brick_capacity; // nominal capacity (H / 2 or less): the pools grow once half of it is in use
 };
 
 __device__ __forceinline__ uint32_t hash_block(uint64_t key, uint32_t mask) {
     return uint32_t(((key >> 6) * 0x9E3779B97F4A7C15ull) >> 32) & mask;
 }
 
-// Brick index of `key`, creating the brick if needed.  Safe to call from divergent lanes: the claiming lane
-// publishes its brick index before any lane of its wave reaches the wait loop, and lanes of other waves are
-// never waited on while masked.  Returns kNoBrick when the table or pool is full.
-__device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint64_t key, FrameHeader* h) {
-    uint32_t slot = hash_block(key, m.hash_mask);
-    bool claimed = false, found = false;
-    for (uint32_t probes = 0; probes <= m.hash_mask; probes++) {
-        const uint64_t seen = __hip_atomic_load(&m.hash_keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen == key) { found = true; break; }
-        if (seen == kEmptyKey) {
-            const uint64_t prev = atomicCAS((unsigned long long*)&m.hash_keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-            if (prev == kEmptyKey) { claimed = true; found = true; break; }
-            if (prev == key) { found = true; break; }
+__device__ __forceinline__ uint32_t live_brick_count(const MapView& m) {
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < kCountStripes; k++) n += m.brick_count[k * 16];
+    return n;
+}
+
+// Slot (= brick index) of `key`, claiming an empty slot if the block is new.  One CAS per probe; a claim also sets
+// the slot's live bit and bumps a counter stripe, both without waiting for a result.  Returns kNoBrick when no
+// slot is found within kMaxProbes.
+__device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint64_t key, FrameHeader* h, uint32_t slot) {
+    for (uint32_t probes = 0; probes < kMaxProbes; probes++) {
+        const uint64_t prev = atomicCAS((unsigned long long*)&m.hash_keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (prev == key) return slot;
+        if (prev == kEmptyKey) {
+            atomicOr(&m.live_bits[slot >> 5], 1u << (slot & 31u));
+            atomicAdd(&m.brick_count[(slot & (kCountStripes - 1)) * 16], 1u);
+            return slot;
         }
         slot = (slot + 1) & m.hash_mask;
     }
-    if (!found) { atomicOr(&h->overflow, 1u); return kNoBrick; }
-    if (claimed) {
-        uint32_t b = atomicAdd(m.brick_count, 1u);
-        if (b >= m.brick_capacity) { atomicOr(&h->overflow, 1u); b = kNoBrick; }
-        else { m.brick_key[b] = key; m.brick_slot[b] = slot; }
-        __hip_atomic_store(&m.hash_vals[slot], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    uint32_t b;
-    do { b = __hip_atomic_load(&m.hash_vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (b == kPending);
-    return b;
-}
-
-// Lookup only (no creation); kNoBrick if absent.
-__device__ __forceinline__ uint32_t find_brick(const MapView& m, uint64_t key) {
-    uint32_t slot = hash_block(key, m.hash_mask);
-    for (uint32_t probes = 0; probes <= m.hash_mask; probes++) {
-        const uint64_t seen = m.hash_keys[slot];
-        if (seen == key) return m.hash_vals[slot];
-        if (seen == kEmptyKey) return kNoBrick;
-        slot = (slot + 1) & m.hash_mask;
-    }
+    atomicOr(&h->overflow, 1u);
     return kNoBrick;
+}
+__device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint64_t key, FrameHeader* h) {
+    return find_or_create_brick(m, key, h, hash_block(key, m.hash_mask));
 }
 
 // ---- update, general form: one lane per point, global atomics per observation (octree.hpp:86-164) -----------
@@ -140,9 +133,6 @@ __global__ void k_morton_codes(const float* __restrict__ xyz, uint32_t n, float 
 __global__ void k_fill_u64(uint64_t* p, size_t n, uint64_t v) {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) p[i] = v;
 }
-__global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t v) {
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) p[i] = v;
-}
 
 // Copy bricks in the order given by `order` (brick indices) into dense output arrays: one wave per brick,
 // 256-byte rows, fully coalesced.
@@ -161,66 +151,92 @@ k_gather_bricks(const uint32_t* __restrict__ order, uint32_t count, const uint64
     }
 }
 
-// Insert externally produced blocks (a merged submap) into an empty map: one wave per block.
-__global__ void __launch_bounds__(256)
-k_import_bricks(const uint64_t* __restrict__ keys, const float* __restrict__ sum, const uint32_t* __restrict__ cnt, uint32_t count,
-                FrameHeader* __restrict__ h, MapView m) {
+// Walk the live bitmap: every wave takes 64 words at a time (lane = word) and calls visit(slot) -- wave-uniformly,
+// all 64 lanes active -- for each set bit.
+template <class Visit>
+__device__ __forceinline__ void for_each_live_brick(const MapView& m, Visit visit) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t k = wave; k < count; k += waves) {
-        uint32_t b = 0;
-        if (lane == 0) b = find_or_create_brick(m, keys[k], h);
-        b = __shfl(b, 0);
-        if (b == kNoBrick) continue;
-        atomicAdd(&m.brick_sum[size_t(b) * 64 + lane], sum[size_t(k) * 64 + lane]);
-        atomicAdd(&m.brick_cnt[size_t(b) * 64 + lane], cnt[size_t(k) * 64 + lane]);
-    }
-}
-
-// Octree::clear() (octree.hpp:22-29) in O(bricks) and without a host round trip: the number of live bricks is read
-// from device memory; one wave per brick releases its hash slot and zeroes its two 256-byte rows.
-// (The counter itself is reset by k_reset_counters enqueued behind this kernel.)
-__global__ void __launch_bounds__(256)
-k_clear_bricks(MapView m) {
-    const uint32_t blocks = min(*m.brick_count, m.brick_capacity);
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t b = wave; b < blocks; b += waves) {
-        if (lane == 0) {
-            const uint32_t slot = m.brick_slot[b];
-            m.hash_keys[slot] = kEmptyKey;
-            m.hash_vals[slot] = kPending;
+    const uint32_t words = (m.hash_mask >> 5) + 1u;
+    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u) {
+        const uint32_t word = w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
+        for (uint64_t holders = __ballot(word != 0u); holders; holders &= holders - 1ull) {
+            const uint32_t l = uint32_t(__ffsll((unsigned long long)holders)) - 1u;
+            for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u)
+                visit((w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u);
         }
-        m.brick_sum[size_t(b) * 64 + lane] = 0.0f;
-        m.brick_cnt[size_t(b) * 64 + lane] = 0u;
     }
 }
 
-__global__ void k_reset_counters(uint32_t* brick_count, FrameHeader* h, uint32_t clear_overflow) {
-    *brick_count = 0u;
-    if (clear_overflow) h->overflow = 0u;
-}
-
-// Rebuild the hash of a grown map: brick b (key already copied) takes a slot of the new, larger table.
-__global__ void k_rehash_bricks(MapView m, uint32_t blocks, FrameHeader* __restrict__ h) {
-    for (size_t b = size_t(blockIdx.x) * blockDim.x + threadIdx.x; b < blocks; b += size_t(gridDim.x) * blockDim.x) {
-        const uint64_t key = m.brick_key[b];
-        uint32_t slot = hash_block(key, m.hash_mask);
-        for (uint32_t probes = 0; probes <= m.hash_mask; probes++) {
-            if (atomicCAS((unsigned long long*)&m.hash_keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key) == kEmptyKey) {
-                m.hash_vals[slot] = uint32_t(b);
-                m.brick_slot[b] = slot;
-                break;
+// Dense copy of the live bricks, in no particular order (the export sorts by key afterwards).  A wave reserves
+// output rows for all bricks of its 64 bitmap words with ONE returning atomic (same-address atomics serialise at
+// ~25 ns each on gfx950: one per brick would cost more than the copy).
+__global__ void __launch_bounds__(256)
+k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, uint64_t* __restrict__ out_key, float* __restrict__ out_sum,
+                 uint32_t* __restrict__ out_cnt) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t words = (m.hash_mask >> 5) + 1u;
+    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u) {
+        const uint32_t word = w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
+        uint64_t holders = __ballot(word != 0u);
+        if (!holders) continue;
+        uint32_t total = uint32_t(__popc(word));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(cursor, total);
+        k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
+        for (; holders; holders &= holders - 1ull) {
+            const uint32_t l = uint32_t(__ffsll((unsigned long long)holders)) - 1u;
+            for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u, k++) {
+                if (k >= capacity) continue;
+                const uint32_t slot = (w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u;
+                out_sum[size_t(k) * 64 + lane] = m.brick_sum[size_t(slot) * 64 + lane];
+                out_cnt[size_t(k) * 64 + lane] = m.brick_cnt[size_t(slot) * 64 + lane];
+                if (lane == 0) out_key[k] = m.hash_keys[slot];
             }
-            slot = (slot + 1) & m.hash_mask;
         }
     }
-    (void)h;
 }
 
-// keys for sorting bricks by block key: key' = brick_key (ascending), payload = brick index (implicit)
+// Octree::clear() (octree.hpp:22-29) in O(H/32 + bricks) and without a host round trip: every live brick's key is
+// released and its two 256-byte rows are zeroed; then the bitmap words and the counter stripes.
+__global__ void __launch_bounds__(256)
+k_clear_bricks(MapView m, FrameHeader* h, uint32_t clear_overflow) {
+    const uint32_t lane = threadIdx.x & 63;
+    for_each_live_brick(m, [&](uint32_t slot) {
+        if (lane == 0) m.hash_keys[slot] = kEmptyKey;
+        m.brick_sum[size_t(slot) * 64 + lane] = 0.0f;
+        m.brick_cnt[size_t(slot) * 64 + lane] = 0u;
+    });
+    // each wave clears exactly the words it has just read
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t words = (m.hash_mask >> 5) + 1u;
+    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u)
+        if (w0 + lane < words && m.live_bits[w0 + lane]) m.live_bits[w0 + lane] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < kCountStripes) m.brick_count[threadIdx.x * 16] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clear_overflow) h->overflow = 0u;
+}
+
+// Move the bricks of a map into a larger, empty one (capacity growth between frames).
+__global__ void __launch_bounds__(256)
+k_rehash_bricks(MapView from, MapView to, FrameHeader* __restrict__ h) {
+    const uint32_t lane = threadIdx.x & 63;
+    for_each_live_brick(from, [&](uint32_t slot) {
+        uint32_t dst = 0;
+        if (lane == 0) dst = find_or_create_brick(to, from.hash_keys[slot], h);
+        dst = uint32_t(__builtin_amdgcn_readfirstlane(int(dst)));
+        if (dst == kNoBrick) return;
+        to.brick_sum[size_t(dst) * 64 + lane] = from.brick_sum[size_t(slot) * 64 + lane];
+        to.brick_cnt[size_t(dst) * 64 + lane] = from.brick_cnt[size_t(slot) * 64 + lane];
+    });
+}
+
+// keys for sorting bricks by block key: key' = brick key (ascending), payload = brick index (implicit)
 __global__ void k_copy_u64(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t n) {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) dst[i] = src[i];
 }
