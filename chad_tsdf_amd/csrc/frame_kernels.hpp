@@ -6,10 +6,13 @@
 // never crosses a change of code >> 6, and every block's first neighbourhood starts at the block's first
 // point), except one thing: the globally last point is never absorbed into a neighbourhood (normals.hpp:100).
 // So the device sorts by a SHORT key -- the position of the voxel's block inside the frame's bounding box (whose
-// corner is aligned to 4 voxels, so the block partition is that of the global code) followed by the voxel's low
+// corner is aligned to 8 voxels, so the block partition is that of the global code) followed by the voxel's low
 // 6 code bits -- and finds the reference's "last point" (smallest global code, largest input index among equals)
 // with a reduction.  A room-sized frame needs 3 radix passes instead of 8.
 // Inside a block the order is the reference's: descending voxel code, ties by ascending input index.
+// The ORDER OF THE BLOCKS is free, and is chosen for the update kernel: the block position is split into the
+// position of its 2x2x2-block "super block" (8x8x8 voxels, the unit the update kernel stages in LDS) and three bits
+// for the block inside it, so that the points of a super block are contiguous as well.
 #pragma once
 #include "device_math.hpp"
 #include "radix_sort.hpp"
@@ -18,7 +21,7 @@ namespace chadhip {
 
 constexpr int kFrameBlocks = 512;     // fixed grid of the bounds / keys / gather kernels (2 workgroups per CU)
 constexpr int kGatherChunk = 2048;    // points per gather step of one workgroup
-constexpr uint32_t kItemPoints = 256; // an update work item never holds more points than this
+constexpr uint32_t kItemPoints = 512; // an update work item never holds more points than this
 constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of this many counters (blockIdx % kWorkGroups)
 
 // Per-frame scalars living in device memory (one per map; rewritten every insert).
@@ -132,8 +135,8 @@ k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, F
 }
 
 struct LocalFrame {  // geometry of the frame-local sort key
-    int ox, oy, oz;          // block-aligned corner of the frame's voxel bounds
-    uint32_t wx, wy, wz;     // bits needed for the block index along each axis
+    int ox, oy, oz;          // super-block-aligned (8 voxels) corner of the frame's voxel bounds
+    uint32_t wx, wy, wz;     // bits needed for the super-block index along each axis
     uint32_t bits, kept;     // bits of a usable key; usable points
     int lo[3], hi[3];
 };
@@ -168,24 +171,25 @@ __device__ __forceinline__ LocalFrame combine_bounds(const FramePartial* __restr
             f.hi[a] = max(max(red[0][3 + a], red[1][3 + a]), max(red[2][3 + a], red[3][3 + a]));
         }
         f.kept = uint32_t(red[0][6]) + uint32_t(red[1][6]) + uint32_t(red[2][6]) + uint32_t(red[3][6]);
-        f.ox = f.lo[0] & ~3; f.oy = f.lo[1] & ~3; f.oz = f.lo[2] & ~3;  // align down to a block corner
-        // block index widths: blocks 0 .. (hi - o) >> 2 along each axis; at most 19 bits (beyond 2^21 voxels the
-        // reference's code aliases as well, morton.hpp:22)
-        auto width = [](int span_voxels) { const uint32_t last = uint32_t(span_voxels) >> 2; return last ? min(19u, 32u - uint32_t(__clz(last))) : 0u; };
+        f.ox = f.lo[0] & ~7; f.oy = f.lo[1] & ~7; f.oz = f.lo[2] & ~7;  // align down to a super-block corner
+        // super-block index widths: super blocks 0 .. (hi - o) >> 3 along each axis; at most 18 bits (beyond 2^21
+        // voxels the reference's code aliases as well, morton.hpp:22)
+        auto width = [](int span_voxels) { const uint32_t last = uint32_t(span_voxels) >> 3; return last ? min(18u, 32u - uint32_t(__clz(last))) : 0u; };
         f.wx = f.kept ? width(f.hi[0] - f.ox) : 0u; f.wy = f.kept ? width(f.hi[1] - f.oy) : 0u; f.wz = f.kept ? width(f.hi[2] - f.oz) : 0u;
-        f.bits = f.wx + f.wy + f.wz + 6u;
+        f.bits = f.wx + f.wy + f.wz + 3u + 6u;
         shared_frame = f;
     }
     __syncthreads();
     return shared_frame;
 }
 
-// Stage 2: sort keys.  key = [block index : wx + wy + wz bits][63 - voxel in block : 6 bits], the block index being
-// the block's x | y << wx | z << (wx + wy) position inside the frame's bounds.  Ascending keys therefore group the
-// points by block and order them by descending voxel code inside a block (ties keep input order: the sort is
-// stable); the order of the blocks themselves is irrelevant (see the header of this file), so it need not be
-// Morton order -- and a room-sized frame needs 22 key bits (3 radix passes) instead of 3*8 + 1.  Unusable points
-// get 2^bits, above every usable key, so they end up behind the n_usable usable points.
+// Stage 2: sort keys.  key = [super-block index : wx + wy + wz bits][block in super block : 3 bits]
+// [63 - voxel in block : 6 bits], the super-block index being its x | y << wx | z << (wx + wy) position inside the
+// frame's bounds.  Ascending keys therefore group the points by super block, then by block, and order them by
+// descending voxel code inside a block (ties keep input order: the sort is stable); the order of the blocks themselves
+// is irrelevant (see the header of this file), so it need not be Morton order -- and a room-sized frame needs 22 key
+// bits (3 radix passes) instead of 3*8 + 1.  Unusable points get 2^bits, above every usable key, so they end up
+// behind the n_usable usable points.
 __global__ void __launch_bounds__(256)
 k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
              FramePartial* __restrict__ part, uint64_t* __restrict__ keys,
@@ -215,8 +219,10 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
         if (point_usable(p, pos, recip)) {
             const I3 v = voxel_of(p, recip);
             const unsigned long long mc = morton_encode(v.x, v.y, v.z);
-            const uint64_t bx = (uint32_t(v.x - f.ox) >> 2) & mask_x, by = (uint32_t(v.y - f.oy) >> 2) & mask_y, bz = (uint32_t(v.z - f.oz) >> 2) & mask_z;
-            key = ((bx | (by << f.wx) | (bz << (f.wx + f.wy))) << 6) | (63u - (uint32_t(mc) & 63u));
+            const uint32_t rx = uint32_t(v.x - f.ox), ry = uint32_t(v.y - f.oy), rz = uint32_t(v.z - f.oz);  // voxel inside the frame's bounds
+            const uint64_t sx = (rx >> 3) & mask_x, sy = (ry >> 3) & mask_y, sz = (rz >> 3) & mask_z;
+            const uint32_t inner = ((rx >> 2) & 1u) | (((ry >> 2) & 1u) << 1) | (((rz >> 2) & 1u) << 2);
+            key = ((((sx | (sy << f.wx) | (sz << (f.wx + f.wy))) << 3) | inner) << 6) | (63u - (uint32_t(mc) & 63u));
             mc_min = mc < mc_min ? mc : mc_min;
         }
         keys[i] = key;
@@ -242,8 +248,8 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
 
 // Stage 3 (after the sort): gather the points into processing order as float4 (x, y, z, input index), recompute
 // their global codes, and list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
-// normal estimation and (b) the update work items (start, length, block key) in items[]: the point blocks cut again at
-// every kItemPoints-th point, so that no item is longer than kItemPoints.  A workgroup collects its entries in
+// normal estimation and (b) the update work items (start, length, super-block code) in items[]: the super blocks (runs
+// of equal code >> 9) cut again at every kItemPoints-th point, so that no item is longer than kItemPoints.  A workgroup collects its entries in
 // LDS (block heads as a list, item starts as a 2048-bit mask whose next set bit gives an item's length) and
 // reserves output space with ONE atomic per list and chunk; the lists are in no particular order.
 // The sorted (key, idx) pairs are in sort buffer (sort_passes & 1).
@@ -294,7 +300,8 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
                 codes[i] = mc;
                 const bool head = i == 0 || (keys[i] >> 6) != (keys[i - 1] >> 6);
                 if (head) heads[atomicAdd(&n_heads, 1u)] = i;
-                if (head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
+                const bool super_head = i == 0 || (keys[i] >> 9) != (keys[i - 1] >> 9);
+                if (super_head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (mc == mc_min) atomicMax(&h->last_idx, src);
             }
         }
@@ -319,7 +326,7 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
                 const uint32_t rank = word_rank[k >> 5] + __popc(word & ((1u << bit) - 1u));
                 const uint32_t higher = bit == 31u ? 0u : word >> (bit + 1u);
                 const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[k >> 5];
-                const uint64_t block_key = codes[c * kGatherChunk + k] & kBlockMask;  // written by this very thread above
+                const uint64_t block_key = codes[c * kGatherChunk + k] & ~511ull;  // corner of the 8x8x8 super block; codes[] written by this very thread above
                 items[base_marks + rank] = make_uint4(c * kGatherChunk + k, min(next, chunk_len) - k, uint32_t(block_key), uint32_t(block_key >> 32));
             }
         }

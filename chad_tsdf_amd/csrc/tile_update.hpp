@@ -1,39 +1,45 @@
 // tile_update.hpp -- the TSDF update with the voxel neighbourhood staged in LDS (reference: octree.hpp:80-170).
 //
-// Points arrive grouped by 4x4x4-voxel block (the "point block").  A ray segment reaches at most
-// R = ceil(trunc/res) + 1 voxels away from its point, so every voxel a point block's rays touch lies in the cube of
-// D = 4 + 2R voxels around the block: D^3 x 8 bytes of LDS -- 8 KiB for trunc = 2*res (D = 10),
-// 13.5 KiB for trunc = 3*res (D = 12, the largest tile kept in LDS).  One wave per work item (a point block, cut
-// at every 256th point by k_frame_gather); per item:
-//   0. lanes 0..26 compute the keys of the 3x3x3 neighbour blocks and LOAD their home hash slots -- speculative,
-//      nothing is created -- so that the answers are back when the walk is over;
-//   1. each lane walks the rays of its points and accumulates (d, 1) into the tile with ONE ds_add_u64 per
-//      observation.  A tile cell is a 64-bit word [count : 24 | sum of (d * 2^30/trunc + 2^30) : 40]: the
-//      fixed-point step trunc * 2^-30 is finer than the f32 rounding of d itself, an item adds at most 256
-//      observations per cell (no carry into the count), and integer sums do not depend on the order of arrival.
+// Points arrive grouped by "super block": 2x2x2 point blocks = 8x8x8 voxels (the sort key of frame_kernels.hpp puts
+// them next to each other).  A ray segment reaches at most R = ceil(trunc/res) + 1 voxels away from its point, so
+// every voxel a super block's rays touch lies in the cube of D = 8 + 2R voxels around it: D^3 x 8 bytes of LDS --
+// 21.4 KiB for trunc = 2*res (D = 14), 32 KiB for D = 16 (the largest tile kept in LDS) -- which the 4x4x4 = 64
+// bricks around the super block cover.  One workgroup of four waves per work item (a super block, cut at every
+// 512th point by k_frame_gather); the first version staged one 4x4x4 block per wave: 3.2 times as many items,
+// each paying the per-item latencies below, and 83 % of the lanes busy instead of 97 %.  Per item:
+//   1. the waves take the item's 64-point chunks in turn; each lane walks the ray of its point and accumulates
+//      (d, 1) into the tile with ONE ds_add_u64 per observation.  A tile cell is a 64-bit word
+//      [count : 24 | sum of (d * 2^30/trunc + 2^30) : 40]: the fixed-point step trunc * 2^-30 is finer than the f32
+//      rounding of d itself, an item adds at most 512 observations per cell (no carry into the count), and integer
+//      sums do not depend on the order of arrival.
 //      The walk itself is the reference's traversal (same f32 operations on tmax/delta, same comparison tree, so
 //      the voxel lists are bit-identical) with the bookkeeping folded into three registers: the LDS address and the
 //      per-axis remaining step counts share one word that a step updates with a single add, and the signed
 //      distance -- for which the bar is 1e-4, not bit equality -- is carried incrementally in fixed-point scale.
-//      ~25 VALU instructions per voxel step (the first version: ~110).
+//      ~26 VALU instructions per voxel step (the first version: ~110).
 //      Rays that leave the tile (float rounding at the rim, trunc > 3*res) or whose normal is not finite (Q4) take
 //      the global path of k_update_scatter instead, outside the hot loop;
-//   2. the 27 bricks of the tile are read back (lane = voxel of the brick, all reads in flight together) to learn
-//      which of them received observations; lanes 0..26 whose brick was touched and whose speculative load did
-//      not already show the key claim or find the slot with one CAS (map_kernels.hpp);
+//   2. workgroup barrier; wave w owns the 16 bricks of slab z = w from here on.  It reads them back (lane = voxel
+//      of the brick, all 16 reads in flight together) to learn which received observations; lanes 0..15 whose brick
+//      was touched and whose speculative look-up (below) did not already show the key claim or find the slot with
+//      one CAS (map_kernels.hpp);
 //   3. every touched brick is flushed with two 256-byte wave-wide atomic adds (sum, count), the full-rate shape for
-//      memory-side atomics, and its part of the tile is zeroed for the next item.
-// Work items are pulled from 256 separate counters (a returning atomic on ONE shared address serialises at ~25 ns
-// per dequeue).  Sparse frames (few points per block) skip this kernel and take k_update_scatter instead: with one
-// point per block the staging is pure overhead.
+//      memory-side atomics, and its part of the tile is zeroed for the next item; workgroup barrier.
+// Memory operations of a wave complete in issue order, so a load issued behind the flush's atomics waits ~3000
+// cycles for them.  The loop is therefore software-pipelined: right after the first barrier -- before the flush --
+// every wave loads the NEXT item's first chunk of points and the home hash slots of its 16 bricks (speculative,
+// nothing is created), and the next item's record itself was fetched by wave 0 during the walk.
+// Work items: the first one is static (workgroup index), the rest are pulled from 256 separate counters (a
+// returning atomic on ONE shared address serialises at ~25 ns per dequeue).  Sparse frames (few points per block)
+// skip this kernel and take k_update_scatter instead: with one point per block the staging is pure overhead.
 #pragma once
 #include "map_kernels.hpp"
 
 namespace chadhip {
 
-constexpr int kTileWaves = 4;            // independent waves per workgroup, each with its own tile (no workgroup barriers)
+constexpr int kTileWaves = 4;            // waves per workgroup: they share the item's tile and take its chunks in turn
 constexpr int kTileThreads = 64 * kTileWaves;
-constexpr uint32_t kMaxReach = 4;        // tiles beyond D = 12 do not fit the LDS budget per wave
+constexpr uint32_t kMaxReach = 4;        // D = 16: 32 KiB of LDS per workgroup
 constexpr float kFixedOne = 1073741824.0f;  // 2^30: |d| = trunc in the tile's fixed-point scale
 
 // Order this wave's LDS accesses (issued in order by the hardware) without a workgroup barrier and without
@@ -64,153 +70,198 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     return t;
 }
 
-template <bool kStamps>
-__global__ void __launch_bounds__(kTileThreads, 5)  // <= 96 VGPRs: 5 workgroups per CU, what the 32 KB of LDS per workgroup allow
+// LDS-only workgroup barrier: __syncthreads() would also drain the global atomics in flight.
+__device__ __forceinline__ void tile_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool kStamps, int kMinWaves>
+__global__ void __launch_bounds__(kTileThreads, kMinWaves)
 k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normals, const uint4* __restrict__ items, FrameHeader* __restrict__ h,
                F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
     if (adaptive && frame_is_sparse(h)) return;
-    const int R = int(reach), D = 4 + 2 * R;
+    const int R = int(reach), D = 8 + 2 * R;
     const uint32_t cells = uint32_t(D * D * D);
-    const uint32_t lane = threadIdx.x & 63u, wave_in_group = threadIdx.x >> 6;
-    // cells + 1 words per wave: the last one is never added to and stands in for cells outside the tile
-    unsigned long long* tile = reinterpret_cast<unsigned long long*>(tile_raw) + size_t(wave_in_group) * (cells + 1u);
+    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+    // cells + 1 words: the last one is never added to and stands in for cells outside the tile; then the next item's record
+    unsigned long long* tile = reinterpret_cast<unsigned long long*>(tile_raw);
+    uint4* next_record = reinterpret_cast<uint4*>(tile + ((cells + 2u) & ~1u));
     const uint32_t tile_base = uint32_t(uintptr_t(tile));  // LDS byte address (low half of the flat address)
     const float to_fixed = kFixedOne / trunc, from_fixed = trunc / kFixedOne;
-    for (uint32_t k = lane; k <= cells; k += 64) tile[k] = 0ull;
+    for (uint32_t k = threadIdx.x; k <= cells; k += kTileThreads) tile[k] = 0ull;
     const uint32_t nitems = h->n_items;
-    unsigned long long applied = 0;
+    uint32_t applied = 0;
 
-    // lane = voxel v of a brick (Morton order of the low 6 code bits): its cell in the centre brick, and for which of
-    // the 27 bricks of the 3x3x3 neighbourhood that voxel lies inside the tile
+    // lane = voxel v of a brick (Morton order of the low 6 code bits).  This wave's bricks: (bx, by) = 0..3 x 0..3 in
+    // slab bz = wave; brick b sits at voxel offset 4 * (b - 1) from the super block's corner.
     const int vx = int((lane & 1u) | ((lane >> 2) & 2u)), vy = int(((lane >> 1) & 1u) | ((lane >> 3) & 2u)), vz = int(((lane >> 2) & 1u) | ((lane >> 4) & 2u));
-    const int centre_cell = (vx + R) + D * (vy + R) + D * D * (vz + R);
-    uint32_t lane_valid = 0;
-    for (int b = 0; b < 27; b++) {
-        const int tx = (b % 3 - 1) * 4 + vx + R, ty = ((b / 3) % 3 - 1) * 4 + vy + R, tz = (b / 9 - 1) * 4 + vz + R;
+    const int tz = 4 * int(wave) + vz + R - 4;
+    const int slab_cell = (vx + R - 4) + D * (vy + R - 4) + D * D * tz;   // this lane's cell in brick (0, 0) of the slab
+    uint32_t lane_valid = 0;   // bit bx + 4 * by: this lane's voxel of that brick lies inside the tile
+    for (int b = 0; b < 16; b++) {
+        const int tx = 4 * (b & 3) + vx + R - 4, ty = 4 * (b >> 2) + vy + R - 4;
         if (uint32_t(tx) < uint32_t(D) && uint32_t(ty) < uint32_t(D) && uint32_t(tz) < uint32_t(D)) lane_valid |= 1u << b;
     }
-    // lanes 0..26: offset of neighbour brick `lane` from the point block
-    const int nbx = (int(lane % 3u) - 1) * 4, nby = (int((lane / 3u) % 3u) - 1) * 4, nbz = (int(lane / 9u) - 1) * 4;
-    wave_sync();
+    // cell of this lane's voxel in brick b of the slab.  For a voxel outside the tile the address is meaningless but
+    // harmless (DS reads beyond the workgroup's allocation return zero; every use is masked by lane_valid)
+    auto cell_of = [&](int b) { return uint32_t(slab_cell + 4 * ((b & 3) + D * (b >> 2))); };
 
-    // Work items are pulled from one of kWorkGroups counters (this wave's group = wave % kWorkGroups; group g owns
-    // items g, g + kWorkGroups, ...): ~20 waves share a counter, so the load balances dynamically inside a group
-    // while no counter sees more than a few dozen atomics.
-    const uint32_t wave_global = blockIdx.x * kTileWaves + wave_in_group;
-    const uint32_t group = wave_global % kWorkGroups;
+    const uint32_t group = blockIdx.x % kWorkGroups;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t_begin = 0, items_done = 0;
     if (kStamps) t_begin = stamp_now();
-    auto take_ticket = [&]() {  // one returning atomic per wave and item, broadcast through an SGPR
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&h->work_cursor[group * 16u], 1u);
-        return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
-    };
-    uint32_t turn = take_ticket();
-    for (;;) {
-        if (kStamps) t0 = stamp_now();
-        const uint32_t item = group + kWorkGroups * turn;
-        if (item >= nitems) break;
-        const uint4 record = items[item];  // (first point, number of points <= kItemPoints, block key), from k_frame_gather
-        turn = take_ticket();              // the next item's ticket is fetched while this one is processed
-        if (kStamps) items_done++;
-        const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(record.x))), len = uint32_t(__builtin_amdgcn_readfirstlane(int(record.y)));
-        const uint64_t block_key = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(record.z)))) | (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(record.w)))) << 32);
-        const I3 corner = morton_decode(block_key);                          // lowest voxel of the point block
-        const int ox = corner.x - R, oy = corner.y - R, oz = corner.z - R;    // tile origin
 
-        // step 0: speculative look-up of the 27 neighbour blocks (plain loads that bypass the L1: a stale "empty" only
-        // sends the lane to the CAS below; keys never change or vanish during an insert)
-        uint64_t my_key = kEmptyKey, early = kEmptyKey;
-        uint32_t my_slot = 0;
-        if (lane < 27u) {
-            my_key = morton_encode(corner.x + nbx, corner.y + nby, corner.z + nbz);
+    // everything a wave holds about an item before it starts on it
+    uint4 record = blockIdx.x < nitems ? items[blockIdx.x] : make_uint4(0u, 0u, 0u, 0u);   // length 0: no more work
+    float4 q_first = make_float4(0, 0, 0, 0), n_first = make_float4(0, 0, 0, 0);            // its first chunk's point and normal for this lane
+    uint64_t my_key = kEmptyKey, early = kEmptyKey;                                         // lanes 0..15: key of their brick, what its home slot held
+    uint32_t my_slot = 0;
+    auto prefetch = [&](const uint4& rec) {
+        const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.x))), len = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.y)));
+        const uint32_t k = wave * 64u + lane;
+        if (k < len) { q_first = pts[first + k]; n_first = normals[first + k]; }
+        if (lane < 16u && len) {
+            // key of brick (bx, by, wave): the corner's code with -4 / 0 / +4 / +8 voxels added per axis, in interleaved
+            // ("dilated") arithmetic -- a subtraction borrows through the zero gaps of the masked operand, an addition
+            // carries through gaps filled with ones; the corner is a multiple of 8, so +4 just sets a bit.  The four
+            // candidates per axis are wave-uniform (scalar unit); a lane only selects.
+            const uint64_t code = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(rec.z)))) | (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(rec.w)))) << 32);
+            constexpr uint64_t kMx = 0x1249249249249249ull, kMy = kMx << 1, kMz = kMx << 2;
+            const uint64_t xd = code & kMx, yd = code & kMy, zd = code & kMz;
+            const uint64_t x0 = (xd - (1ull << 6)) & kMx, x2 = xd | (1ull << 6), x3 = ((xd | ~kMx) + (1ull << 9)) & kMx;
+            const uint64_t y0 = (yd - (1ull << 7)) & kMy, y2 = yd | (1ull << 7), y3 = ((yd | ~kMy) + (1ull << 10)) & kMy;
+            const uint64_t zs = wave == 0u ? (zd - (1ull << 8)) & kMz : wave == 1u ? zd : wave == 2u ? zd | (1ull << 8) : ((zd | ~kMz) + (1ull << 11)) & kMz;
+            const uint32_t bx = lane & 3u, by = (lane >> 2) & 3u;
+            my_key = (bx == 0u ? x0 : bx == 1u ? xd : bx == 2u ? x2 : x3) | (by == 0u ? y0 : by == 1u ? yd : by == 2u ? y2 : y3) | zs;
             my_slot = hash_block(my_key, m.hash_mask);
+            // plain load that bypasses the L1: a stale "empty" only sends the lane to the CAS; keys never change or vanish during an insert
             early = __hip_atomic_load(&m.hash_keys[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    };
+    prefetch(record);
+    uint32_t turn = 0;  // first lane of the last wave: ticket of the item after the current one (in flight during the walk)
+    tile_barrier();     // the tile is zeroed
+
+    while (__builtin_amdgcn_readfirstlane(int(record.y)) != 0) {
+        if (kStamps) { t0 = stamp_now(); items_done++; }
+        const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(record.x))), len = uint32_t(__builtin_amdgcn_readfirstlane(int(record.y)));
+        const uint64_t corner_code = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(record.z)))) | (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(record.w)))) << 32);
+        const I3 corner = morton_decode(corner_code);                         // lowest voxel of the super block
+        const int ox = corner.x - R, oy = corner.y - R, oz = corner.z - R;    // tile origin
+        if (threadIdx.x == kTileThreads - 64) turn = atomicAdd(&h->work_cursor[group * 16u], 1u);
         if (kStamps) { const unsigned long long t1 = stamp_now(); ph[0] += t1 - t0; t0 = t1; }
 
-        // step 1: the walk
-        for (uint32_t k = lane; k < len; k += 64) {
-            const float4 q = pts[first + k], nq = normals[first + k];
-            const F3 p{q.x, q.y, q.z}, nrm{nq.x, nq.y, nq.z};
-            RayWalk w;
-            w.begin(p, pos, res, recip, trunc);
-            const int lx = w.cur.x - ox, ly = w.cur.y - oy, lz = w.cur.z - oz;
-            const uint32_t spx = uint32_t(abs(w.last.x - w.cur.x)), spy = uint32_t(abs(w.last.y - w.cur.y)), spz = uint32_t(abs(w.last.z - w.cur.z));
-            // every voxel of the walk lies in the box spanned by its first and last voxel
-            const bool inside = uint32_t(lx) < uint32_t(D) && uint32_t(ly) < uint32_t(D) && uint32_t(lz) < uint32_t(D) &&
-                                uint32_t(w.last.x - ox) < uint32_t(D) && uint32_t(w.last.y - oy) < uint32_t(D) && uint32_t(w.last.z - oz) < uint32_t(D) &&
-                                (spx | spy | spz) < 8u && finite3(nrm);
-            if (inside) {
-                LeanRay r;
-                r.tx = w.tmax.x; r.ty = w.tmax.y; r.tz = w.tmax.z;
-                r.dx = w.delta.x; r.dy = w.delta.y; r.dz = w.delta.z;
-                const float scale = res * to_fixed;
-                r.d = dot3(nrm, F3{float(w.cur.x) * res - p.x, float(w.cur.y) * res - p.y, float(w.cur.z) * res - p.z}) * to_fixed;  // octree.hpp:157-158
-                r.ddx = float(w.step.x) * scale * nrm.x; r.ddy = float(w.step.y) * scale * nrm.y; r.ddz = float(w.step.z) * scale * nrm.z;
-                r.s = ((tile_base + 8u * uint32_t(lx + D * ly + D * D * lz)) << 16) | 0x888u | spx | (spy << 4) | (spz << 8);
-                r.kx = (uint32_t(8 * w.step.x) << 16) - 1u;
-                r.ky = (uint32_t(8 * D * w.step.y) << 16) - 16u;
-                r.kz = (uint32_t(8 * D * D * w.step.z) << 16) - 256u;
-                do {
-                    const float clamped = __builtin_amdgcn_fmed3f(r.d, -kFixedOne, kFixedOne);  // octree.hpp:159
-                    const uint32_t fixed = uint32_t(int(clamped)) + (1u << 30);
-                    __hip_atomic_fetch_add(lds_cell(r.s >> 16), (1ull << 40) | fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const bool xy = r.tx < r.ty, xz = r.tx < r.tz, yz = r.ty < r.tz;   // comparison tree of octree.hpp:126-150
-                    const bool sx = xy && xz, sy = !xy && yz, sz = !(sx || sy);
-                    r.tx += sx ? r.dx : 0.0f;   // tmax >= 0 (or NaN/inf): adding +0.0f leaves it unchanged
-                    r.ty += sy ? r.dy : 0.0f;
-                    r.tz += sz ? r.dz : 0.0f;
-                    r.d += sx ? r.ddx : (sy ? r.ddy : r.ddz);
-                    r.s += sx ? r.kx : (sy ? r.ky : r.kz);
-                } while ((r.s & 0x888u) == 0x888u);
-            } else {  // straight to HBM, one observation at a time (rare)
-                uint64_t far_key = kEmptyKey;
-                uint32_t far_brick = kNoBrick;
-                do {
-                    const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
-                    const uint64_t key = mc & kBlockMask;
-                    if (key != far_key) { far_brick = find_or_create_brick(m, key, h); far_key = key; }
-                    if (far_brick != kNoBrick) {
-                        const size_t at = size_t(far_brick) * 64 + (uint32_t(mc) & 63u);
-                        atomicAdd(&m.brick_sum[at], observe(w.cur, p, nrm, res, trunc));
-                        atomicAdd(&m.brick_cnt[at], 1u);
-                        applied++;
-                    }
-                } while (w.next());
+        // step 1: the walk (the wave's first chunk is already in registers)
+        float4 q = q_first, nq = n_first;
+        for (uint32_t base = wave * 64u; base < len; base += kTileThreads) {
+            const uint32_t k = base + lane;
+            float4 q_next = q, n_next = nq;
+            if (k < len) {
+                const F3 p{q.x, q.y, q.z}, nrm{nq.x, nq.y, nq.z};
+                RayWalk w;
+                w.begin(p, pos, res, recip, trunc);
+                const int lx = w.cur.x - ox, ly = w.cur.y - oy, lz = w.cur.z - oz;
+                const uint32_t spx = uint32_t(abs(w.last.x - w.cur.x)), spy = uint32_t(abs(w.last.y - w.cur.y)), spz = uint32_t(abs(w.last.z - w.cur.z));
+                // every voxel of the walk lies in the box spanned by its first and last voxel
+                const bool inside = uint32_t(lx) < uint32_t(D) && uint32_t(ly) < uint32_t(D) && uint32_t(lz) < uint32_t(D) &&
+                                    uint32_t(w.last.x - ox) < uint32_t(D) && uint32_t(w.last.y - oy) < uint32_t(D) && uint32_t(w.last.z - oz) < uint32_t(D) &&
+                                    (spx | spy | spz) < 8u && finite3(nrm);
+                // the wave's next chunk: loads issued here, behind the register-hungry traversal setup, in flight during the steps
+                if (k + kTileThreads < len) { q_next = pts[first + k + kTileThreads]; n_next = normals[first + k + kTileThreads]; }
+                if (inside) {
+                    LeanRay r;
+                    r.tx = w.tmax.x; r.ty = w.tmax.y; r.tz = w.tmax.z;
+                    r.dx = w.delta.x; r.dy = w.delta.y; r.dz = w.delta.z;
+                    const float scale = res * to_fixed;
+                    r.d = dot3(nrm, F3{float(w.cur.x) * res - p.x, float(w.cur.y) * res - p.y, float(w.cur.z) * res - p.z}) * to_fixed;  // octree.hpp:157-158
+                    r.ddx = float(w.step.x) * scale * nrm.x; r.ddy = float(w.step.y) * scale * nrm.y; r.ddz = float(w.step.z) * scale * nrm.z;
+                    r.s = ((tile_base + 8u * uint32_t(lx + D * ly + D * D * lz)) << 16) | 0x888u | spx | (spy << 4) | (spz << 8);
+                    r.kx = (uint32_t(8 * w.step.x) << 16) - 1u;
+                    r.ky = (uint32_t(8 * D * w.step.y) << 16) - 16u;
+                    r.kz = (uint32_t(8 * D * D * w.step.z) << 16) - 256u;
+                    do {
+                        const float clamped = __builtin_amdgcn_fmed3f(r.d, -kFixedOne, kFixedOne);  // octree.hpp:159
+                        const uint32_t fixed = uint32_t(int(clamped)) + (1u << 30);
+                        __hip_atomic_fetch_add(lds_cell(r.s >> 16), (1ull << 40) | fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const bool xy = r.tx < r.ty, xz = r.tx < r.tz, yz = r.ty < r.tz;   // comparison tree of octree.hpp:126-150
+                        const bool sx = xy && xz, sy = !xy && yz, sz = !(sx || sy);
+                        r.tx += sx ? r.dx : 0.0f;   // tmax >= 0 (or NaN/inf): adding +0.0f leaves it unchanged
+                        r.ty += sy ? r.dy : 0.0f;
+                        r.tz += sz ? r.dz : 0.0f;
+                        r.d += sx ? r.ddx : (sy ? r.ddy : r.ddz);
+                        r.s += sx ? r.kx : (sy ? r.ky : r.kz);
+                    } while ((r.s & 0x888u) == 0x888u);
+                } else {  // straight to HBM, one observation at a time (rare)
+                    uint64_t far_key = kEmptyKey;
+                    uint32_t far_brick = kNoBrick;
+                    do {
+                        const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
+                        const uint64_t key = mc & kBlockMask;
+                        if (key != far_key) { far_brick = find_or_create_brick(m, key, h); far_key = key; }
+                        if (far_brick != kNoBrick) {
+                            const size_t at = size_t(far_brick) * 64 + (uint32_t(mc) & 63u);
+                            atomicAdd(&m.brick_sum[at], observe(w.cur, p, nrm, res, trunc));
+                            atomicAdd(&m.brick_cnt[at], 1u);
+                            applied++;
+                        }
+                    } while (w.next());
+                }
             }
+            q = q_next; nq = n_next;
         }
-        wave_sync();  // all LDS adds of this item are issued (in order) before the read-back
+        // the last wave -- the one with the fewest chunks -- fetches the next item's record while the others finish walking:
+        // ticket t -> item gridDim + group + 256 t
+        if (threadIdx.x == kTileThreads - 64) {
+            const uint32_t next = gridDim.x + group + kWorkGroups * turn;
+            *next_record = next < nitems ? items[next] : make_uint4(0u, 0u, 0u, 0u);
+        }
         if (kStamps) { const unsigned long long t1 = stamp_now(); ph[3] += t1 - t0; t0 = t1; }
+        tile_barrier();  // all LDS adds of this item have been performed; the next record is in place
+        if (kStamps) { const unsigned long long t1 = stamp_now(); ph[1] += t1 - t0; t0 = t1; }
 
-        // step 2: which of the 27 bricks received observations (all 27 reads in flight together)
+        // step 2: which of this wave's 16 bricks received observations (four reads in flight at a time)
+        const uint64_t this_key = my_key;
+        const uint32_t this_slot = my_slot;
         uint32_t touched = 0;
 #pragma unroll 1
-        for (int bz = 0; bz < 3; bz++) {  // one slab of 9 bricks at a time, its 9 reads in flight together (27 hoisted addresses cost 27 VGPRs)
-            const uint32_t valid9 = lane_valid >> (9 * bz);
-            const int slab = centre_cell + 4 * D * D * (bz - 1);
-            uint32_t t9 = 0;
+        for (int by = 0; by < 4; by++) {   // four bricks at a time: one address register, the four reads in flight together
+            const unsigned long long* row = tile + cell_of(4 * by);
+            const uint32_t valid4 = lane_valid >> (4 * by);
+            uint32_t t4 = 0;
 #pragma unroll
-            for (int b = 0; b < 9; b++) {
-                const uint32_t at = ((valid9 >> b) & 1u) ? uint32_t(slab + 4 * ((b % 3 - 1) + D * (b / 3 - 1))) : cells;
-                t9 |= __ballot(tile[at] != 0ull) ? (1u << b) : 0u;
-            }
-            touched |= t9 << (9 * bz);
+            for (int bx = 0; bx < 4; bx++) t4 |= __ballot(((valid4 >> bx) & 1u) && row[4 * bx] != 0ull) ? (1u << bx) : 0u;
+            touched |= t4 << (4 * by);
         }
         if (kStamps) { asm volatile("" :: "s"(touched)); const unsigned long long t1 = stamp_now(); ph[6] += t1 - t0; t0 = t1; }
-        uint32_t my_brick = kNoBrick;
-        if (lane < 27u && ((touched >> lane) & 1u)) my_brick = early == my_key ? my_slot : find_or_create_brick(m, my_key, h, my_slot);
-        if (kStamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" :: "v"(my_brick)); const unsigned long long t1 = stamp_now(); ph[7] += t1 - t0; t0 = t1; }
+        // touched bricks whose key the speculative look-up did not show: one CAS claims or finds the home slot.  It is
+        // issued here and resolved behind the next item's loads (below), so its round trip overlaps their address arithmetic
+        const bool mine = lane < 16u && ((touched >> lane) & 1u);
+        const bool ask = mine && early != this_key;
+        uint64_t seen = this_key;
+        if (ask) seen = atomicCAS((unsigned long long*)&m.hash_keys[this_slot], (unsigned long long)kEmptyKey, (unsigned long long)this_key);
+        // the loads for the next item (in flight during the rest of step 2 and step 3)
+        record = *next_record;
+        prefetch(record);
+        uint32_t my_brick = mine ? this_slot : kNoBrick;
+        if (ask && seen != this_key) {
+            if (seen == kEmptyKey) {  // claimed (map_kernels.hpp, find_or_create_brick)
+                atomicOr(&m.live_bits[this_slot >> 5], 1u << (this_slot & 31u));
+                atomicAdd(&m.brick_count[(this_slot & (kCountStripes - 1)) * 16], 1u);
+            } else my_brick = find_or_create_brick(m, this_key, h, (this_slot + 1u) & m.hash_mask);  // the home slot holds another block
+        }
+        // the prefetched loads are older than the flush's atomics: wait for them here, where they have long arrived,
+        // and not at their first use, where the in-order counter would make that wait cover the atomics as well
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(q_first.x), "+v"(q_first.y), "+v"(q_first.z), "+v"(n_first.x), "+v"(n_first.y), "+v"(n_first.z));
+        if (kStamps) { asm volatile("" :: "v"(my_brick)); const unsigned long long t1 = stamp_now(); ph[7] += t1 - t0; t0 = t1; }
 
         // step 3: flush
         for (uint32_t left = touched; left;) {
             const int b = __ffs(int(left)) - 1;
             left &= left - 1u;
             const uint32_t brick = uint32_t(__builtin_amdgcn_readlane(int(my_brick), b));
-            const int off = 4 * ((b % 3 - 1) + D * ((b / 3) % 3 - 1) + D * D * (b / 9 - 1));
-            const uint32_t at = ((lane_valid >> b) & 1u) ? uint32_t(centre_cell + off) : cells;
-            const unsigned long long cell = tile[at];
+            const uint32_t at = cell_of(b);
+            const unsigned long long cell = ((lane_valid >> b) & 1u) ? tile[at] : 0ull;
             if (cell) {
                 const uint32_t c = uint32_t(cell >> 40);
                 // sum of d = (sum of biased fixed values - c * 2^30) * trunc / 2^30: exact integer, one rounding to f32
@@ -223,18 +274,21 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
                 tile[at] = 0ull;
             }
         }
-        wave_sync();
         if (kStamps) { const unsigned long long t1 = stamp_now(); ph[4] += t1 - t0; t0 = t1; }
+        tile_barrier();  // the tile is zero again
+        if (kStamps) { const unsigned long long t1 = stamp_now(); ph[2] += t1 - t0; t0 = t1; }
     }
     if (kStamps && lane == 0) {
+        const uint32_t wave_global = blockIdx.x * kTileWaves + wave;
         ph[5] = stamp_now() - t_begin;
-        ph[1] = t_begin;        // diagnostic build only: start time and items done replace the unused slots
+        ph[1] += ph[2];         // both barriers
         ph[2] = items_done;
         for (int k = 0; k < 8; k++) stamps[size_t(wave_global) * 8 + k] = ph[k];
     }
+    unsigned long long total = applied;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) applied += __shfl_xor(applied, o);
-    if (lane == 0 && applied) atomicAdd(&h->n_updates[(wave_global & 31u) * 16u], applied);
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0 && total) atomicAdd(&h->n_updates[((blockIdx.x * kTileWaves + wave) & 31u) * 16u], total);
 }
 
 inline uint32_t tile_reach(float res, float trunc) {
@@ -245,14 +299,28 @@ inline uint32_t tile_reach(float res, float trunc) {
 inline void tile_update_enqueue(const float4* pts, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
                                 const MapView& m, hipStream_t stream, bool adaptive, unsigned long long* stamps = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
-    const uint32_t d = 4 + 2 * reach;
-    const size_t lds = (size_t(d) * d * d + 1) * 8 * kTileWaves;
-    uint32_t per_cu = uint32_t(std::min<size_t>(6, (160 * 1024) / (lds + 64)));  // persistent workgroups (of 4 waves) per CU
+    const uint32_t d = 8 + 2 * reach;
+    const size_t lds = ((size_t(d) * d * d + 2) & ~size_t(1)) * 8 + 16;   // tile + spare zero cell (padded to 16 bytes) + next item's record
+    // persistent workgroups: as many as are resident at once (registers and LDS decide), on every CU
+    static int resident[3] = {0, 0, 0};
+    static size_t resident_lds = 0;
+    static int variant = 0;  // 0: 5 waves per SIMD (96 VGPRs), 1: 6 waves per SIMD (80 VGPRs, a few spills)
+    if (resident_lds != lds) {
+        if (const char* e = std::getenv("CHAD_DEBUG_TILE_VARIANT")) variant = std::atoi(e) ? 1 : 0;
+        resident[0] = resident[1] = resident[2] = 1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[0], k_update_tiled<false, 5>, kTileThreads, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[1], k_update_tiled<false, 6>, kTileThreads, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[2], k_update_tiled<true, 5>, kTileThreads, lds);
+        resident_lds = lds;
+    }
+    uint32_t per_cu = uint32_t(std::max(1, std::min(8, resident[stamps ? 2 : variant])));
     if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::atoi(e));
     if (stamps)
-        hipLaunchKernelGGL(k_update_tiled<true>, dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+    else if (variant)
+        hipLaunchKernelGGL((k_update_tiled<false, 6>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
     else
-        hipLaunchKernelGGL(k_update_tiled<false>, dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
 }
 
 }  // namespace chadhip
