@@ -3,7 +3,9 @@
 (cfg2: voxel 0.05 m, trunc 0.10 m), one process per GPU.
 
 A step = chad::TSDFMap::insert() of one 1 M-point synthetic scan into an EMPTY map on this rank's GPU
-(map.reset() + map.insert(), both inside the timed region), with the scan already resident in HBM.  With N > 1
+(map.reset() + map.insert(), both inside the timed region), with the scan already resident in HBM.  insert() is
+asynchronous, as in any streaming use: the library keeps up to three frames in flight (the map-independent stages
+of the next frames run beside the update of the current one), and the timed region ends with a full synchronisation.  With N > 1
 ranks every rank inserts its own scans (frames dealt round-robin: weak scaling) and the ranks' submaps are merged
 once at the end of the timed region with the RCCL exchange of chad_tsdf_amd/sharded.py (all_gather of block keys
 + all_reduce of the per-block partial sums), which is the path's only collective.
@@ -106,7 +108,8 @@ def main():
         elapsed = float(t.item())
 
     st = m.stats()  # ms_oct_upd: mean duration of the update kernel over the timed steps (HIP events on the map's stream)
-    # the reference's five stage timers: a separate untimed pass over the same scans with full stage timing
+    # the reference's five stage timers: a separate untimed pass over the same scans with full stage timing (stage timing
+    # makes the map run its frames one after the other on one stream, so the stage times do not overlap)
     ms_ = TSDFMap(res, trunc, timing=True, update_mode=args.update_mode, max_points=args.points)
     for i in range(min(8, args.steps) + 1):
         ms_.reset()
@@ -161,6 +164,10 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": round(upd_ms, 4),
+            # the timed region keeps three frames in flight (the preparation of the next frames runs beside the update), so the
+            # live duration above includes that contention; the same kernel with the frames run one after the other:
+            "kernel_ms_serial": round(float(stage["ms_oct_upd"]), 4),
+            "frac_serial": round(algo_bytes / (float(stage["ms_oct_upd"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if stage["ms_oct_upd"] > 0 else None,
         },
     }
 

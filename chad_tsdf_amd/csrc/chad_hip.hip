@@ -59,34 +59,52 @@ enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
 
 }  // namespace
 
+// Everything one frame needs on its way from raw points to (points, normals, work items) in processing order.  A few
+// slots, used in turn, each with a stream of its own: the preparation of the next frames (bounds, keys, sort, gather,
+// normals -- none of which touches the map; every kernel of it is latency-bound and leaves most of the chip idle)
+// runs beside the update of frame k, which stays on the map's stream together with every other operation on the map
+// (clear, roll-over, growth, export), in call order.
+struct FrameSlot {
+    hipStream_t prep = nullptr;
+    hipEvent_t prep_done = nullptr;     // recorded on `prep` behind the normals kernel: the update may start
+    hipEvent_t update_done = nullptr;   // recorded on the map's stream behind the update: the slot's buffers are free again
+    bool used = false;
+    FrameHeader* d_hdr = nullptr;
+    FramePartial* d_part = nullptr;     // kFrameBlocks partial reductions of the frame kernels
+    size_t cap_points = 0;
+    float* d_xyz = nullptr;             // device copy of a host frame
+    float* h_stage = nullptr;           // pinned staging buffer for chad_map_insert (host points), cap_points * 12 bytes
+    hipEvent_t stage_done = nullptr;    // the H2D copies out of h_stage have completed
+    RadixSortBuffers sort{};
+    float4* d_pts = nullptr;
+    uint64_t* d_codes = nullptr;
+    float4* d_normals = nullptr;
+    uint32_t* d_seg = nullptr;
+};
+
 struct chad_map {
     float res = 0, trunc = 0, recip = 0;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the map's stream: updates and every other operation on the map
     bool own_stream = false;
+    hipEvent_t caller_ready = nullptr;  // caller-supplied stream only: the frame's input is ready once this has passed
+    static constexpr uint32_t kMaxSlots = 8;
+    uint32_t n_slots = 3;               // frames in flight (CHAD_SLOTS overrides, for experiments)
+    FrameSlot slot[kMaxSlots];
+    bool serial = false;                // stage timing / verbose: the slots share the map's stream, so that stage times do not overlap
+    uint32_t last_slot = 0;             // slot of the last insert
     uint32_t flags = 0, update_mode = CHAD_UPDATE_AUTO;
     uint32_t ablate = 0;  // CHAD_DEBUG_ABLATE: timing experiments only
     unsigned long long* d_stamps = nullptr;  // CHAD_DEBUG_STAMPS: per-phase cycle stamps of the update kernel
 
     MapView view{};
     uint32_t hash_capacity = 0, brick_capacity = 0;
-    FrameHeader* d_hdr = nullptr;
     FrameHeader* h_hdr = nullptr;  // pinned
-    FramePartial* d_part = nullptr;  // kFrameBlocks partial reductions of the frame kernels
+    uint32_t* d_overflow = nullptr;  // MapView::overflow
     volatile uint32_t* h_live_blocks = nullptr;  // host-mapped word the device mirrors the live block count into each frame
     uint32_t* d_live_blocks = nullptr;           // (its device address): lets the host grow the pools without a round trip
     bool fixed_capacity = false;
 
-    size_t cap_points = 0;
-    float* d_xyz = nullptr;  // device copy of a host frame
-    float* h_stage[2] = {nullptr, nullptr};  // pinned staging ring for chad_map_insert (host points), cap_points * 12 bytes each
-    hipEvent_t stage_done[2] = {nullptr, nullptr};  // the H2D copies out of h_stage[i] have completed
-    uint32_t stage_turn = 0;
-    RadixSortBuffers sort{};
-    float4* d_pts = nullptr;
-    uint64_t* d_codes = nullptr;
-    float4* d_normals = nullptr;
-    uint32_t* d_seg = nullptr;
 
     std::vector<std::array<float, 3>> positions;  // poses of the active submap (submap.hpp:110)
     std::vector<Submap> closed;                   // tsdf.cpp:54
@@ -122,50 +140,59 @@ inline dim3 grid_for(size_t n, int threads = 256, int max_blocks = 2048) {
     return dim3(unsigned(b));
 }
 
-void free_frame_buffers(chad_map* m) {
-    for (int i = 0; i < 2; i++) { if (m->h_stage[i]) (void)hipHostFree(m->h_stage[i]); m->h_stage[i] = nullptr; }
-    (void)hipFree(m->d_xyz); (void)hipFree(m->sort.keys[0]); (void)hipFree(m->sort.keys[1]);
-    (void)hipFree(m->sort.idx[0]); (void)hipFree(m->sort.idx[1]); (void)hipFree(m->sort.hist_part);
-    (void)hipFree(m->sort.digit_base); (void)hipFree(m->sort.tile_status);
-    (void)hipFree(m->d_pts); (void)hipFree(m->d_codes); (void)hipFree(m->d_normals); (void)hipFree(m->d_seg);
-    m->d_xyz = nullptr; m->sort = RadixSortBuffers{}; m->d_pts = nullptr; m->d_codes = nullptr; m->d_normals = nullptr; m->d_seg = nullptr;
-    m->cap_points = 0;
+void free_frame_buffers(FrameSlot& f) {
+    if (f.h_stage) (void)hipHostFree(f.h_stage);
+    f.h_stage = nullptr;
+    (void)hipFree(f.d_xyz); (void)hipFree(f.sort.keys[0]); (void)hipFree(f.sort.keys[1]);
+    (void)hipFree(f.sort.idx[0]); (void)hipFree(f.sort.idx[1]); (void)hipFree(f.sort.hist_part);
+    (void)hipFree(f.sort.digit_base); (void)hipFree(f.sort.tile_status);
+    (void)hipFree(f.d_pts); (void)hipFree(f.d_codes); (void)hipFree(f.d_normals); (void)hipFree(f.d_seg);
+    f.d_xyz = nullptr; f.sort = RadixSortBuffers{}; f.d_pts = nullptr; f.d_codes = nullptr; f.d_normals = nullptr; f.d_seg = nullptr;
+    f.cap_points = 0;
 }
 
-chad_status ensure_frame_capacity(chad_map* m, size_t n) {
-    if (n <= m->cap_points) return CHAD_OK;
+// Wait for everything enqueued for this map, on all of its streams.
+chad_status join_streams(chad_map* m) {
+    for (auto& f : m->slot) if (f.prep && f.prep != m->stream) HIP_TRY(hipStreamSynchronize(f.prep));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    size_t cap = std::max<size_t>(n, m->cap_points * 2);
+    return CHAD_OK;
+}
+
+chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
+    if (n <= f.cap_points) return CHAD_OK;
+    TRY(join_streams(m));
+    size_t cap = std::max<size_t>(n, f.cap_points * 2);
     cap = (cap + kSortTile - 1) / kSortTile * kSortTile;
-    free_frame_buffers(m);
-    HIP_TRY(hipMalloc(&m->d_xyz, cap * 12));
+    free_frame_buffers(f);
+    HIP_TRY(hipMalloc(&f.d_xyz, cap * 12));
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipMalloc(&m->sort.keys[i], cap * 8));
-        HIP_TRY(hipMalloc(&m->sort.idx[i], cap * 4));
+        HIP_TRY(hipMalloc(&f.sort.keys[i], cap * 8));
+        HIP_TRY(hipMalloc(&f.sort.idx[i], cap * 4));
     }
-    HIP_TRY(hipMalloc(&m->sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&m->sort.digit_base, size_t(kMaxPasses) * kRadix * 4));
-    HIP_TRY(hipMalloc(&m->sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
-    m->sort.tiles_capacity = radix_tiles(cap);
-    HIP_TRY(hipMalloc(&m->d_pts, cap * 16));
-    HIP_TRY(hipMalloc(&m->d_codes, cap * 8));
-    HIP_TRY(hipMalloc(&m->d_normals, cap * 16));
-    HIP_TRY(hipMalloc(&m->d_seg, cap * 24));  // point-block starts u32 [cap], lengths u32 [cap], update work items uint4 [cap] (start, length, block key)
-    m->cap_points = cap;
+    HIP_TRY(hipMalloc(&f.sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kMaxPasses) * kRadix * 4));
+    HIP_TRY(hipMalloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
+    f.sort.tiles_capacity = radix_tiles(cap);
+    HIP_TRY(hipMalloc(&f.d_pts, cap * 16));
+    HIP_TRY(hipMalloc(&f.d_codes, cap * 8));
+    HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
+    HIP_TRY(hipMalloc(&f.d_seg, cap * 24));  // point-block starts u32 [cap], lengths u32 [cap], update work items uint4 [cap] (start, length, block key)
+    f.cap_points = cap;
     return CHAD_OK;
 }
 
 void free_map_storage(MapView& v) {
     (void)hipFree(v.hash_keys); (void)hipFree(v.live_bits);
     (void)hipFree(v.brick_sum); (void)hipFree(v.brick_cnt); (void)hipFree(v.brick_count);
-    v = MapView{};
+    v = MapView{};  // (v.overflow belongs to the chad_map)
 }
 
 // Hash table + brick pools for `blocks` bricks, empty (keys EMPTY, values PENDING, sums and counts zero).
-chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream) {
+chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream, uint32_t* overflow) {
     uint64_t hcap = 1024;
     while (hcap < blocks * 2) hcap <<= 1;  // load factor <= 0.5
     v = MapView{};
+    v.overflow = overflow;
     HIP_TRY(hipMalloc(&v.hash_keys, hcap * 8));
     HIP_TRY(hipMalloc(&v.live_bits, hcap / 8));
     HIP_TRY(hipMalloc(&v.brick_sum, hcap * 256));   // a brick lives at its hash slot (map_kernels.hpp)
@@ -184,7 +211,7 @@ chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream) {
 
 // Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  Fully asynchronous.
 chad_status clear_active(chad_map* m, bool clear_overflow = false) {
-    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_hdr, clear_overflow ? 1u : 0u);
+    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, clear_overflow ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
 }
@@ -284,9 +311,9 @@ chad_status grow_if_needed(chad_map* m) {
     if (live < m->brick_capacity / 2) return CHAD_OK;
     MapView bigger;
     const uint64_t blocks = std::min<uint64_t>(uint64_t(m->brick_capacity) * 2, 1ull << 30);
-    const chad_status s = alloc_map_storage(bigger, blocks, m->stream);
+    const chad_status s = alloc_map_storage(bigger, blocks, m->stream, m->d_overflow);
     if (s != CHAD_OK) { free_map_storage(bigger); m->fixed_capacity = true; g_error.clear(); return CHAD_OK; }  // keep going at the old size
-    if (live) hipLaunchKernelGGL(k_rehash_bricks, dim3(512), dim3(256), 0, m->stream, m->view, bigger, m->d_hdr);
+    if (live) hipLaunchKernelGGL(k_rehash_bricks, dim3(512), dim3(256), 0, m->stream, m->view, bigger);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     free_map_storage(m->view);
@@ -296,9 +323,9 @@ chad_status grow_if_needed(chad_map* m) {
     return CHAD_OK;
 }
 
-void record(chad_map* m, Stage s) {
+void record(chad_map* m, Stage s, hipStream_t stream) {
     if (times_stages(m) || ((m->flags & CHAD_FLAG_TIME_UPDATE) && (s == T_NORM || s == T_UPD)))
-        (void)hipEventRecord(m->ev[m->timed_end % chad_map::kTimingRing][s], m->stream);
+        (void)hipEventRecord(m->ev[m->timed_end % chad_map::kTimingRing][s], stream);
 }
 
 // mean stage times over the inserts whose event sets have not been read yet (the stream must be idle)
@@ -323,8 +350,24 @@ void collect_timing(chad_map* m) {
     m->timed_begin = m->timed_end;
 }
 
+// The slot of the next insert, with room for n points and its buffers free: its stream waits until the update of the
+// frame that used the slot before (n_slots inserts ago) has finished with them.
+chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
+    const uint32_t turn = uint32_t(m->frames % m->n_slots);
+    FrameSlot& f = m->slot[turn];
+    TRY(ensure_frame_capacity(m, f, n));
+    if (f.used) HIP_TRY(hipStreamWaitEvent(f.prep, f.update_done, 0));
+    if (m->caller_ready) {  // caller-supplied stream: the caller's work enqueued so far (it may produce the points) comes first
+        HIP_TRY(hipEventRecord(m->caller_ready, m->stream));
+        HIP_TRY(hipStreamWaitEvent(f.prep, m->caller_ready, 0));
+    }
+    m->last_slot = turn;
+    *out = &f;
+    return CHAD_OK;
+}
+
 // tsdf.cpp:39-75 with the points already on the device
-chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float position[3]) {
+chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t n, const float position[3]) {
     if (n >= (1ull << 30)) return fail(CHAD_ERR_INVALID_ARG, "more than 2^30 points in one frame");
     // submap bookkeeping, tsdf.cpp:46-61 (f32 distance in the reference's operation order; this file is built
     // with -ffp-contract=off)
@@ -343,35 +386,44 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
     TRY(grow_if_needed(m));
     const F3 pos{position[0], position[1], position[2]};
     const uint32_t count = uint32_t(n);
-    record(m, T_BEGIN);
-    if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, m->stream, m->d_hdr);
+    // preparation on the slot's own stream (it has already waited for the slot's previous update: prepare_slot) ...
+    hipStream_t prep = f.prep;
+    record(m, T_BEGIN, prep);
+    uint4* item_start = reinterpret_cast<uint4*>(f.d_seg + 2 * f.cap_points);
+    if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, prep, f.d_hdr);
     if (count) {
-        uint4* item_start = reinterpret_cast<uint4*>(m->d_seg + 2 * m->cap_points);
-        hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_part);
-        hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, count, pos, m->recip, m->d_hdr, m->d_part, m->sort.keys[0],
-                           m->sort.hist_part, m->sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
-        record(m, T_CALC);
-        radix_sort_enqueue(m->sort, count, kMaxPasses, &m->d_hdr->sort_passes, m->stream, kFrameBlocks);
-        hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, m->stream, d_xyz, m->recip, m->d_hdr, m->d_part, m->sort.keys[0], m->sort.keys[1],
-                           m->sort.idx[0], m->sort.idx[1], m->d_pts, m->d_codes, m->d_seg, item_start);
-        record(m, T_SORT);
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * 24), dim3(64 * kNormalWavesPerBlock), 0, m->stream, m->d_pts, m->d_codes, m->d_seg, m->d_seg + m->cap_points, m->d_hdr, pos, m->d_normals, m->ablate);
-        if (times_stages(m)) record(m, T_NORM);
+        hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part);
+        hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
+                           f.sort.hist_part, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
+        record(m, T_CALC, prep);
+        radix_sort_enqueue(f.sort, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks);
+        hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
+                           f.sort.idx[0], f.sort.idx[1], f.d_pts, f.d_codes, f.d_seg, item_start);
+        record(m, T_SORT, prep);
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * 24), dim3(64 * kNormalWavesPerBlock), 0, prep, f.d_pts, f.d_codes, f.d_seg, f.d_seg + f.cap_points, f.d_hdr, pos, f.d_normals, m->ablate);
+        if (times_stages(m)) record(m, T_NORM, prep);
+    } else {
+        record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
+    }
+    HIP_TRY(hipEventRecord(f.prep_done, prep));
+    // ... the update on the map's stream, behind whatever the caller has done to the map before this insert
+    HIP_TRY(hipStreamWaitEvent(m->stream, f.prep_done, 0));
+    if (count) {
         // CHAD_UPDATE_AUTO enqueues both forms; each looks at the frame's points-per-block ratio (device memory)
         // and exactly one of them does the work
         const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
-        if (!times_stages(m) && m->update_mode == CHAD_UPDATE_SCATTER) record(m, T_NORM);
+        if (!times_stages(m) && m->update_mode == CHAD_UPDATE_SCATTER) record(m, T_NORM, m->stream);
         if (m->update_mode != CHAD_UPDATE_TILED)
-            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, m->d_pts, m->d_normals, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
+            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, f.d_pts, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
         // CHAD_FLAG_TIME_UPDATE brackets the dominant kernel alone: in auto mode the scatter launch (which returns at
         // once for a dense frame) stays outside the bracket
-        if (!times_stages(m) && m->update_mode != CHAD_UPDATE_SCATTER) record(m, T_NORM);
+        if (!times_stages(m) && m->update_mode != CHAD_UPDATE_SCATTER) record(m, T_NORM, m->stream);
         if (m->update_mode != CHAD_UPDATE_SCATTER)
-            tile_update_enqueue(m->d_pts, m->d_normals, item_start, m->d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->d_stamps);
-        record(m, T_UPD);
-    } else {
-        record(m, T_CALC); record(m, T_SORT); record(m, T_NORM); record(m, T_UPD);
-    }
+            tile_update_enqueue(f.d_pts, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->d_stamps);
+    } else if (!times_stages(m)) record(m, T_NORM, m->stream);
+    record(m, T_UPD, m->stream);
+    HIP_TRY(hipEventRecord(f.update_done, m->stream));
+    f.used = true;
     HIP_TRY(hipGetLastError());
     m->frames++;
     m->last_points_in = n;
@@ -379,7 +431,7 @@ chad_status insert_device(chad_map* m, const float* d_xyz, size_t n, const float
         m->timed_end++;
         if (m->timed_end - m->timed_begin > chad_map::kTimingRing) m->timed_begin = m->timed_end - chad_map::kTimingRing;
         if (m->flags & CHAD_FLAG_VERBOSE) {  // the reference prints its five stage lines on every insert
-            HIP_TRY(hipStreamSynchronize(m->stream));
+            TRY(join_streams(m));
             collect_timing(m);
             std::printf("mc  calc %.2f\nmc  sort %.2f\nnorm est %.2f\noct  upd %.2f\ntotal    %.2f\n", m->ms[T_CALC], m->ms[T_SORT], m->ms[T_NORM], m->ms[T_UPD], m->ms[T_BEGIN]);
         }
@@ -428,23 +480,46 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
     if (o.stream) m->stream = hipStream_t(o.stream);
-    else { CREATE_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    else {  // the update is what the map waits for: its stream gets the highest priority, the preparation streams the lowest
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        CREATE_TRY(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, greatest));
+        m->own_stream = true;
+    }
+    if (const char* e = std::getenv("CHAD_SLOTS")) m->n_slots = std::min<uint32_t>(chad_map::kMaxSlots, std::max(1, std::atoi(e)));
+    m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr;
 
     uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
     if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
-    if (alloc_map_storage(m->view, blocks, m->stream) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
+    CREATE_TRY(hipMalloc(&m->d_overflow, 64));
+    CREATE_TRY(hipMemsetAsync(m->d_overflow, 0, 64, m->stream));
+    if (alloc_map_storage(m->view, blocks, m->stream, m->d_overflow) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     m->brick_capacity = m->view.brick_capacity; m->hash_capacity = m->view.hash_mask + 1;
-    CREATE_TRY(hipMalloc(&m->d_hdr, sizeof(FrameHeader)));
+    for (uint32_t k = 0; k < m->n_slots; k++) {
+        FrameSlot& f = m->slot[k];
+        if (m->serial) f.prep = m->stream;
+        else {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            CREATE_TRY(hipStreamCreateWithPriority(&f.prep, hipStreamNonBlocking, least));
+        }
+        CREATE_TRY(hipEventCreateWithFlags(&f.prep_done, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&f.update_done, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&f.stage_done, hipEventDisableTiming));
+        CREATE_TRY(hipMalloc(&f.d_hdr, sizeof(FrameHeader)));
+        CREATE_TRY(hipMemsetAsync(f.d_hdr, 0, sizeof(FrameHeader), m->stream));
+        CREATE_TRY(hipMalloc(&f.d_part, sizeof(FramePartial) * kFrameBlocks));
+    }
+    if (!m->own_stream) CREATE_TRY(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
     CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
     *m->h_live_blocks = 0;
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
-    CREATE_TRY(hipMalloc(&m->d_part, sizeof(FramePartial) * kFrameBlocks));
     CREATE_TRY(hipMalloc(&m->d_cursor, 4));
-    CREATE_TRY(hipMemsetAsync(m->d_hdr, 0, sizeof(FrameHeader), m->stream));
     if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
-    if (ensure_frame_capacity(m, o.max_points ? o.max_points : (1u << 20)) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
+    for (uint32_t k = 0; k < m->n_slots; k++)
+        if (ensure_frame_capacity(m, m->slot[k], o.max_points ? o.max_points : (1u << 20)) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     CREATE_TRY(hipStreamSynchronize(m->stream));
 #undef CREATE_TRY
     *out = m;
@@ -454,6 +529,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
 void chad_map_destroy(chad_map* m) {
     if (!m) return;
     DeviceGuard guard(m->device);
+    for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->d_stamps) {  // diagnostic: mean cycles per phase over the waves of the last update launch
         std::vector<unsigned long long> st(8192 * 8);
@@ -473,15 +549,22 @@ void chad_map_destroy(chad_map* m) {
         }
         (void)hipFree(m->d_stamps);
     }
-    free_frame_buffers(m);
+    for (auto& f : m->slot) {
+        free_frame_buffers(f);
+        (void)hipFree(f.d_hdr); (void)hipFree(f.d_part);
+        if (f.prep_done) (void)hipEventDestroy(f.prep_done);
+        if (f.update_done) (void)hipEventDestroy(f.update_done);
+        if (f.stage_done) (void)hipEventDestroy(f.stage_done);
+        if (f.prep && f.prep != m->stream) (void)hipStreamDestroy(f.prep);
+    }
+    if (m->caller_ready) (void)hipEventDestroy(m->caller_ready);
     for (auto& s : m->closed) free_submap(s);
     free_submap(m->active_copy);
     free_map_storage(m->view);
-    (void)hipFree(m->d_hdr); (void)hipFree(m->d_part); (void)hipFree(m->d_cursor);
+    (void)hipFree(m->d_overflow); (void)hipFree(m->d_cursor);
     if (m->h_live_blocks) (void)hipHostFree(const_cast<uint32_t*>(m->h_live_blocks));
     if (m->h_hdr) (void)hipHostFree(m->h_hdr);
     for (auto& set : m->ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
-    for (auto& e : m->stage_done) if (e) (void)hipEventDestroy(e);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -489,41 +572,48 @@ void chad_map_destroy(chad_map* m) {
 chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t n, const float position[3]) {
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
-    TRY(ensure_frame_capacity(m, n));
-    return insert_device(m, xyz_device, n, position);
+    FrameSlot* f = nullptr;
+    TRY(prepare_slot(m, n, &f));
+    return insert_device(m, *f, xyz_device, n, position);
 }
 
 chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float position[3]) {
     if (!m || !position || (n && !xyz)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
-    TRY(ensure_frame_capacity(m, n));
+    FrameSlot* fp = nullptr;
+    TRY(prepare_slot(m, n, &fp));
+    FrameSlot& f = *fp;
     if (n) {
-        // The caller's buffer is borrowed for the duration of the call only: copy it into a pinned staging buffer
-        // (two of them, alternating, so the next frame can be staged while this one is still in flight) in chunks,
-        // each chunk's DMA overlapping the CPU copy of the next.  No device synchronisation: insert() returns as soon
-        // as the last chunk is staged, and the host copy of frame k+1 overlaps the kernels of frame k.
-        const uint32_t turn = m->stage_turn++ & 1u;
-        if (!m->h_stage[turn]) {
-            HIP_TRY(hipHostMalloc(&m->h_stage[turn], m->cap_points * 12, hipHostMallocDefault));
-            if (!m->stage_done[turn]) HIP_TRY(hipEventCreateWithFlags(&m->stage_done[turn], hipEventDisableTiming));
-        } else HIP_TRY(hipEventSynchronize(m->stage_done[turn]));  // its previous frame (two inserts ago) has left the buffer
+        // The caller's buffer is borrowed for the duration of the call only: copy it into the slot's pinned staging
+        // buffer in chunks, each chunk's DMA overlapping the CPU copy of the next.  No device synchronisation: insert()
+        // returns as soon as the last chunk is staged, and the host copy of frame k+1 overlaps the kernels of frame k.
+        if (!f.h_stage) HIP_TRY(hipHostMalloc(&f.h_stage, f.cap_points * 12, hipHostMallocDefault));
+        else HIP_TRY(hipEventSynchronize(f.stage_done));  // its previous frame (two inserts ago) has left the buffer
         const size_t chunk = size_t(1) << 18;  // points per chunk (3 MiB)
         for (size_t at = 0; at < n; at += chunk) {
             const size_t len = std::min(chunk, n - at);
-            std::memcpy(m->h_stage[turn] + 3 * at, xyz + 3 * at, len * 12);
-            HIP_TRY(hipMemcpyAsync(m->d_xyz + 3 * at, m->h_stage[turn] + 3 * at, len * 12, hipMemcpyHostToDevice, m->stream));
+            std::memcpy(f.h_stage + 3 * at, xyz + 3 * at, len * 12);
+            HIP_TRY(hipMemcpyAsync(f.d_xyz + 3 * at, f.h_stage + 3 * at, len * 12, hipMemcpyHostToDevice, f.prep));
         }
-        HIP_TRY(hipEventRecord(m->stage_done[turn], m->stream));
+        HIP_TRY(hipEventRecord(f.stage_done, f.prep));
     }
-    return insert_device(m, m->d_xyz, n, position);
+    return insert_device(m, f, f.d_xyz, n, position);
+}
+
+// the last insert's header (stage read-back, statistics) and the sticky overflow flag, after everything has finished
+chad_status read_back_header(chad_map* m, uint32_t* overflow) {
+    TRY(join_streams(m));
+    HIP_TRY(hipMemcpy(m->h_hdr, m->slot[m->last_slot].d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(overflow, m->d_overflow, 4, hipMemcpyDeviceToHost));
+    return CHAD_OK;
 }
 
 chad_status chad_map_sync(chad_map* m) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
-    HIP_TRY(hipMemcpyAsync(m->h_hdr, m->d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->h_hdr->overflow) return fail(CHAD_ERR_CAPACITY, "block capacity of the active submap exceeded; raise chad_options.max_blocks");
+    uint32_t overflow = 0;
+    TRY(read_back_header(m, &overflow));
+    if (overflow) return fail(CHAD_ERR_CAPACITY, "block capacity of the active submap exceeded; raise chad_options.max_blocks");
     return CHAD_OK;
 }
 
@@ -578,8 +668,8 @@ chad_status chad_map_export_leaves(chad_map* m, int32_t submap, uint64_t* mc, fl
 chad_status chad_map_stats(chad_map* m, chad_stats* out) {
     if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
-    HIP_TRY(hipMemcpyAsync(m->h_hdr, m->d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost, m->stream));
-    uint32_t blocks = 0;
+    uint32_t overflow = 0, blocks = 0;
+    TRY(read_back_header(m, &overflow));
     TRY(read_block_count(m, &blocks));
     collect_timing(m);
     std::memset(out, 0, sizeof(*out));
@@ -588,7 +678,7 @@ chad_status chad_map_stats(chad_map* m, chad_stats* out) {
     for (int k = 0; k < 32; k++) out->updates += m->h_hdr->n_updates[k * 16];
     out->blocks = blocks; out->block_capacity = m->brick_capacity;
     out->hash_capacity = m->hash_capacity; out->closed_submaps = m->closed.size();
-    out->sort_passes = m->h_hdr->sort_passes; out->overflow = m->h_hdr->overflow;
+    out->sort_passes = m->h_hdr->sort_passes; out->overflow = overflow;
     out->ms_mc_calc = m->ms[T_CALC]; out->ms_mc_sort = m->ms[T_SORT]; out->ms_norm_est = m->ms[T_NORM];
     out->ms_oct_upd = m->ms[T_UPD]; out->ms_total = m->ms[T_BEGIN];
     return CHAD_OK;
@@ -616,11 +706,13 @@ chad_status chad_map_export_blocks_device(chad_map* m, int32_t submap, uint64_t*
     if (nb > capacity_blocks) return fail(CHAD_ERR_INVALID_ARG, "capacity_blocks too small");
     if (!nb) return CHAD_OK;
     if (!keys_device || !sum_device || !cnt_device) return fail(CHAD_ERR_INVALID_ARG, "null output");
-    TRY(ensure_frame_capacity(m, nb));
+    TRY(join_streams(m));  // slot 0's sort buffers are borrowed below
+    FrameSlot& f = m->slot[0];
+    TRY(ensure_frame_capacity(m, f, nb));
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
-    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->sort.keys[0], nb);
-    radix_sort_enqueue(m->sort, nb, kMaxPasses, nullptr, m->stream);
-    hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->sort.idx[0], nb, keys, sum, cnt, keys_device, sum_device, cnt_device);
+    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, f.sort.keys[0], nb);
+    radix_sort_enqueue(f.sort, nb, kMaxPasses, nullptr, m->stream);
+    hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)f.sort.idx[0], nb, keys, sum, cnt, keys_device, sum_device, cnt_device);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHAD_OK;
@@ -647,20 +739,21 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
 chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, float* normals, size_t capacity, size_t* count) {
     if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
-    HIP_TRY(hipMemcpyAsync(m->h_hdr, m->d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    uint32_t overflow = 0;
+    TRY(read_back_header(m, &overflow));
+    const FrameSlot& f = m->slot[m->last_slot];
     const size_t n = m->frames ? m->h_hdr->n_usable : 0;
     *count = n;
     const size_t k = std::min(n, capacity);
     if (!k) return CHAD_OK;
     std::vector<float> tmp(k * 4);
     if (order) {
-        HIP_TRY(hipMemcpy(tmp.data(), m->d_pts, k * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tmp.data(), f.d_pts, k * 16, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; i++) std::memcpy(&order[i], &tmp[4 * i + 3], 4);
     }
-    if (mc) HIP_TRY(hipMemcpy(mc, m->d_codes, k * 8, hipMemcpyDeviceToHost));
+    if (mc) HIP_TRY(hipMemcpy(mc, f.d_codes, k * 8, hipMemcpyDeviceToHost));
     if (normals) {
-        HIP_TRY(hipMemcpy(tmp.data(), m->d_normals, k * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tmp.data(), f.d_normals, k * 16, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; i++) std::memcpy(&normals[3 * i], &tmp[4 * i], 12);
     }
     return CHAD_OK;

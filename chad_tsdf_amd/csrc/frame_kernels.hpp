@@ -33,7 +33,7 @@ struct FrameHeader {
     uint32_t n_segments;        // point blocks (runs of equal code >> 6) found by k_frame_gather
     unsigned long long mc_min;  // smallest global Morton code of the frame ...
     uint32_t last_idx;          // ... and the largest input index among the points having it (normals.hpp:100)
-    uint32_t overflow;          // set when the block pool / hash could not take a new block
+    uint32_t reserved0;
     uint32_t n_items;           // update work items: point blocks cut at every kItemPoints-th point
     uint32_t item_cursor;       // work counter of the persistent update waves
     unsigned long long n_updates[32 * 16];  // voxel updates applied by the last insert, striped over 32 cache lines
@@ -53,17 +53,16 @@ struct FramePartial {
     unsigned long long mc_min;
 };
 
-// Per-frame reset of the header (everything except the sticky overflow flag).  Runs as its own kernel only for
+// Per-frame reset of the header.  Runs as its own kernel only for
 // empty frames; otherwise workgroup 0 of k_frame_keys does it (nothing before k_frame_gather reads the header).
 __device__ __forceinline__ void frame_header_reset(FrameHeader* h) {
-    const uint32_t keep_overflow = h->overflow;
     for (uint32_t k = threadIdx.x; k < 32 * 16; k += blockDim.x) h->n_updates[k] = 0;
     for (uint32_t k = threadIdx.x; k < kWorkGroups * 16; k += blockDim.x) h->work_cursor[k] = 0;
     if (threadIdx.x == 0) {
         h->vmin[0] = h->vmin[1] = h->vmin[2] = 0x7fffffff;
         h->vmax[0] = h->vmax[1] = h->vmax[2] = int(0x80000000);
         h->n_usable = 0; h->axis_bits = 0; h->sort_passes = 0; h->n_segments = 0;
-        h->mc_min = ~0ull; h->last_idx = 0; h->overflow = keep_overflow; h->n_items = 0; h->item_cursor = 0;
+        h->mc_min = ~0ull; h->last_idx = 0; h->reserved0 = 0; h->n_items = 0; h->item_cursor = 0;
     }
 }
 __global__ void k_frame_init(FrameHeader* h) { frame_header_reset(h); }
@@ -201,13 +200,18 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
         for (uint32_t k = 0; k < 32; k++) live += live_blocks[k * 16];
         *live_blocks_host = live;
     }
-    // clear the radix sort's look-back table for this frame (saves a memset launch)
-    for (size_t k = size_t(blockIdx.x) * blockDim.x + threadIdx.x; k < status_words; k += size_t(gridDim.x) * blockDim.x) tile_status[k] = 0u;
     const LocalFrame f = combine_bounds(part);
     __shared__ unsigned long long wave_mc[4];
     // digit histograms of all radix passes, taken while the key is in a register (radix_sort.hpp)
     __shared__ uint32_t hist[kMaxPasses][kRadix];
     const uint32_t passes = (f.bits + (f.kept < n ? 1u : 0u) + kRadixBits - 1) / kRadixBits;
+    // clear the radix sort's look-back table for this frame (saves a memset launch): the words of the passes that will run
+    // (layout [pass][tile][digit], radix_sort.hpp) and the ticket words behind the table
+    {
+        const size_t per_pass = (status_words - 64) / kMaxPasses, used = per_pass * passes;
+        for (size_t k = size_t(blockIdx.x) * blockDim.x + threadIdx.x; k < used; k += size_t(gridDim.x) * blockDim.x) tile_status[k] = 0u;
+        if (blockIdx.x == 0 && threadIdx.x < 64) tile_status[status_words - 64 + threadIdx.x] = 0u;
+    }
     for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += blockDim.x) (&hist[0][0])[k] = 0;
     __syncthreads();
     const uint64_t top = 1ull << f.bits;
@@ -288,21 +292,45 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
         if (threadIdx.x == 0) n_heads = 0;
         if (threadIdx.x < kGatherChunk / 32) mark_bits[threadIdx.x] = 0u;
         __syncthreads();
+        // Three batches of independent loads (the compiler keeps a batch in flight together) instead of eight dependent
+        // index -> point chains per thread: the kernel is bound by the latency of the scattered point reads.
+        constexpr uint32_t kPer = kGatherChunk / 256;
+        uint32_t heads_mask = 0, supers_mask = 0, src[kPer];
+        {
+            uint64_t kcur[kPer], kprev[kPer];
 #pragma unroll
-        for (uint32_t j = 0; j < kGatherChunk / 256; j++) {
+            for (uint32_t j = 0; j < kPer; j++) {
+                const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
+                kcur[j] = i < n ? keys[i] : 0ull;
+                kprev[j] = i < n && i ? keys[i - 1] : ~0ull;   // nothing precedes point 0: it opens a block
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) {
+                const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
+                src[j] = i < n ? idx[i] : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) {
+                heads_mask |= ((kcur[j] >> 6) != (kprev[j] >> 6) ? 1u : 0u) << j;
+                supers_mask |= ((kcur[j] >> 9) != (kprev[j] >> 9) ? 1u : 0u) << j;
+            }
+        }
+        F3 point[kPer];
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) point[j] = load_point(xyz, src[j]);
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
             const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
             if (i < n) {
-                const uint32_t src = idx[i];
-                const F3 p = load_point(xyz, src);
+                const F3 p = point[j];
                 const I3 v = voxel_of(p, recip);
                 const uint64_t mc = morton_encode(v.x, v.y, v.z);
-                pts[i] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
+                pts[i] = make_float4(p.x, p.y, p.z, __uint_as_float(src[j]));
                 codes[i] = mc;
-                const bool head = i == 0 || (keys[i] >> 6) != (keys[i - 1] >> 6);
+                const bool head = (heads_mask >> j) & 1u, super_head = (supers_mask >> j) & 1u;
                 if (head) heads[atomicAdd(&n_heads, 1u)] = i;
-                const bool super_head = i == 0 || (keys[i] >> 9) != (keys[i - 1] >> 9);
                 if (super_head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
-                if (mc == mc_min) atomicMax(&h->last_idx, src);
+                if (mc == mc_min) atomicMax(&h->last_idx, src[j]);
             }
         }
         __syncthreads();

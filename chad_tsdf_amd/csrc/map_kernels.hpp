@@ -38,6 +38,7 @@ struct MapView {
     uint32_t* brick_cnt;
     uint32_t* live_bits;
     uint32_t* brick_count;   // striped device counter of live bricks
+    uint32_t* overflow;      // sticky: set when a block found no slot (its updates are dropped)
     uint32_t hash_mask;      // H - 1 (H a power of two)
     uint32_t brick_capacity; // nominal capacity (H / 2 or less): the pools grow once half of it is in use
 };
@@ -55,7 +56,7 @@ __device__ __forceinline__ uint32_t live_brick_count(const MapView& m) {
 // Slot (= brick index) of `key`, claiming an empty slot if the block is new.  One CAS per probe; a claim also sets
 // the slot's live bit and bumps a counter stripe, both without waiting for a result.  Returns kNoBrick when no
 // slot is found within kMaxProbes.
-__device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint64_t key, FrameHeader* h, uint32_t slot) {
+__device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint64_t key, uint32_t slot) {
     for (uint32_t probes = 0; probes < kMaxProbes; probes++) {
         const uint64_t prev = atomicCAS((unsigned long long*)&m.hash_keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
         if (prev == key) return slot;
@@ -66,11 +67,11 @@ __device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint6
         }
         slot = (slot + 1) & m.hash_mask;
     }
-    atomicOr(&h->overflow, 1u);
+    atomicOr(m.overflow, 1u);
     return kNoBrick;
 }
-__device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint64_t key, FrameHeader* h) {
-    return find_or_create_brick(m, key, h, hash_block(key, m.hash_mask));
+__device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint64_t key) {
+    return find_or_create_brick(m, key, hash_block(key, m.hash_mask));
 }
 
 // ---- update, general form: one lane per point, global atomics per observation (octree.hpp:86-164) -----------
@@ -90,7 +91,7 @@ k_update_scatter(const float4* __restrict__ pts, const float4* __restrict__ norm
         do {
             const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
             const uint64_t key = mc & kBlockMask;
-            if (key != cached_key) { brick = find_or_create_brick(m, key, h); cached_key = key; }
+            if (key != cached_key) { brick = find_or_create_brick(m, key); cached_key = key; }
             if (brick != kNoBrick) {
                 const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
                 atomicAdd(&m.brick_sum[at], observe(w.cur, p, nrm, res, trunc));
@@ -205,7 +206,7 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
 // Octree::clear() (octree.hpp:22-29) in O(H/32 + bricks) and without a host round trip: every live brick's key is
 // released and its two 256-byte rows are zeroed; then the bitmap words and the counter stripes.
 __global__ void __launch_bounds__(256)
-k_clear_bricks(MapView m, FrameHeader* h, uint32_t clear_overflow) {
+k_clear_bricks(MapView m, uint32_t clear_overflow) {
     const uint32_t lane = threadIdx.x & 63;
     for_each_live_brick(m, [&](uint32_t slot) {
         if (lane == 0) m.hash_keys[slot] = kEmptyKey;
@@ -219,16 +220,16 @@ k_clear_bricks(MapView m, FrameHeader* h, uint32_t clear_overflow) {
     for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u)
         if (w0 + lane < words && m.live_bits[w0 + lane]) m.live_bits[w0 + lane] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < kCountStripes) m.brick_count[threadIdx.x * 16] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && clear_overflow) h->overflow = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clear_overflow) *m.overflow = 0u;
 }
 
 // Move the bricks of a map into a larger, empty one (capacity growth between frames).
 __global__ void __launch_bounds__(256)
-k_rehash_bricks(MapView from, MapView to, FrameHeader* __restrict__ h) {
+k_rehash_bricks(MapView from, MapView to) {
     const uint32_t lane = threadIdx.x & 63;
     for_each_live_brick(from, [&](uint32_t slot) {
         uint32_t dst = 0;
-        if (lane == 0) dst = find_or_create_brick(to, from.hash_keys[slot], h);
+        if (lane == 0) dst = find_or_create_brick(to, from.hash_keys[slot]);
         dst = uint32_t(__builtin_amdgcn_readfirstlane(int(dst)));
         if (dst == kNoBrick) return;
         to.brick_sum[size_t(dst) * 64 + lane] = from.brick_sum[size_t(slot) * 64 + lane];

@@ -197,7 +197,7 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
                     do {
                         const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
                         const uint64_t key = mc & kBlockMask;
-                        if (key != far_key) { far_brick = find_or_create_brick(m, key, h); far_key = key; }
+                        if (key != far_key) { far_brick = find_or_create_brick(m, key); far_key = key; }
                         if (far_brick != kNoBrick) {
                             const size_t at = size_t(far_brick) * 64 + (uint32_t(mc) & 63u);
                             atomicAdd(&m.brick_sum[at], observe(w.cur, p, nrm, res, trunc));
@@ -247,7 +247,7 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
             if (seen == kEmptyKey) {  // claimed (map_kernels.hpp, find_or_create_brick)
                 atomicOr(&m.live_bits[this_slot >> 5], 1u << (this_slot & 31u));
                 atomicAdd(&m.brick_count[(this_slot & (kCountStripes - 1)) * 16], 1u);
-            } else my_brick = find_or_create_brick(m, this_key, h, (this_slot + 1u) & m.hash_mask);  // the home slot holds another block
+            } else my_brick = find_or_create_brick(m, this_key, (this_slot + 1u) & m.hash_mask);  // the home slot holds another block
         }
         // the prefetched loads are older than the flush's atomics: wait for them here, where they have long arrived,
         // and not at their first use, where the in-order counter would make that wait cover the atomics as well

@@ -56,7 +56,8 @@ class TSDFMap:
                 t = t.to(torch.float32).contiguous()
             n = t.numel() // 3
             _lib.check(self._lib.chad_map_insert_device(self._h, t.data_ptr(), n, pos.ctypes.data), "TSDFMap.insert")
-            self._keepalive = t  # the device buffer must outlive the enqueued kernels
+            # the device buffer must outlive the kernels that read it: two frames are in flight at a time
+            self._keepalive = (getattr(self, "_keepalive", (None, None))[1], t)
         else:
             pts = _np_f32(points)
             _lib.check(self._lib.chad_map_insert(self._h, pts.ctypes.data, pts.shape[0], pos.ctypes.data), "TSDFMap.insert")
