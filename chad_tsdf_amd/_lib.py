@@ -71,6 +71,7 @@ SYMBOLS = {
     "chad_map_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "chad_map_block_count": (_i32, [_vp, _i32, C.POINTER(_sz)]),
     "chad_map_export_blocks_device": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
+    "chad_map_export_blocks_device_unordered": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
     "chad_map_close_submap_with_blocks_device": (_i32, [_vp, _vp, _vp, _vp, _sz]),
     "chad_map_last_frame": (_i32, [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_walk_rays": (_i32, [_vp, _sz, _vp, _f32, _f32, _vp, _vp, _sz]),

@@ -697,7 +697,7 @@ chad_status chad_map_block_count(chad_map* m, int32_t submap, size_t* blocks) {
     return CHAD_OK;
 }
 
-chad_status chad_map_export_blocks_device(chad_map* m, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks) {
+static chad_status export_blocks(chad_map* m, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks, bool sorted) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
     uint32_t nb = 0;
@@ -706,6 +706,13 @@ chad_status chad_map_export_blocks_device(chad_map* m, int32_t submap, uint64_t*
     if (nb > capacity_blocks) return fail(CHAD_ERR_INVALID_ARG, "capacity_blocks too small");
     if (!nb) return CHAD_OK;
     if (!keys_device || !sum_device || !cnt_device) return fail(CHAD_ERR_INVALID_ARG, "null output");
+    if (!sorted) {
+        HIP_TRY(hipMemcpyAsync(keys_device, keys, size_t(nb) * 8, hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(sum_device, sum, size_t(nb) * 256, hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(cnt_device, cnt, size_t(nb) * 256, hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return CHAD_OK;
+    }
     TRY(join_streams(m));  // slot 0's sort buffers are borrowed below
     FrameSlot& f = m->slot[0];
     TRY(ensure_frame_capacity(m, f, nb));
@@ -716,6 +723,14 @@ chad_status chad_map_export_blocks_device(chad_map* m, int32_t submap, uint64_t*
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHAD_OK;
+}
+
+chad_status chad_map_export_blocks_device(chad_map* m, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks) {
+    return export_blocks(m, submap, keys_device, sum_device, cnt_device, capacity_blocks, true);
+}
+
+chad_status chad_map_export_blocks_device_unordered(chad_map* m, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks) {
+    return export_blocks(m, submap, keys_device, sum_device, cnt_device, capacity_blocks, false);
 }
 
 chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t* keys_device, const float* sum_device, const uint32_t* cnt_device, size_t blocks) {

@@ -25,7 +25,7 @@ SUBMAP_DISTANCE = np.float32(5.0)  # tsdf.cpp:52
 
 
 def merge_blocks(keys: torch.Tensor, sums: torch.Tensor, cnts: torch.Tensor, group=None):
-    """Combine per-rank partial bricks.  keys int64 [B] sorted ascending, sums f32 [B,64], cnts i32 [B,64].
+    """Combine per-rank partial bricks.  keys int64 [B] (distinct, in any order), sums f32 [B,64], cnts i32 [B,64].
 
     Returns (union keys [U], summed sums [U,64], summed counts [U,64]), identical on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -102,7 +102,10 @@ class ShardedTSDFMap:
 
     def merge_and_close(self):
         """The exchange step: merge the active submap across ranks and archive it on every rank."""
-        keys, sums, cnts = self.local.export_blocks(-1)
+        try:
+            keys, sums, cnts = self.local.export_blocks(-1, ordered=False)   # the merge orders the union of all ranks' keys
+        except TypeError:  # a stand-in map without the option
+            keys, sums, cnts = self.local.export_blocks(-1)
         keys, sums, cnts = merge_blocks(keys, sums, cnts, self.group)
         self.local.close_submap_with_blocks(keys, sums, cnts)
         self._first_pose = None

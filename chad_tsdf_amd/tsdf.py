@@ -57,7 +57,7 @@ class TSDFMap:
             n = t.numel() // 3
             _lib.check(self._lib.chad_map_insert_device(self._h, t.data_ptr(), n, pos.ctypes.data), "TSDFMap.insert")
             # the device buffer must outlive the kernels that read it: two frames are in flight at a time
-            self._keepalive = (getattr(self, "_keepalive", (None, None))[1], t)
+            self._keepalive = (getattr(self, "_keepalive", (None, None, None)) + (t,))[-3:]
         else:
             pts = _np_f32(points)
             _lib.check(self._lib.chad_map_insert(self._h, pts.ctypes.data, pts.shape[0], pos.ctypes.data), "TSDFMap.insert")
@@ -123,8 +123,9 @@ class TSDFMap:
         _lib.check(self._lib.chad_map_block_count(self._h, submap, C.byref(n)), "TSDFMap.block_count")
         return n.value
 
-    def export_blocks(self, submap: int = -1):
-        """Per-block partial sums as torch CUDA tensors (keys int64 [B], sum f32 [B,64], cnt int32 [B,64]), sorted by key."""
+    def export_blocks(self, submap: int = -1, ordered: bool = True):
+        """Per-block partial sums as torch CUDA tensors (keys int64 [B], sum f32 [B,64], cnt int32 [B,64]), sorted by key
+        unless ordered=False (the multi-GPU merge sorts the union of all ranks' keys itself)."""
         import torch
 
         b = self.block_count(submap)
@@ -132,7 +133,8 @@ class TSDFMap:
         keys = torch.empty(b, dtype=torch.int64, device=dev)
         s = torch.empty((b, 64), dtype=torch.float32, device=dev)
         c = torch.empty((b, 64), dtype=torch.int32, device=dev)
-        _lib.check(self._lib.chad_map_export_blocks_device(self._h, submap, keys.data_ptr(), s.data_ptr(), c.data_ptr(), b), "TSDFMap.export_blocks")
+        call = self._lib.chad_map_export_blocks_device if ordered else self._lib.chad_map_export_blocks_device_unordered
+        _lib.check(call(self._h, submap, keys.data_ptr(), s.data_ptr(), c.data_ptr(), b), "TSDFMap.export_blocks")
         return keys, s, c
 
     def close_submap_with_blocks(self, keys, s, c):

@@ -84,7 +84,9 @@ void chad_map_destroy(chad_map* map);
 /* TSDFMap::insert(const float* points_p, size_t points_count, const float* position_p)  -- tsdf.hpp:50-57 -> tsdf.cpp:39-75.
  * xyz: points_count packed x,y,z triples in HOST memory, borrowed for the duration of the call. */
 chad_status chad_map_insert(chad_map* map, const float* xyz, size_t points_count, const float position[3]);
-/* Same, with the points already resident in DEVICE memory of the map's device (no PCIe copy). */
+/* Same, with the points already resident in DEVICE memory of the map's device (no PCIe copy).  The call returns when the
+ * work is enqueued (on internal streams: up to three frames are in flight): the buffer must stay valid and unchanged until
+ * three further inserts or a synchronisation point (chad_map_sync / export / stats) have returned. */
 chad_status chad_map_insert_device(chad_map* map, const float* xyz_device, size_t points_count, const float position[3]);
 
 /* Wait for all enqueued work of this map; reports CHAD_ERR_CAPACITY if any update was dropped. */
@@ -111,6 +113,8 @@ chad_status chad_map_stats(chad_map* map, chad_stats* out);
  * octree.hpp:161-163). */
 chad_status chad_map_block_count(chad_map* map, int32_t submap, size_t* blocks);
 chad_status chad_map_export_blocks_device(chad_map* map, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks);
+/* The same blocks in no particular order (skips the sort: the multi-GPU merge orders the union of all ranks' keys anyway). */
+chad_status chad_map_export_blocks_device_unordered(chad_map* map, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks);
 /* Close the active submap as if a roll-over happened, replacing its content by the given (merged) blocks. */
 chad_status chad_map_close_submap_with_blocks_device(chad_map* map, const uint64_t* keys_device, const float* sum_device, const uint32_t* cnt_device, size_t blocks);
 
