@@ -400,7 +400,8 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
                            f.sort.idx[0], f.sort.idx[1], f.d_pts, f.d_codes, f.d_seg, item_start);
         record(m, T_SORT, prep);
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * 24), dim3(64 * kNormalWavesPerBlock), 0, prep, f.d_pts, f.d_codes, f.d_seg, f.d_seg + f.cap_points, f.d_hdr, pos, f.d_normals, m->ablate);
+        static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, f.d_pts, f.d_codes, f.d_seg, f.d_seg + f.cap_points, f.d_hdr, pos, f.d_normals, m->ablate);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);

@@ -38,7 +38,7 @@ json.dump(per_kernel, open(os.path.join(prof, f"{tag}_pmc_per_kernel.json"), "w"
 durations = {}
 for r in csv.DictReader(open(stats)):
     durations[r["Name"].split("(")[0].replace("chadhip::", "").replace("void ", "")] = float(r["AverageNs"])
-upd = "k_update_tiled<false>"
+upd = [k for k in per_kernel if k.startswith("k_update_tiled<false")][0]
 u = per_kernel[upd]
 traffic = (2.0 * u["FETCH_SIZE"] + u["WRITE_SIZE"]) * 1024.0
 json.dump({
