@@ -96,6 +96,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    t_enqueued = time.perf_counter() - t0  # host side only: all steps are enqueued, the device is still working
     if world > 1:
         merged_keys, merged_sum, merged_cnt = merge_blocks(*m.export_blocks(-1, ordered=False))
     m.sync()
@@ -151,6 +152,7 @@ def main():
             "parallelism": f"frames round-robin over {world} GPU(s); one RCCL block-partial merge per timed region" if world > 1 else "1 GPU",
             "update_kernel": {0: "auto (tiled for this dense frame)", 1: "scatter", 2: "tiled"}[args.update_mode],
         },
+        "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
         "stage_ms": {k: round(float(stage[k]), 4) for k in ("ms_mc_calc", "ms_mc_sort", "ms_norm_est", "ms_oct_upd", "ms_total")},
         "frame": {"updates": int(st["updates"]), "voxels": n_voxels, "blocks": int(st["blocks"]), "sort_passes": int(st["sort_passes"]),
                   "hash_load": round(st["blocks"] / max(1, st["hash_capacity"]), 5)},

@@ -93,6 +93,7 @@ struct chad_map {
     FrameSlot slot[kMaxSlots];
     bool serial = false;                // stage timing / verbose: the slots share the map's stream, so that stage times do not overlap
     uint32_t last_slot = 0;             // slot of the last insert
+    uint32_t sort_passes_forced = 0;    // CHAD_DEBUG_SORT_PASSES: single-pass sort launches per frame (tests of the guarded tail kernel)
     uint32_t flags = 0, update_mode = CHAD_UPDATE_AUTO;
     uint32_t ablate = 0;  // CHAD_DEBUG_ABLATE: timing experiments only
     unsigned long long* d_stamps = nullptr;  // CHAD_DEBUG_STAMPS: per-phase cycle stamps of the update kernel
@@ -176,7 +177,7 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     HIP_TRY(hipMalloc(&f.d_pts, cap * 16));
     HIP_TRY(hipMalloc(&f.d_codes, cap * 8));
     HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
-    HIP_TRY(hipMalloc(&f.d_seg, cap * 24));  // point-block starts u32 [cap], lengths u32 [cap], update work items uint4 [cap] (start, length, block key)
+    HIP_TRY(hipMalloc(&f.d_seg, cap * 24));  // point blocks uint2 [cap] (start, length | flag), update work items uint4 [cap] (start, length, super-block code)
     f.cap_points = cap;
     return CHAD_OK;
 }
@@ -396,12 +397,15 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
                            f.sort.hist_part, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
         record(m, T_CALC, prep);
-        radix_sort_enqueue(f.sort, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks);
+        // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
+        // rest -- normally none -- in one guarded launch (radix_sort.hpp, k_radix_tail)
+        const uint32_t hint = m->sort_passes_forced ? m->sort_passes_forced : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1])));
+        radix_sort_enqueue(f.sort, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint);
         hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                           f.sort.idx[0], f.sort.idx[1], f.d_pts, f.d_codes, f.d_seg, item_start);
+                           f.sort.idx[0], f.sort.idx[1], f.d_pts, f.d_codes, reinterpret_cast<uint2*>(f.d_seg), item_start);
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, f.d_pts, f.d_codes, f.d_seg, f.d_seg + f.cap_points, f.d_hdr, pos, f.d_normals, m->ablate);
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, f.d_pts, f.d_codes, reinterpret_cast<const uint2*>(f.d_seg), f.d_hdr, pos, f.d_normals, m->ablate);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -514,7 +518,9 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     if (!m->own_stream) CREATE_TRY(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
     CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
-    *m->h_live_blocks = 0;
+    m->h_live_blocks[0] = 0;
+    m->h_live_blocks[1] = kMaxPasses;  // sort pass hint: all passes as single launches until the first frame has reported
+    if (const char* e = std::getenv("CHAD_DEBUG_SORT_PASSES")) m->sort_passes_forced = uint32_t(std::atoi(e));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
     CREATE_TRY(hipMalloc(&m->d_cursor, 4));
     if (times_anything(m))

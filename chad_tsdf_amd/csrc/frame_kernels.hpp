@@ -246,6 +246,7 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             h->n_usable = f.kept;
             h->axis_bits = f.bits;
             h->sort_passes = passes;  // the extra top bit is only needed when some point is unusable
+            live_blocks_host[1] = passes;  // host-mapped hint: how many single-pass sort kernels the next frames should enqueue
         }
     }
 }
@@ -261,11 +262,11 @@ __global__ void __launch_bounds__(256)
 k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const uint32_t* __restrict__ idx0, const uint32_t* __restrict__ idx1,
-               float4* __restrict__ pts, uint64_t* codes, uint32_t* __restrict__ seg_start, uint4* __restrict__ items) {
-    __shared__ uint32_t heads[kGatherChunk];
-    __shared__ uint32_t mark_bits[kGatherChunk / 32];  // bit k: point k of the chunk starts a work item
-    __shared__ uint32_t word_rank[kGatherChunk / 32], word_next[kGatherChunk / 32];
-    __shared__ uint32_t n_heads, base_heads, base_marks;
+               float4* __restrict__ pts, uint64_t* codes, uint2* __restrict__ segments, uint4* __restrict__ items) {
+    constexpr uint32_t kWords = kGatherChunk / 32;
+    __shared__ uint32_t mark_bits[kWords], head_bits[kWords];  // bit k: point k of the chunk starts a work item / a point block
+    __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
+    __shared__ uint32_t base_heads, base_marks;
     __shared__ unsigned long long wave_mc[4], block_mc_min;
     // frame-wide smallest code from the keys kernel's partials
     {
@@ -289,8 +290,7 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
     const uint32_t* idx = odd ? idx1 : idx0;
     const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        if (threadIdx.x == 0) n_heads = 0;
-        if (threadIdx.x < kGatherChunk / 32) mark_bits[threadIdx.x] = 0u;
+        if (threadIdx.x < kWords) { mark_bits[threadIdx.x] = 0u; head_bits[threadIdx.x] = 0u; }
         __syncthreads();
         // Three batches of independent loads (the compiler keeps a batch in flight together) instead of eight dependent
         // index -> point chains per thread: the kernel is bound by the latency of the scattered point reads.
@@ -328,7 +328,7 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
                 pts[i] = make_float4(p.x, p.y, p.z, __uint_as_float(src[j]));
                 codes[i] = mc;
                 const bool head = (heads_mask >> j) & 1u, super_head = (supers_mask >> j) & 1u;
-                if (head) heads[atomicAdd(&n_heads, 1u)] = i;
+                if (head) atomicOr(&head_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (super_head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (mc == mc_min) atomicMax(&h->last_idx, src[j]);
             }
@@ -337,25 +337,41 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
         // work items: every mark opens an item that runs to the next mark, or to the end of the chunk (chunks start at a
         // multiple of kItemPoints, i.e. at a mark, so items never span chunks)
         const uint32_t chunk_len = min(uint32_t(kGatherChunk), n - c * kGatherChunk);
-        if (threadIdx.x == 0) {
+        // rank of every mark among the chunk's marks and position of the next one: thread 0 for the items, thread 64 (another
+        // wave) for the point blocks
+        if (threadIdx.x == 0 || threadIdx.x == 64) {
+            const uint32_t which = threadIdx.x ? 1u : 0u;
+            const uint32_t* bits = which ? head_bits : mark_bits;
             uint32_t run = 0;
-            for (uint32_t w = 0; w < kGatherChunk / 32; w++) { word_rank[w] = run; run += __popc(mark_bits[w]); }
+            for (uint32_t w = 0; w < kWords; w++) { word_rank[which][w] = run; run += __popc(bits[w]); }
             uint32_t later = chunk_len;  // position of the first mark in a later word
-            for (int w = kGatherChunk / 32 - 1; w >= 0; w--) { word_next[w] = later; if (mark_bits[w]) later = uint32_t(w) * 32u + uint32_t(__ffs(int(mark_bits[w])) - 1); }
-            base_heads = n_heads ? atomicAdd(&h->n_segments, n_heads) : 0u;
-            base_marks = run ? atomicAdd(&h->n_items, run) : 0u;
+            for (int w = int(kWords) - 1; w >= 0; w--) { word_next[which][w] = later; if (bits[w]) later = uint32_t(w) * 32u + uint32_t(__ffs(int(bits[w])) - 1); }
+            if (which) base_heads = run ? atomicAdd(&h->n_segments, run) : 0u;
+            else base_marks = run ? atomicAdd(&h->n_items, run) : 0u;
         }
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n_heads; k += 256) seg_start[base_heads + k] = heads[k];
 #pragma unroll
         for (uint32_t j = 0; j < kGatherChunk / 256; j++) {
-            const uint32_t k = j * 256 + threadIdx.x, word = mark_bits[k >> 5], bit = k & 31u;
-            if (k < chunk_len && ((word >> bit) & 1u)) {
-                const uint32_t rank = word_rank[k >> 5] + __popc(word & ((1u << bit) - 1u));
+            const uint32_t k = j * 256 + threadIdx.x, bit = k & 31u;
+            if (k >= chunk_len) continue;
+            const uint32_t word = mark_bits[k >> 5], hword = head_bits[k >> 5];
+            if (!(((word | hword) >> bit) & 1u)) continue;
+            const uint64_t code = codes[c * kGatherChunk + k];  // written by this very thread above
+            if ((word >> bit) & 1u) {
+                const uint32_t rank = word_rank[0][k >> 5] + __popc(word & ((1u << bit) - 1u));
                 const uint32_t higher = bit == 31u ? 0u : word >> (bit + 1u);
-                const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[k >> 5];
-                const uint64_t block_key = codes[c * kGatherChunk + k] & ~511ull;  // corner of the 8x8x8 super block; codes[] written by this very thread above
-                items[base_marks + rank] = make_uint4(c * kGatherChunk + k, min(next, chunk_len) - k, uint32_t(block_key), uint32_t(block_key >> 32));
+                const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[0][k >> 5];
+                const uint64_t corner = code & ~511ull;  // corner of the 8x8x8 super block
+                items[base_marks + rank] = make_uint4(c * kGatherChunk + k, min(next, chunk_len) - k, uint32_t(corner), uint32_t(corner >> 32));
+            }
+            if ((hword >> bit) & 1u) {
+                // a point block: (start, length | "holds the frame's last point" << 31).  A block that runs to the end of the
+                // chunk may go on in the next one: length 0 = "find out" (k_frame_normals probes), unless the frame ends here
+                const uint32_t rank = word_rank[1][k >> 5] + __popc(hword & ((1u << bit) - 1u));
+                const uint32_t higher = bit == 31u ? 0u : hword >> (bit + 1u);
+                const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[1][k >> 5];
+                const uint32_t len = next < chunk_len ? next - k : (c == chunks - 1 ? chunk_len - k : 0u);
+                segments[base_heads + rank] = make_uint2(c * kGatherChunk + k, len | ((code >> 6) == (mc_min >> 6) ? 0x80000000u : 0u));
             }
         }
         __syncthreads();
@@ -492,20 +508,21 @@ constexpr int kNormalWavesPerBlock = 1;  // one wave per workgroup: __syncthread
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 
 __global__ void __launch_bounds__(64 * kNormalWavesPerBlock, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
-k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ seg_start,
-                uint32_t* __restrict__ seg_len, FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
+k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ codes, const uint2* __restrict__ segments,
+                FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
     __shared__ NormalScratch s;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = h->n_usable, nseg = h->n_segments;
-    const uint64_t last_block = h->mc_min >> 6;
 
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint32_t first = seg_start[seg];
-        const uint64_t block = codes[first] >> 6;
-        const uint32_t len = run_length(codes, first, n, block, lane);
-        if (lane == 0) seg_len[seg] = len;
+        // (start, length, flag) from k_frame_gather; only a block that runs across the end of a gather chunk (one in
+        // fourteen) still has to find its length by probing -- two dependent loads that every block used to pay
+        const uint2 record = segments[seg];
+        const uint32_t first = record.x;
+        uint32_t len = record.y & 0x7fffffffu;
+        if (len == 0u) len = run_length(codes, first, n, codes[first] >> 6, lane);
         // normals.hpp:100 -- the frame's last point never joins a neighbourhood; it is the last point of this segment
-        const bool holds_last = block == last_block;
+        const bool holds_last = (record.y >> 31) != 0u;
         const uint32_t grouped = holds_last ? len - 1 : len;
 
         // pass 1 over the block: voxel histogram in LDS, first kStagePoints points staged in LDS

@@ -106,13 +106,12 @@ k_radix_bases(const uint32_t* __restrict__ hist_part, uint32_t hist_blocks, uint
     digit_base[p * kRadix + d] = before + incl - count;
 }
 
-// idx_in may be null: the payload is then the element's own position (first pass).
-__global__ void __launch_bounds__(kSortThreads)
-k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
-                 uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
-                 uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
-                 uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit) {
-    if (pass_limit && pass >= *pass_limit) return;
+// One pass for the tile of this workgroup.  idx_in may be null: the payload is then the element's own position (first pass).
+__device__ __forceinline__ void
+radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                    uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
+                    uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket) {
     __shared__ uint32_t wave_count[kSortWaves][kRadix];  // per-wave digit counts, then the wave's base inside the tile
     __shared__ int offset[kRadix];                       // global slot of local sorted position s is offset[digit] + s
     __shared__ uint32_t wave_total[kSortWaves];
@@ -232,13 +231,54 @@ k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
     }
 }
 
+__global__ void __launch_bounds__(kSortThreads)
+k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                 uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                 uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
+                 uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit) {
+    if (pass_limit && pass >= *pass_limit) return;
+    radix_onesweep_tile(keys_in, idx_in, keys_out, idx_out, n, pass, tiles, digit_base, tile_status, tile_ticket);
+}
+
+// The passes from `first_pass` up to *pass_limit in ONE launch, separated by grid-wide barriers.  The host enqueues as
+// many single-pass kernels as the previous frames needed (a hint read from host-mapped memory) and then this kernel:
+// normally first_pass >= *pass_limit and it returns at once -- one cheap launch instead of five -- and when a frame
+// suddenly needs more passes than were enqueued (its extent has grown) the rest still runs, just slower.
+// Requires every workgroup of the grid to be resident at once (tiles <= kResidentTiles; the caller checks).
+__global__ void __launch_bounds__(kSortThreads)
+k_radix_tail(uint64_t* __restrict__ keys0, uint32_t* __restrict__ idx0, uint64_t* __restrict__ keys1, uint32_t* __restrict__ idx1,
+             uint32_t n, uint32_t first_pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
+             uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit) {
+    const uint32_t limit = min(uint32_t(kMaxPasses), *pass_limit);
+    uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
+    for (uint32_t pass = first_pass; pass < limit; pass++) {
+        const bool odd = pass & 1u;
+        radix_onesweep_tile(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? idx1 : idx0), odd ? keys0 : keys1, odd ? idx0 : idx1, n, pass, tiles, digit_base,
+                            tile_status, tile_ticket);
+        if (pass + 1 == limit) break;
+        // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicAdd(arrived, 1u);
+            const uint32_t target = gridDim.x * (pass - first_pass + 1u);
+            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+            __threadfence();
+        }
+        __syncthreads();
+    }
+}
+
 // Enqueue a sort of n pairs over key bits [0, 8*passes).  Input in keys[0] (idx[0] unused: the payload of the
 // first pass is the position); the result of pass p lands in buffer (p+1)&1, so with *pass_limit = L <= passes
 // active passes the sorted data is in buffer (L & 1).
 // hist_blocks == 0: the digit histograms are computed here (k_radix_histograms, which also clears the look-back
 // table); otherwise the caller's key-producing kernel has already written hist_blocks partial tables into
 // b.hist_part AND cleared b.tile_status (k_frame_keys does both while it still holds the keys in registers).
-inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0) {
+// launch_passes (0 = all `passes`): single-pass kernels to enqueue; the rest are covered by one k_radix_tail launch when
+// the grid is small enough to be resident at once, by single-pass kernels otherwise.
+inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
+                               uint32_t launch_passes = 0) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
     uint32_t* ticket = b.tile_status + size_t(kMaxPasses) * tiles * kRadix;
@@ -248,11 +288,16 @@ inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t p
                            uint32_t(radix_status_words(tiles)));
     }
     hipLaunchKernelGGL(k_radix_bases, dim3(passes), dim3(4 * kRadix), 0, stream, b.hist_part, hist_blocks, passes, pass_limit, b.digit_base);
-    for (uint32_t p = 0; p < passes; p++) {
+    const bool tail = pass_limit && launch_passes && launch_passes < passes && tiles <= kResidentTiles;
+    const uint32_t single = tail ? launch_passes : passes;
+    for (uint32_t p = 0; p < single; p++) {
         const int src = p & 1, dst = src ^ 1;
         hipLaunchKernelGGL(k_radix_onesweep, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[src], p == 0 ? nullptr : b.idx[src], b.keys[dst], b.idx[dst], n, p,
                            tiles, b.digit_base, b.tile_status, ticket, pass_limit);
     }
+    if (tail)
+        hipLaunchKernelGGL(k_radix_tail, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], b.idx[0], b.keys[1], b.idx[1], n, single, tiles, b.digit_base,
+                           b.tile_status, ticket, pass_limit);
 }
 
 }  // namespace chadhip

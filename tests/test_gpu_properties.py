@@ -16,6 +16,14 @@ def chad():
     return chad_tsdf_amd
 
 
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import pyoracle
+
+    pyoracle.lib()
+    return pyoracle
+
+
 def rel_err(a, b, trunc):
     return float((np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), trunc)).max())
 
@@ -141,4 +149,43 @@ def test_sparse_outdoor_frame_and_hash_occupancy(chad):
     assert st["blocks"] == len(np.unique(mc >> np.uint64(6)))
     assert st["blocks"] / st["hash_capacity"] <= 0.5
     assert 1_500_000 < len(mc) < 1_700_000
+    m.close()
+
+
+def test_cfg3_stream_back_to_back_matches_survey_pin(chad):
+    """cfg3 at full size, the way a stream is inserted: 100 frames of 200 k points enqueued back to back (three frames in
+    flight, no synchronisation in between), device-resident.  The accumulated submap must be the reference's (SURVEY.md
+    8(c) G7, reproduced by the oracle in test_oracle_survey_pins.py): V = 737 935 voxels, sum of weights 135 382 309."""
+    import torch
+
+    frames = [synth.cfg3_frame(k) for k in range(100)]
+    dev = [torch.from_numpy(p).cuda() for p, _ in frames]
+    m = chad.TSDFMap(0.05, 0.10)
+    for (_, pos), d in zip(frames, dev):
+        m.insert(d, pos)
+    m.sync()
+    mc, sd, w = m.export_leaves()
+    assert m.closed_submaps == 0
+    assert len(mc) == 737_935 and int(w.sum(dtype=np.uint64)) == 135_382_309
+    assert np.isfinite(sd).all() and np.abs(sd).max() <= 0.10 * (1 + 1e-5)  # a mean of values clamped to +-trunc, summed in f32
+    m.close()
+
+
+def test_sort_survives_a_frame_that_needs_more_passes_than_were_enqueued(chad, oracle):
+    """The number of single-pass sort launches follows the previous frames (a hint in host-mapped memory); a frame whose
+    extent suddenly needs more key bits is finished by the guarded tail kernel (radix_sort.hpp, k_radix_tail)."""
+    small = synth.cfg2_frame(30_000, seed=3)[0] * np.float32(0.05)      # a 0.5 m box: few key bits
+    pos = np.array([0.015, -0.01, 0.005], dtype=np.float32)
+    wide, pos2 = synth.cfg3_frame(0, 60_000)                             # a 30 m corridor: many more
+    m = chad.TSDFMap(0.05, 0.10)
+    o = oracle.OracleMap(0.05, 0.10)
+    for _ in range(3):
+        m.insert(small, pos); o.insert(small, pos)
+    few = m.stats()["sort_passes"]
+    m.insert(wide, pos2 * np.float32(0.0) + pos); o.insert(wide, pos2 * np.float32(0.0) + pos)
+    m.sync()
+    assert m.stats()["sort_passes"] > few
+    got, want = m.export_leaves(), o.export_leaves()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    assert rel_err(got[1], want[1], 0.10) <= SD_TOL
     m.close()
