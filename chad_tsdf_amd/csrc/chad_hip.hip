@@ -76,7 +76,6 @@ struct FrameSlot {
     float* h_stage = nullptr;           // pinned staging buffer for chad_map_insert (host points), cap_points * 12 bytes
     hipEvent_t stage_done = nullptr;    // the H2D copies out of h_stage have completed
     RadixSortBuffers sort{};
-    float4* d_pts = nullptr;
     uint64_t* d_codes = nullptr;
     float4* d_normals = nullptr;
     uint32_t* d_seg = nullptr;
@@ -147,8 +146,9 @@ void free_frame_buffers(FrameSlot& f) {
     (void)hipFree(f.d_xyz); (void)hipFree(f.sort.keys[0]); (void)hipFree(f.sort.keys[1]);
     (void)hipFree(f.sort.idx[0]); (void)hipFree(f.sort.idx[1]); (void)hipFree(f.sort.hist_part);
     (void)hipFree(f.sort.digit_base); (void)hipFree(f.sort.tile_status);
-    (void)hipFree(f.d_pts); (void)hipFree(f.d_codes); (void)hipFree(f.d_normals); (void)hipFree(f.d_seg);
-    f.d_xyz = nullptr; f.sort = RadixSortBuffers{}; f.d_pts = nullptr; f.d_codes = nullptr; f.d_normals = nullptr; f.d_seg = nullptr;
+    (void)hipFree(f.sort.points[0]); (void)hipFree(f.sort.points[1]);
+    (void)hipFree(f.d_codes); (void)hipFree(f.d_normals); (void)hipFree(f.d_seg);
+    f.d_xyz = nullptr; f.sort = RadixSortBuffers{}; f.d_codes = nullptr; f.d_normals = nullptr; f.d_seg = nullptr;
     f.cap_points = 0;
 }
 
@@ -169,12 +169,12 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipMalloc(&f.sort.keys[i], cap * 8));
         HIP_TRY(hipMalloc(&f.sort.idx[i], cap * 4));
+        HIP_TRY(hipMalloc(&f.sort.points[i], cap * 16));  // the points travel with their keys; the last pass's output is the frame in processing order
     }
     HIP_TRY(hipMalloc(&f.sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kMaxPasses) * kRadix * 4));
     HIP_TRY(hipMalloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     f.sort.tiles_capacity = radix_tiles(cap);
-    HIP_TRY(hipMalloc(&f.d_pts, cap * 16));
     HIP_TRY(hipMalloc(&f.d_codes, cap * 8));
     HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
     HIP_TRY(hipMalloc(&f.d_seg, cap * 24));  // point blocks uint2 [cap] (start, length | flag), update work items uint4 [cap] (start, length, super-block code)
@@ -400,12 +400,14 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
         // rest -- normally none -- in one guarded launch (radix_sort.hpp, k_radix_tail)
         const uint32_t hint = m->sort_passes_forced ? m->sort_passes_forced : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1])));
-        radix_sort_enqueue(f.sort, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint);
-        hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                           f.sort.idx[0], f.sort.idx[1], f.d_pts, f.d_codes, reinterpret_cast<uint2*>(f.d_seg), item_start);
+        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint);
+        const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
+        const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
+        hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
+                           points0, points1, f.d_codes, reinterpret_cast<uint2*>(f.d_seg), item_start);
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, f.d_pts, f.d_codes, reinterpret_cast<const uint2*>(f.d_seg), f.d_hdr, pos, f.d_normals, m->ablate);
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.d_codes, reinterpret_cast<const uint2*>(f.d_seg), f.d_hdr, pos, f.d_normals, m->ablate);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -414,17 +416,19 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     // ... the update on the map's stream, behind whatever the caller has done to the map before this insert
     HIP_TRY(hipStreamWaitEvent(m->stream, f.prep_done, 0));
     if (count) {
+        const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
+        const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         // CHAD_UPDATE_AUTO enqueues both forms; each looks at the frame's points-per-block ratio (device memory)
         // and exactly one of them does the work
         const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
         if (!times_stages(m) && m->update_mode == CHAD_UPDATE_SCATTER) record(m, T_NORM, m->stream);
         if (m->update_mode != CHAD_UPDATE_TILED)
-            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, f.d_pts, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
+            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
         // CHAD_FLAG_TIME_UPDATE brackets the dominant kernel alone: in auto mode the scatter launch (which returns at
         // once for a dense frame) stays outside the bracket
         if (!times_stages(m) && m->update_mode != CHAD_UPDATE_SCATTER) record(m, T_NORM, m->stream);
         if (m->update_mode != CHAD_UPDATE_SCATTER)
-            tile_update_enqueue(f.d_pts, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->d_stamps);
+            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->d_stamps);
     } else if (!times_stages(m)) record(m, T_NORM, m->stream);
     record(m, T_UPD, m->stream);
     HIP_TRY(hipEventRecord(f.update_done, m->stream));
@@ -506,7 +510,8 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         else {
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            CREATE_TRY(hipStreamCreateWithPriority(&f.prep, hipStreamNonBlocking, least));
+            if (std::getenv("CHAD_DEBUG_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&f.prep, hipStreamNonBlocking));
+            else CREATE_TRY(hipStreamCreateWithPriority(&f.prep, hipStreamNonBlocking, least));
         }
         CREATE_TRY(hipEventCreateWithFlags(&f.prep_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.update_done, hipEventDisableTiming));
@@ -770,7 +775,7 @@ chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, floa
     if (!k) return CHAD_OK;
     std::vector<float> tmp(k * 4);
     if (order) {
-        HIP_TRY(hipMemcpy(tmp.data(), f.d_pts, k * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tmp.data(), f.sort.points[m->h_hdr->sort_passes & 1u], k * 16, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; i++) std::memcpy(&order[i], &tmp[4 * i + 3], 4);
     }
     if (mc) HIP_TRY(hipMemcpy(mc, f.d_codes, k * 8, hipMemcpyDeviceToHost));

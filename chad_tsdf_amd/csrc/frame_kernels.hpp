@@ -251,7 +251,7 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
     }
 }
 
-// Stage 3 (after the sort): gather the points into processing order as float4 (x, y, z, input index), recompute
+// Stage 3 (after the sort, which has carried the points along as float4 (x, y, z, input index)): recompute
 // their global codes, and list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
 // normal estimation and (b) the update work items (start, length, super-block code) in items[]: the super blocks (runs
 // of equal code >> 9) cut again at every kItemPoints-th point, so that no item is longer than kItemPoints.  A workgroup collects its entries in
@@ -259,10 +259,10 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
 // reserves output space with ONE atomic per list and chunk; the lists are in no particular order.
 // The sorted (key, idx) pairs are in sort buffer (sort_passes & 1).
 __global__ void __launch_bounds__(256)
-k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
+k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
-               const uint32_t* __restrict__ idx0, const uint32_t* __restrict__ idx1,
-               float4* __restrict__ pts, uint64_t* codes, uint2* __restrict__ segments, uint4* __restrict__ items) {
+               const float4* __restrict__ points0, const float4* __restrict__ points1,
+               uint64_t* codes, uint2* __restrict__ segments, uint4* __restrict__ items) {
     constexpr uint32_t kWords = kGatherChunk / 32;
     __shared__ uint32_t mark_bits[kWords], head_bits[kWords];  // bit k: point k of the chunk starts a work item / a point block
     __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
@@ -287,50 +287,25 @@ k_frame_gather(const float* __restrict__ xyz, float recip, FrameHeader* __restri
     const uint32_t n = h->n_usable;
     const bool odd = h->sort_passes & 1u;
     const uint64_t* keys = odd ? keys1 : keys0;
-    const uint32_t* idx = odd ? idx1 : idx0;
+    const float4* pts = odd ? points1 : points0;   // the sort carries the points along: its last pass left them in processing order
     const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         if (threadIdx.x < kWords) { mark_bits[threadIdx.x] = 0u; head_bits[threadIdx.x] = 0u; }
         __syncthreads();
-        // Three batches of independent loads (the compiler keeps a batch in flight together) instead of eight dependent
-        // index -> point chains per thread: the kernel is bound by the latency of the scattered point reads.
         constexpr uint32_t kPer = kGatherChunk / 256;
-        uint32_t heads_mask = 0, supers_mask = 0, src[kPer];
-        {
-            uint64_t kcur[kPer], kprev[kPer];
-#pragma unroll
-            for (uint32_t j = 0; j < kPer; j++) {
-                const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
-                kcur[j] = i < n ? keys[i] : 0ull;
-                kprev[j] = i < n && i ? keys[i - 1] : ~0ull;   // nothing precedes point 0: it opens a block
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < kPer; j++) {
-                const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
-                src[j] = i < n ? idx[i] : 0u;
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < kPer; j++) {
-                heads_mask |= ((kcur[j] >> 6) != (kprev[j] >> 6) ? 1u : 0u) << j;
-                supers_mask |= ((kcur[j] >> 9) != (kprev[j] >> 9) ? 1u : 0u) << j;
-            }
-        }
-        F3 point[kPer];
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) point[j] = load_point(xyz, src[j]);
 #pragma unroll
         for (uint32_t j = 0; j < kPer; j++) {
             const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
             if (i < n) {
-                const F3 p = point[j];
-                const I3 v = voxel_of(p, recip);
+                const uint64_t kcur = keys[i], kprev = i ? keys[i - 1] : ~0ull;   // nothing precedes point 0: it opens a block
+                const float4 q = pts[i];
+                const I3 v = voxel_of(F3{q.x, q.y, q.z}, recip);
                 const uint64_t mc = morton_encode(v.x, v.y, v.z);
-                pts[i] = make_float4(p.x, p.y, p.z, __uint_as_float(src[j]));
                 codes[i] = mc;
-                const bool head = (heads_mask >> j) & 1u, super_head = (supers_mask >> j) & 1u;
+                const bool head = (kcur >> 6) != (kprev >> 6), super_head = (kcur >> 9) != (kprev >> 9);
                 if (head) atomicOr(&head_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (super_head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
-                if (mc == mc_min) atomicMax(&h->last_idx, src[j]);
+                if (mc == mc_min) atomicMax(&h->last_idx, __float_as_uint(q.w));
             }
         }
         __syncthreads();
@@ -508,9 +483,10 @@ constexpr int kNormalWavesPerBlock = 1;  // one wave per workgroup: __syncthread
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 
 __global__ void __launch_bounds__(64 * kNormalWavesPerBlock, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
-k_frame_normals(const float4* __restrict__ pts, const uint64_t* __restrict__ codes, const uint2* __restrict__ segments,
+k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ points1, const uint64_t* __restrict__ codes, const uint2* __restrict__ segments,
                 FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
     __shared__ NormalScratch s;
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = h->n_usable, nseg = h->n_segments;
 

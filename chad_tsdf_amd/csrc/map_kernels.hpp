@@ -76,9 +76,10 @@ __device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint6
 
 // ---- update, general form: one lane per point, global atomics per observation (octree.hpp:86-164) -----------
 __global__ void __launch_bounds__(256)
-k_update_scatter(const float4* __restrict__ pts, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
+k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
                  F3 pos, float res, float recip, float trunc, MapView m, uint32_t adaptive) {
     if (adaptive && !frame_is_sparse(h)) return;  // dense frame: k_update_tiled handles it
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
     const uint32_t n = h->n_usable;
     unsigned long long applied = 0;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {

@@ -25,7 +25,6 @@ constexpr int kSortThreads = 256;                       // 4 waves
 constexpr int kSortItems = 8;                           // keys per thread
 constexpr int kSortTile = kSortThreads * kSortItems;    // 2048 keys per workgroup (1024-key tiles: twice the look-back chain, 11 % slower)
 constexpr int kSortWaves = kSortThreads / 64;
-constexpr uint32_t kResidentTiles = 1024;               // 4 workgroups of the pass kernel per CU (it fits 5)
 constexpr int kLookback = 8;                            // predecessor tiles read per round trip of the look-back (32: more traffic, 17 % slower)
 constexpr int kHistBlocks = 256;                        // workgroups of the histogram kernel (one partial table each)
 constexpr int kMaxHistBlocks = 512;                     // partial tables the buffers have room for
@@ -42,9 +41,30 @@ __device__ __forceinline__ size_t tile_index(uint32_t tile, uint32_t wave, uint3
     return size_t(tile) * kSortTile + wave * (64 * kSortItems) + j * 64 + lane;
 }
 
+// What travels with a key.  IndexPayload: the element's input position (4 bytes).  PointPayload: the point itself and its
+// input position as a float4 (x, y, z, index bits) -- 12 more bytes per element and pass, all of them coalesced, instead of
+// one scattered 12-byte read per point after the sort (1 M points = 128 MB of 128-byte lines, the most expensive
+// memory traffic of the frame); the last pass's output IS the frame's point array in processing order.
+struct IndexPayload {
+    using T = uint32_t;
+    static constexpr uint32_t kResident = 1024;   // workgroups of the pass kernel resident at once: 4 per CU (28 KB of LDS each)
+    static __device__ __forceinline__ T first(const void*, size_t i) { return uint32_t(i); }
+    static __device__ __forceinline__ T none() { return 0u; }
+};
+struct PointPayload {
+    using T = uint4;
+    static constexpr uint32_t kResident = 768;    // 3 per CU (52 KB of LDS each)
+    static __device__ __forceinline__ T first(const void* xyz, size_t i) {
+        const float* p = static_cast<const float*>(xyz) + 3 * i;
+        return make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), uint32_t(i));
+    }
+    static __device__ __forceinline__ T none() { return make_uint4(0u, 0u, 0u, 0u); }
+};
+
 struct RadixSortBuffers {
     uint64_t* keys[2];
     uint32_t* idx[2];
+    uint4* points[2];       // PointPayload ping-pong buffers (null for sorters that only carry indices)
     uint32_t* hist_part;    // [kHistBlocks][kMaxPasses][256] partial digit histograms
     uint32_t* digit_base;   // [kMaxPasses][256] first output slot of each digit
     uint32_t* tile_status;  // [kMaxPasses][tiles][256] look-back words, zeroed before every sort
@@ -106,18 +126,21 @@ k_radix_bases(const uint32_t* __restrict__ hist_part, uint32_t hist_blocks, uint
     digit_base[p * kRadix + d] = before + incl - count;
 }
 
-// One pass for the tile of this workgroup.  idx_in may be null: the payload is then the element's own position (first pass).
+// One pass for the tile of this workgroup.  pay_in may be null: the payload is then made from the element's position
+// (and `first_src`, the raw points, for PointPayload) -- the first pass.
+template <class P>
 __device__ __forceinline__ void
-radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
-                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
+                    uint64_t* __restrict__ keys_out, typename P::T* __restrict__ pay_out,
                     uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
-                    uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket) {
+                    uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const void* __restrict__ first_src) {
+    constexpr uint32_t kResidentTiles = P::kResident;
     __shared__ uint32_t wave_count[kSortWaves][kRadix];  // per-wave digit counts, then the wave's base inside the tile
     __shared__ int offset[kRadix];                       // global slot of local sorted position s is offset[digit] + s
     __shared__ uint32_t wave_total[kSortWaves];
     __shared__ uint32_t my_tile;
     __shared__ uint64_t sorted_key[kSortTile];
-    __shared__ uint32_t sorted_val[kSortTile];
+    __shared__ typename P::T sorted_val[kSortTile];
 
     for (uint32_t k = threadIdx.x; k < kSortWaves * kRadix; k += kSortThreads) (&wave_count[0][0])[k] = 0;
     // A tile waits for the tiles before it.  With at most kResidentTiles tiles every workgroup of the grid is
@@ -131,13 +154,14 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const uint32_t* __rest
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 
     uint64_t key[kSortItems];
-    uint32_t val[kSortItems], rank[kSortItems];
+    typename P::T val[kSortItems];
+    uint32_t rank[kSortItems];
 #pragma unroll
     for (uint32_t j = 0; j < kSortItems; j++) {
         const size_t i = tile_index(tile, wave, j, lane);
         const bool live = i < n;
         key[j] = live ? keys_in[i] : ~0ull;
-        val[j] = live ? (idx_in ? idx_in[i] : uint32_t(i)) : 0u;
+        val[j] = live ? (pay_in ? pay_in[i] : P::first(first_src, i)) : P::none();
     }
 #pragma unroll
     for (uint32_t j = 0; j < kSortItems; j++) {
@@ -227,34 +251,36 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const uint32_t* __rest
         const uint64_t k = sorted_key[s];
         const uint32_t slot = uint32_t(offset[uint32_t(k >> shift) & (kRadix - 1)] + int(s));
         keys_out[slot] = k;
-        idx_out[slot] = sorted_val[s];
+        pay_out[slot] = sorted_val[s];
     }
 }
 
+template <class P>
 __global__ void __launch_bounds__(kSortThreads)
-k_radix_onesweep(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
-                 uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+k_radix_onesweep(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
+                 uint64_t* __restrict__ keys_out, typename P::T* __restrict__ pay_out,
                  uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
-                 uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit) {
+                 uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src) {
     if (pass_limit && pass >= *pass_limit) return;
-    radix_onesweep_tile(keys_in, idx_in, keys_out, idx_out, n, pass, tiles, digit_base, tile_status, tile_ticket);
+    radix_onesweep_tile<P>(keys_in, pay_in, keys_out, pay_out, n, pass, tiles, digit_base, tile_status, tile_ticket, first_src);
 }
 
 // The passes from `first_pass` up to *pass_limit in ONE launch, separated by grid-wide barriers.  The host enqueues as
 // many single-pass kernels as the previous frames needed (a hint read from host-mapped memory) and then this kernel:
 // normally first_pass >= *pass_limit and it returns at once -- one cheap launch instead of five -- and when a frame
 // suddenly needs more passes than were enqueued (its extent has grown) the rest still runs, just slower.
-// Requires every workgroup of the grid to be resident at once (tiles <= kResidentTiles; the caller checks).
+// Requires every workgroup of the grid to be resident at once (tiles <= P::kResident; the caller checks).
+template <class P>
 __global__ void __launch_bounds__(kSortThreads)
-k_radix_tail(uint64_t* __restrict__ keys0, uint32_t* __restrict__ idx0, uint64_t* __restrict__ keys1, uint32_t* __restrict__ idx1,
+k_radix_tail(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
              uint32_t n, uint32_t first_pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
-             uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit) {
+             uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src) {
     const uint32_t limit = min(uint32_t(kMaxPasses), *pass_limit);
     uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
     for (uint32_t pass = first_pass; pass < limit; pass++) {
         const bool odd = pass & 1u;
-        radix_onesweep_tile(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? idx1 : idx0), odd ? keys0 : keys1, odd ? idx0 : idx1, n, pass, tiles, digit_base,
-                            tile_status, tile_ticket);
+        radix_onesweep_tile<P>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base,
+                               tile_status, tile_ticket, first_src);
         if (pass + 1 == limit) break;
         // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
         __syncthreads();
@@ -277,8 +303,11 @@ k_radix_tail(uint64_t* __restrict__ keys0, uint32_t* __restrict__ idx0, uint64_t
 // b.hist_part AND cleared b.tile_status (k_frame_keys does both while it still holds the keys in registers).
 // launch_passes (0 = all `passes`): single-pass kernels to enqueue; the rest are covered by one k_radix_tail launch when
 // the grid is small enough to be resident at once, by single-pass kernels otherwise.
-inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
-                               uint32_t launch_passes = 0) {
+// P = IndexPayload: pairs (key, input position) in b.keys / b.idx.  P = PointPayload: (key, point) in b.keys / b.points,
+// the first pass reading the raw points `first_src` (float xyz[n][3]) in input order.
+template <class P>
+inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
+                                  uint32_t hist_blocks, uint32_t launch_passes, const void* first_src) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
     uint32_t* ticket = b.tile_status + size_t(kMaxPasses) * tiles * kRadix;
@@ -288,16 +317,24 @@ inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t p
                            uint32_t(radix_status_words(tiles)));
     }
     hipLaunchKernelGGL(k_radix_bases, dim3(passes), dim3(4 * kRadix), 0, stream, b.hist_part, hist_blocks, passes, pass_limit, b.digit_base);
-    const bool tail = pass_limit && launch_passes && launch_passes < passes && tiles <= kResidentTiles;
+    const bool tail = pass_limit && launch_passes && launch_passes < passes && tiles <= P::kResident;
     const uint32_t single = tail ? launch_passes : passes;
     for (uint32_t p = 0; p < single; p++) {
         const int src = p & 1, dst = src ^ 1;
-        hipLaunchKernelGGL(k_radix_onesweep, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[src], p == 0 ? nullptr : b.idx[src], b.keys[dst], b.idx[dst], n, p,
-                           tiles, b.digit_base, b.tile_status, ticket, pass_limit);
+        hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[src], p == 0 ? nullptr : pay[src], b.keys[dst], pay[dst], n, p,
+                           tiles, b.digit_base, b.tile_status, ticket, pass_limit, first_src);
     }
     if (tail)
-        hipLaunchKernelGGL(k_radix_tail, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], b.idx[0], b.keys[1], b.idx[1], n, single, tiles, b.digit_base,
-                           b.tile_status, ticket, pass_limit);
+        hipLaunchKernelGGL(k_radix_tail<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, single, tiles, b.digit_base,
+                           b.tile_status, ticket, pass_limit, first_src);
+}
+inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
+                               uint32_t launch_passes = 0) {
+    radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr);
+}
+inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
+                                      uint32_t hist_blocks, uint32_t launch_passes) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz);
 }
 
 }  // namespace chadhip

@@ -9,7 +9,7 @@
 // each paying the per-item latencies below, and 83 % of the lanes busy instead of 97 %.  Per item:
 //   1. the waves take the item's 64-point chunks in turn; each lane walks the ray of its point and accumulates
 //      (d, 1) into the tile with ONE ds_add_u64 per observation.  A tile cell is a 64-bit word
-//      [count : 24 | sum of (d * 2^30/trunc + 2^30) : 40]: the fixed-point step trunc * 2^-30 is finer than the f32
+//      [count : 20 | sum of (d * 2^30/trunc + 2^30) : 44]: the fixed-point step trunc * 2^-30 is finer than the f32
 //      rounding of d itself, an item adds at most 512 observations per cell (no carry into the count), and integer
 //      sums do not depend on the order of arrival.
 //      The walk itself is the reference's traversal (same f32 operations on tmax/delta, same comparison tree, so
@@ -41,6 +41,10 @@ constexpr int kTileWaves = 4;            // waves per workgroup: they share the 
 constexpr int kTileThreads = 64 * kTileWaves;
 constexpr uint32_t kMaxReach = 4;        // D = 16: 32 KiB of LDS per workgroup
 constexpr float kFixedOne = 1073741824.0f;  // 2^30: |d| = trunc in the tile's fixed-point scale
+constexpr uint32_t kCountShift = 44;        // tile cell = [count : 20 | sum of biased fixed-point distances : 44]: an item's 512 observations of
+                                            // at most 2^31 each stay below 2^40 (with the count at bit 40 a cell that took 512 observations of
+                                            // +trunc carried into its own count: found by test_sort_survives_..., whose small frames put
+                                            // thousands of points into the voxels next to the sensor)
 
 // Order this wave's LDS accesses (issued in order by the hardware) without a workgroup barrier and without
 // draining the global atomics still in flight, which __syncthreads() would do.
@@ -77,10 +81,11 @@ __device__ __forceinline__ void tile_barrier() {
 
 template <bool kStamps, int kMinWaves>
 __global__ void __launch_bounds__(kTileThreads, kMinWaves)
-k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normals, const uint4* __restrict__ items, FrameHeader* __restrict__ h,
-               F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, unsigned long long* stamps) {
+k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, const uint4* __restrict__ items,
+               FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
     if (adaptive && frame_is_sparse(h)) return;
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
     const int R = int(reach), D = 8 + 2 * R;
     const uint32_t cells = uint32_t(D * D * D);
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
@@ -182,7 +187,7 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
                     do {
                         const float clamped = __builtin_amdgcn_fmed3f(r.d, -kFixedOne, kFixedOne);  // octree.hpp:159
                         const uint32_t fixed = uint32_t(int(clamped)) + (1u << 30);
-                        __hip_atomic_fetch_add(lds_cell(r.s >> 16), (1ull << 40) | fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(lds_cell(r.s >> 16), (1ull << kCountShift) | fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         const bool xy = r.tx < r.ty, xz = r.tx < r.tz, yz = r.ty < r.tz;   // comparison tree of octree.hpp:126-150
                         const bool sx = xy && xz, sy = !xy && yz, sz = !(sx || sy);
                         r.tx += sx ? r.dx : 0.0f;   // tmax >= 0 (or NaN/inf): adding +0.0f leaves it unchanged
@@ -263,9 +268,9 @@ k_update_tiled(const float4* __restrict__ pts, const float4* __restrict__ normal
             const uint32_t at = cell_of(b);
             const unsigned long long cell = ((lane_valid >> b) & 1u) ? tile[at] : 0ull;
             if (cell) {
-                const uint32_t c = uint32_t(cell >> 40);
+                const uint32_t c = uint32_t(cell >> kCountShift);
                 // sum of d = (sum of biased fixed values - c * 2^30) * trunc / 2^30: exact integer, one rounding to f32
-                const long long fixed_sum = (long long)(cell & ((1ull << 40) - 1)) - ((long long)c << 30);
+                const long long fixed_sum = (long long)(cell & ((1ull << kCountShift) - 1)) - ((long long)c << 30);
                 if (brick != kNoBrick) {
                     atomicAdd(&m.brick_sum[size_t(brick) * 64 + lane], float(fixed_sum) * from_fixed);
                     atomicAdd(&m.brick_cnt[size_t(brick) * 64 + lane], c);
@@ -296,7 +301,7 @@ inline uint32_t tile_reach(float res, float trunc) {
     return r < 1.0f ? 1u : (r > float(kMaxReach) ? kMaxReach : uint32_t(r));
 }
 
-inline void tile_update_enqueue(const float4* pts, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
+inline void tile_update_enqueue(const float4* points0, const float4* points1, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
                                 const MapView& m, hipStream_t stream, bool adaptive, unsigned long long* stamps = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
     const uint32_t d = 8 + 2 * reach;
@@ -316,11 +321,11 @@ inline void tile_update_enqueue(const float4* pts, const float4* normals, const 
     uint32_t per_cu = uint32_t(std::max(1, std::min(8, resident[stamps ? 2 : variant])));
     if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::atoi(e));
     if (stamps)
-        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
     else if (variant)
-        hipLaunchKernelGGL((k_update_tiled<false, 6>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<false, 6>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
     else
-        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, pts, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
 }
 
 }  // namespace chadhip
