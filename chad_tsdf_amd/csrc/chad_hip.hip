@@ -398,12 +398,12 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                            f.sort.hist_part, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
         record(m, T_CALC, prep);
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
-        // rest -- normally none -- in one guarded launch (radix_sort.hpp, k_radix_tail)
+        // last of them covering whatever else the frame turns out to need (radix_sort.hpp, k_radix_onesweep to_limit)
         const uint32_t hint = m->sort_passes_forced ? m->sort_passes_forced : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1])));
         radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint);
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
-        hipLaunchKernelGGL(k_frame_gather, dim3(kFrameBlocks), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
+        hipLaunchKernelGGL(k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
                            points0, points1, f.d_codes, reinterpret_cast<uint2*>(f.d_seg), item_start);
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;

@@ -20,7 +20,7 @@
 namespace chadhip {
 
 constexpr int kFrameBlocks = 512;     // fixed grid of the bounds / keys / gather kernels (2 workgroups per CU)
-constexpr int kGatherChunk = 2048;    // points per gather step of one workgroup
+constexpr int kGatherChunk = 2048;    // points per gather step of one workgroup (1024: more blocks cross a chunk end and probe for their length; slower)
 constexpr uint32_t kItemPoints = 512; // an update work item never holds more points than this
 constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of this many counters (blockIdx % kWorkGroups)
 

@@ -4,7 +4,7 @@
 // (the deterministic tie order D3 of the oracle).  8-bit digits.  Per sort:
 //   k_radix_histograms  one read of the keys: digit histograms of ALL passes at once (LDS atomics), one partial
 //                       table per workgroup (no global atomics);
-//   k_radix_bases       sums the partials and scans the 256 digits of each pass -> first output slot of each digit;
+//   k_radix_bases       sums the partials -> keys per digit and pass (the pass kernel scans those 256 values itself);
 //   k_radix_onesweep    ONE kernel per pass: a workgroup ranks its tile (wave64 ballot matching inside a wave,
 //                       per-wave digit counters in LDS across waves), learns how many keys of each digit precede
 //                       its tile from its predecessors' published counts (decoupled look-back over 32-bit
@@ -66,7 +66,7 @@ struct RadixSortBuffers {
     uint32_t* idx[2];
     uint4* points[2];       // PointPayload ping-pong buffers (null for sorters that only carry indices)
     uint32_t* hist_part;    // [kHistBlocks][kMaxPasses][256] partial digit histograms
-    uint32_t* digit_base;   // [kMaxPasses][256] first output slot of each digit
+    uint32_t* digit_base;   // [kMaxPasses][256] keys per digit (totals; every pass workgroup scans them)
     uint32_t* tile_status;  // [kMaxPasses][tiles][256] look-back words, zeroed before every sort
     uint32_t* tile_ticket;  // [kMaxPasses] next tile to hand out, zeroed with tile_status (stored right behind it)
     uint32_t tiles_capacity;
@@ -93,37 +93,29 @@ k_radix_histograms(const uint64_t* __restrict__ keys, uint32_t n, uint32_t passe
     for (uint32_t p = 0; p < active; p++) hist_part[(size_t(blockIdx.x) * kMaxPasses + p) * kRadix + threadIdx.x] = hist[p][threadIdx.x];
 }
 
-// One workgroup per pass: digit_base[p][d] = number of keys whose digit of pass p is < d.  1024 threads: four
-// slices of the kHistBlocks partial tables per digit, so the loads (independent, coalesced over digits) overlap.
+// digit_base[p][d] = number of keys whose digit of pass p is d: the sum of the partial tables.  Four workgroups per pass
+// (64 digits each, sixteen slices of the partial tables per digit, 1024 threads) -- one workgroup per pass took 7.7 us.
+// The exclusive scan over the digits is done by every workgroup of the pass kernel itself (256 values).
 __global__ void __launch_bounds__(4 * kRadix)
 k_radix_bases(const uint32_t* __restrict__ hist_part, uint32_t hist_blocks, uint32_t passes, const uint32_t* __restrict__ pass_limit,
               uint32_t* __restrict__ digit_base) {
-    const uint32_t p = blockIdx.x;
+    const uint32_t p = blockIdx.x >> 2, quarter = blockIdx.x & 3u;
     const uint32_t active = pass_limit ? min(passes, *pass_limit) : passes;
     if (p >= active) return;
-    __shared__ uint32_t slice_sum[4][kRadix];
-    __shared__ uint32_t wave_total[kRadix / 64];
-    const uint32_t d = threadIdx.x & (kRadix - 1), slice = threadIdx.x >> kRadixBits;
+    __shared__ uint32_t slice_sum[16][64];
+    const uint32_t d = quarter * 64u + (threadIdx.x & 63u), slice = threadIdx.x >> 6;
     uint32_t count = 0;
-    const uint32_t per = (hist_blocks + 3) / 4;
+    const uint32_t per = (hist_blocks + 15) / 16;
     const uint32_t b0 = slice * per, b1 = min(hist_blocks, b0 + per);
 #pragma unroll 8
     for (uint32_t b = b0; b < b1; b++) count += hist_part[(size_t(b) * kMaxPasses + p) * kRadix + d];
-    slice_sum[slice][d] = count;
+    slice_sum[slice][threadIdx.x & 63u] = count;
     __syncthreads();
     if (slice != 0) return;
-    count = slice_sum[0][d] + slice_sum[1][d] + slice_sum[2][d] + slice_sum[3][d];
-    const uint32_t lane = d & 63, wave = d >> 6;
-    uint32_t incl = count;
+    count = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (int(lane) >= o) incl += t; }
-    if (lane == 63) wave_total[wave] = incl;
-    // only the first four waves (slice 0) are left: a named barrier is not needed, they sync through LDS after the
-    // other waves have exited (exited waves do not take part in s_barrier)
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wave; w++) before += wave_total[w];
-    digit_base[p * kRadix + d] = before + incl - count;
+    for (uint32_t k = 0; k < 16; k++) count += slice_sum[k][threadIdx.x & 63u];
+    digit_base[p * kRadix + d] = count;
 }
 
 // One pass for the tile of this workgroup.  pay_in may be null: the payload is then made from the element's position
@@ -137,7 +129,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     constexpr uint32_t kResidentTiles = P::kResident;
     __shared__ uint32_t wave_count[kSortWaves][kRadix];  // per-wave digit counts, then the wave's base inside the tile
     __shared__ int offset[kRadix];                       // global slot of local sorted position s is offset[digit] + s
-    __shared__ uint32_t wave_total[kSortWaves];
+    __shared__ uint32_t wave_total[kSortWaves], wave_total_all[kSortWaves];
     __shared__ uint32_t my_tile;
     __shared__ uint64_t sorted_key[kSortTile];
     __shared__ typename P::T sorted_val[kSortTile];
@@ -194,17 +186,22 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     uint32_t* status = tile_status + (size_t(pass) * tiles + tile) * kRadix;
     __hip_atomic_store(&status[d], (tile == 0 ? kStatusInclusive : kStatusAggregate) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // exclusive scan of the tile's digit counts (position of digit d's run in the locally sorted tile)
-    uint32_t incl = count;
+    // exclusive scans over the digits: of the tile's counts (position of digit d's run in the locally sorted tile) and of
+    // the whole input's counts (first output slot of digit d; k_radix_bases left the per-digit totals)
+    const uint32_t total = digit_base[pass * kRadix + d];
+    uint32_t incl = count, incl_all = total;
     {
         const uint32_t l = d & 63;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (int(l) >= o) incl += t; }
-        if (l == 63) wave_total[d >> 6] = incl;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o), u = __shfl_up(incl_all, o);
+            if (int(l) >= o) { incl += t; incl_all += u; }
+        }
+        if (l == 63) { wave_total[d >> 6] = incl; wave_total_all[d >> 6] = incl_all; }
     }
     __syncthreads();
-    uint32_t local_excl = incl - count;
-    for (uint32_t w = 0; w < (d >> 6); w++) local_excl += wave_total[w];
+    uint32_t local_excl = incl - count, first_slot = incl_all - total;
+    for (uint32_t w = 0; w < (d >> 6); w++) { local_excl += wave_total[w]; first_slot += wave_total_all[w]; }
 
     // decoupled look-back: keys of digit d in all earlier tiles.  kLookback predecessors are read per round trip
     // (independent loads), then consumed nearest first; a word that is not published yet is re-polled alone.
@@ -230,7 +227,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
         t -= kLookback;
     }
     if (tile != 0) __hip_atomic_store(&status[d], kStatusInclusive | (earlier + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    offset[d] = int(digit_base[pass * kRadix + d] + earlier) - int(local_excl);
+    offset[d] = int(first_slot + earlier) - int(local_excl);
     // wave_count[w][d] becomes the local sorted position of wave w's first key of digit d
 #pragma unroll
     for (uint32_t w = 0; w < kSortWaves; w++) wave_count[w][d] += local_excl;
@@ -255,33 +252,24 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     }
 }
 
+// One launch = pass `first_pass`, and -- when `to_limit` is set -- every further pass up to *pass_limit as well, separated
+// by grid-wide barriers.  The host enqueues as many launches as the previous frames needed passes (a hint read from
+// host-mapped memory) and sets to_limit on the last of them: normally that launch does its one pass like the others, and
+// when a frame suddenly needs more passes than were enqueued (its extent has grown) the rest still runs, just slower --
+// instead of five surplus launches per frame that return at once.  to_limit requires every workgroup of the grid to be
+// resident at once (tiles <= P::kResident; the caller checks).
 template <class P>
 __global__ void __launch_bounds__(kSortThreads)
-k_radix_onesweep(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
-                 uint64_t* __restrict__ keys_out, typename P::T* __restrict__ pay_out,
-                 uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
+k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
+                 uint32_t n, uint32_t first_pass, uint32_t to_limit, uint32_t tiles, const uint32_t* __restrict__ digit_base,
                  uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src) {
-    if (pass_limit && pass >= *pass_limit) return;
-    radix_onesweep_tile<P>(keys_in, pay_in, keys_out, pay_out, n, pass, tiles, digit_base, tile_status, tile_ticket, first_src);
-}
-
-// The passes from `first_pass` up to *pass_limit in ONE launch, separated by grid-wide barriers.  The host enqueues as
-// many single-pass kernels as the previous frames needed (a hint read from host-mapped memory) and then this kernel:
-// normally first_pass >= *pass_limit and it returns at once -- one cheap launch instead of five -- and when a frame
-// suddenly needs more passes than were enqueued (its extent has grown) the rest still runs, just slower.
-// Requires every workgroup of the grid to be resident at once (tiles <= P::kResident; the caller checks).
-template <class P>
-__global__ void __launch_bounds__(kSortThreads)
-k_radix_tail(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
-             uint32_t n, uint32_t first_pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
-             uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src) {
-    const uint32_t limit = min(uint32_t(kMaxPasses), *pass_limit);
+    const uint32_t limit = pass_limit ? min(uint32_t(kMaxPasses), *pass_limit) : uint32_t(kMaxPasses);
     uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
     for (uint32_t pass = first_pass; pass < limit; pass++) {
         const bool odd = pass & 1u;
         radix_onesweep_tile<P>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base,
                                tile_status, tile_ticket, first_src);
-        if (pass + 1 == limit) break;
+        if (!to_limit || pass + 1 >= limit) break;
         // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -295,14 +283,8 @@ k_radix_tail(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uin
     }
 }
 
-// Enqueue a sort of n pairs over key bits [0, 8*passes).  Input in keys[0] (idx[0] unused: the payload of the
-// first pass is the position); the result of pass p lands in buffer (p+1)&1, so with *pass_limit = L <= passes
-// active passes the sorted data is in buffer (L & 1).
-// hist_blocks == 0: the digit histograms are computed here (k_radix_histograms, which also clears the look-back
-// table); otherwise the caller's key-producing kernel has already written hist_blocks partial tables into
-// b.hist_part AND cleared b.tile_status (k_frame_keys does both while it still holds the keys in registers).
-// launch_passes (0 = all `passes`): single-pass kernels to enqueue; the rest are covered by one k_radix_tail launch when
-// the grid is small enough to be resident at once, by single-pass kernels otherwise.
+// launch_passes (0 = all `passes`): launches to enqueue; the last of them covers whatever passes remain (k_radix_onesweep,
+// to_limit) when the grid is small enough to be resident at once -- otherwise every pass gets its launch.
 // P = IndexPayload: pairs (key, input position) in b.keys / b.idx.  P = PointPayload: (key, point) in b.keys / b.points,
 // the first pass reading the raw points `first_src` (float xyz[n][3]) in input order.
 template <class P>
@@ -316,17 +298,12 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part, b.tile_status,
                            uint32_t(radix_status_words(tiles)));
     }
-    hipLaunchKernelGGL(k_radix_bases, dim3(passes), dim3(4 * kRadix), 0, stream, b.hist_part, hist_blocks, passes, pass_limit, b.digit_base);
-    const bool tail = pass_limit && launch_passes && launch_passes < passes && tiles <= P::kResident;
-    const uint32_t single = tail ? launch_passes : passes;
-    for (uint32_t p = 0; p < single; p++) {
-        const int src = p & 1, dst = src ^ 1;
-        hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[src], p == 0 ? nullptr : pay[src], b.keys[dst], pay[dst], n, p,
-                           tiles, b.digit_base, b.tile_status, ticket, pass_limit, first_src);
-    }
-    if (tail)
-        hipLaunchKernelGGL(k_radix_tail<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, single, tiles, b.digit_base,
-                           b.tile_status, ticket, pass_limit, first_src);
+    hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, hist_blocks, passes, pass_limit, b.digit_base);
+    const bool hinted = pass_limit && launch_passes && launch_passes < passes && tiles <= P::kResident;
+    const uint32_t launches = hinted ? launch_passes : passes;
+    for (uint32_t p = 0; p < launches; p++)
+        hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                           hinted && p + 1 == launches ? 1u : 0u, tiles, b.digit_base, b.tile_status, ticket, pass_limit, first_src);
 }
 inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
                                uint32_t launch_passes = 0) {

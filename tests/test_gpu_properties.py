@@ -173,7 +173,7 @@ def test_cfg3_stream_back_to_back_matches_survey_pin(chad):
 
 def test_sort_survives_a_frame_that_needs_more_passes_than_were_enqueued(chad, oracle):
     """The number of single-pass sort launches follows the previous frames (a hint in host-mapped memory); a frame whose
-    extent suddenly needs more key bits is finished by the guarded tail kernel (radix_sort.hpp, k_radix_tail)."""
+    extent suddenly needs more key bits is finished by the last enqueued launch, which runs on to the pass limit (radix_sort.hpp, k_radix_onesweep to_limit)."""
     small = synth.cfg2_frame(10_000, seed=3)[0] * np.float32(0.1)       # a 1 m box: few key bits
     pos = np.array([0.03, -0.02, 0.01], dtype=np.float32)
     wide, pos2 = synth.cfg3_frame(0, 60_000)                             # a 30 m corridor: many more
