@@ -404,7 +404,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         hipLaunchKernelGGL(k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                           points0, points1, f.d_codes, reinterpret_cast<uint2*>(f.d_seg), item_start);
+                           points0, points1, f.d_codes, reinterpret_cast<uint2*>(f.d_seg), item_start, uint32_t(f.cap_points));
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
         hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.d_codes, reinterpret_cast<const uint2*>(f.d_seg), f.d_hdr, pos, f.d_normals, m->ablate);
@@ -428,7 +428,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         // once for a dense frame) stays outside the bracket
         if (!times_stages(m) && m->update_mode != CHAD_UPDATE_SCATTER) record(m, T_NORM, m->stream);
         if (m->update_mode != CHAD_UPDATE_SCATTER)
-            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, m->d_stamps);
+            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, uint32_t(f.cap_points), m->d_stamps);
     } else if (!times_stages(m)) record(m, T_NORM, m->stream);
     record(m, T_UPD, m->stream);
     HIP_TRY(hipEventRecord(f.update_done, m->stream));

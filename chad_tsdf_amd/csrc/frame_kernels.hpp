@@ -21,7 +21,8 @@ namespace chadhip {
 
 constexpr int kFrameBlocks = 512;     // fixed grid of the bounds / keys / gather kernels (2 workgroups per CU)
 constexpr int kGatherChunk = 2048;    // points per gather step of one workgroup (1024: more blocks cross a chunk end and probe for their length; slower)
-constexpr uint32_t kItemPoints = 512; // an update work item never holds more points than this
+constexpr uint32_t kItemPoints = 1024; // an update work item never holds more points than this
+constexpr uint32_t kBigItem = 384;     // items longer than this are handed out first (longest-first keeps the update kernel's tail short)
 constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of this many counters (blockIdx % kWorkGroups)
 
 // Per-frame scalars living in device memory (one per map; rewritten every insert).
@@ -34,8 +35,8 @@ struct FrameHeader {
     unsigned long long mc_min;  // smallest global Morton code of the frame ...
     uint32_t last_idx;          // ... and the largest input index among the points having it (normals.hpp:100)
     uint32_t reserved0;
-    uint32_t n_items;           // update work items: point blocks cut at every kItemPoints-th point
-    uint32_t item_cursor;       // work counter of the persistent update waves
+    uint32_t n_items;           // update work items longer than kBigItem points (super blocks cut at every kItemPoints-th point): items[0 ..)
+    uint32_t n_items_small;     // the shorter ones: items[capacity - 1], items[capacity - 2], ...  The update kernel starts with the long ones
     unsigned long long n_updates[32 * 16];  // voxel updates applied by the last insert, striped over 32 cache lines
     uint32_t work_cursor[kWorkGroups * 16];  // per-group work counters of the update kernel, one per 64-byte line
 };
@@ -62,7 +63,7 @@ __device__ __forceinline__ void frame_header_reset(FrameHeader* h) {
         h->vmin[0] = h->vmin[1] = h->vmin[2] = 0x7fffffff;
         h->vmax[0] = h->vmax[1] = h->vmax[2] = int(0x80000000);
         h->n_usable = 0; h->axis_bits = 0; h->sort_passes = 0; h->n_segments = 0;
-        h->mc_min = ~0ull; h->last_idx = 0; h->reserved0 = 0; h->n_items = 0; h->item_cursor = 0;
+        h->mc_min = ~0ull; h->last_idx = 0; h->reserved0 = 0; h->n_items = 0; h->n_items_small = 0;
     }
 }
 __global__ void k_frame_init(FrameHeader* h) { frame_header_reset(h); }
@@ -262,11 +263,11 @@ __global__ void __launch_bounds__(256)
 k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const float4* __restrict__ points0, const float4* __restrict__ points1,
-               uint64_t* codes, uint2* __restrict__ segments, uint4* __restrict__ items) {
+               uint64_t* codes, uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t items_capacity) {
     constexpr uint32_t kWords = kGatherChunk / 32;
     __shared__ uint32_t mark_bits[kWords], head_bits[kWords];  // bit k: point k of the chunk starts a work item / a point block
     __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
-    __shared__ uint32_t base_heads, base_marks;
+    __shared__ uint32_t base_heads, n_big, n_small, base_big, base_small;
     __shared__ unsigned long long wave_mc[4], block_mc_min;
     // frame-wide smallest code from the keys kernel's partials
     {
@@ -291,6 +292,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
     const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         if (threadIdx.x < kWords) { mark_bits[threadIdx.x] = 0u; head_bits[threadIdx.x] = 0u; }
+        if (threadIdx.x == 0) { n_big = 0u; n_small = 0u; }
         __syncthreads();
         constexpr uint32_t kPer = kGatherChunk / 256;
 #pragma unroll
@@ -322,7 +324,26 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             uint32_t later = chunk_len;  // position of the first mark in a later word
             for (int w = int(kWords) - 1; w >= 0; w--) { word_next[which][w] = later; if (bits[w]) later = uint32_t(w) * 32u + uint32_t(__ffs(int(bits[w])) - 1); }
             if (which) base_heads = run ? atomicAdd(&h->n_segments, run) : 0u;
-            else base_marks = run ? atomicAdd(&h->n_items, run) : 0u;
+        }
+        __syncthreads();
+        // the items of this chunk, long and short ones counted apart (order inside a class does not matter) ...
+        uint32_t item_len[kGatherChunk / 256], item_slot[kGatherChunk / 256];
+#pragma unroll
+        for (uint32_t j = 0; j < kGatherChunk / 256; j++) {
+            const uint32_t k = j * 256 + threadIdx.x, bit = k & 31u, word = mark_bits[k >> 5];
+            item_len[j] = 0u; item_slot[j] = 0u;
+            if (k < chunk_len && ((word >> bit) & 1u)) {
+                const uint32_t higher = bit == 31u ? 0u : word >> (bit + 1u);
+                const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[0][k >> 5];
+                item_len[j] = min(next, chunk_len) - k;
+                item_slot[j] = atomicAdd(item_len[j] > kBigItem ? &n_big : &n_small, 1u);
+            }
+        }
+        __syncthreads();
+        // ... each class reserving its part of the list with one atomic per chunk: long items from the front, short ones from the back
+        if (threadIdx.x == 0) {
+            base_big = n_big ? atomicAdd(&h->n_items, n_big) : 0u;
+            base_small = n_small ? atomicAdd(&h->n_items_small, n_small) : 0u;
         }
         __syncthreads();
 #pragma unroll
@@ -333,11 +354,9 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             if (!(((word | hword) >> bit) & 1u)) continue;
             const uint64_t code = codes[c * kGatherChunk + k];  // written by this very thread above
             if ((word >> bit) & 1u) {
-                const uint32_t rank = word_rank[0][k >> 5] + __popc(word & ((1u << bit) - 1u));
-                const uint32_t higher = bit == 31u ? 0u : word >> (bit + 1u);
-                const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[0][k >> 5];
                 const uint64_t corner = code & ~511ull;  // corner of the 8x8x8 super block
-                items[base_marks + rank] = make_uint4(c * kGatherChunk + k, min(next, chunk_len) - k, uint32_t(corner), uint32_t(corner >> 32));
+                const uint32_t at = item_len[j] > kBigItem ? base_big + item_slot[j] : items_capacity - 1u - (base_small + item_slot[j]);
+                items[at] = make_uint4(c * kGatherChunk + k, item_len[j], uint32_t(corner), uint32_t(corner >> 32));
             }
             if ((hword >> bit) & 1u) {
                 // a point block: (start, length | "holds the frame's last point" << 31).  A block that runs to the end of the

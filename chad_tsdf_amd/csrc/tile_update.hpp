@@ -82,7 +82,8 @@ __device__ __forceinline__ void tile_barrier() {
 template <bool kStamps, int kMinWaves>
 __global__ void __launch_bounds__(kTileThreads, kMinWaves)
 k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, const uint4* __restrict__ items,
-               FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, unsigned long long* stamps) {
+               FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t items_capacity,
+               unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
     if (adaptive && frame_is_sparse(h)) return;
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
@@ -95,7 +96,9 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     const uint32_t tile_base = uint32_t(uintptr_t(tile));  // LDS byte address (low half of the flat address)
     const float to_fixed = kFixedOne / trunc, from_fixed = trunc / kFixedOne;
     for (uint32_t k = threadIdx.x; k <= cells; k += kTileThreads) tile[k] = 0ull;
-    const uint32_t nitems = h->n_items;
+    // the work list: n_long items from the front of items[], then n_short from its back (k_frame_gather); longest first
+    const uint32_t n_long = h->n_items, nitems = n_long + h->n_items_small;
+    auto item_record = [&](uint32_t v) { return items[v < n_long ? v : items_capacity - 1u - (v - n_long)]; };
     uint32_t applied = 0;
 
     // lane = voxel v of a brick (Morton order of the low 6 code bits).  This wave's bricks: (bx, by) = 0..3 x 0..3 in
@@ -117,13 +120,13 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     if (kStamps) t_begin = stamp_now();
 
     // everything a wave holds about an item before it starts on it
-    uint4 record = blockIdx.x < nitems ? items[blockIdx.x] : make_uint4(0u, 0u, 0u, 0u);   // length 0: no more work
+    uint4 record = blockIdx.x < nitems ? item_record(blockIdx.x) : make_uint4(0u, 0u, 0u, 0u);   // length 0: no more work
     float4 q_first = make_float4(0, 0, 0, 0), n_first = make_float4(0, 0, 0, 0);            // its first chunk's point and normal for this lane
     uint64_t my_key = kEmptyKey, early = kEmptyKey;                                         // lanes 0..15: key of their brick, what its home slot held
     uint32_t my_slot = 0;
     auto prefetch = [&](const uint4& rec) {
         const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.x))), len = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.y)));
-        const uint32_t k = wave * 64u + lane;
+        const uint32_t k = lane * ((len + 63u) >> 6) + wave;   // chunk `wave` of the item (see the walk)
         if (k < len) { q_first = pts[first + k]; n_first = normals[first + k]; }
         if (lane < 16u && len) {
             // key of brick (bx, by, wave): the corner's code with -4 / 0 / +4 / +8 voxels added per axis, in interleaved
@@ -158,8 +161,12 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
 
         // step 1: the walk (the wave's first chunk is already in registers)
         float4 q = q_first, nq = n_first;
-        for (uint32_t base = wave * 64u; base < len; base += kTileThreads) {
-            const uint32_t k = base + lane;
+        // Chunk c of an item with C chunks holds the points lane * C + c: neighbours in processing order -- points of one
+        // voxel, whose rays visit the same cells in the same steps and serialise in the LDS atomic units -- are dealt to
+        // different chunks instead of neighbouring lanes.  (The loads become strided; they are prefetched.)
+        const uint32_t chunks = (len + 63u) >> 6;
+        for (uint32_t c = wave; c < chunks; c += kTileWaves) {
+            const uint32_t k = lane * chunks + c;
             float4 q_next = q, n_next = nq;
             if (k < len) {
                 const F3 p{q.x, q.y, q.z}, nrm{nq.x, nq.y, nq.z};
@@ -172,7 +179,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
                                     uint32_t(w.last.x - ox) < uint32_t(D) && uint32_t(w.last.y - oy) < uint32_t(D) && uint32_t(w.last.z - oz) < uint32_t(D) &&
                                     (spx | spy | spz) < 8u && finite3(nrm);
                 // the wave's next chunk: loads issued here, behind the register-hungry traversal setup, in flight during the steps
-                if (k + kTileThreads < len) { q_next = pts[first + k + kTileThreads]; n_next = normals[first + k + kTileThreads]; }
+                if (c + kTileWaves < chunks && k + kTileWaves < len) { q_next = pts[first + k + kTileWaves]; n_next = normals[first + k + kTileWaves]; }
                 if (inside) {
                     LeanRay r;
                     r.tx = w.tmax.x; r.ty = w.tmax.y; r.tz = w.tmax.z;
@@ -218,7 +225,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
         // ticket t -> item gridDim + group + 256 t
         if (threadIdx.x == kTileThreads - 64) {
             const uint32_t next = gridDim.x + group + kWorkGroups * turn;
-            *next_record = next < nitems ? items[next] : make_uint4(0u, 0u, 0u, 0u);
+            *next_record = next < nitems ? item_record(next) : make_uint4(0u, 0u, 0u, 0u);
         }
         if (kStamps) { const unsigned long long t1 = stamp_now(); ph[3] += t1 - t0; t0 = t1; }
         tile_barrier();  // all LDS adds of this item have been performed; the next record is in place
@@ -302,7 +309,7 @@ inline uint32_t tile_reach(float res, float trunc) {
 }
 
 inline void tile_update_enqueue(const float4* points0, const float4* points1, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
-                                const MapView& m, hipStream_t stream, bool adaptive, unsigned long long* stamps = nullptr) {
+                                const MapView& m, hipStream_t stream, bool adaptive, uint32_t items_capacity, unsigned long long* stamps = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
     const uint32_t d = 8 + 2 * reach;
     const size_t lds = ((size_t(d) * d * d + 2) & ~size_t(1)) * 8 + 16;   // tile + spare zero cell (padded to 16 bytes) + next item's record
@@ -321,11 +328,11 @@ inline void tile_update_enqueue(const float4* points0, const float4* points1, co
     uint32_t per_cu = uint32_t(std::max(1, std::min(8, resident[stamps ? 2 : variant])));
     if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::atoi(e));
     if (stamps)
-        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
     else if (variant)
-        hipLaunchKernelGGL((k_update_tiled<false, 6>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<false, 6>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
     else
-        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, stamps);
+        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
 }
 
 }  // namespace chadhip
