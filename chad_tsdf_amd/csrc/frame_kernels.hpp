@@ -509,10 +509,9 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = h->n_usable, nseg = h->n_segments;
 
-    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    auto estimate_block = [&](const uint2 record) {
         // (start, length, flag) from k_frame_gather; only a block that runs across the end of a gather chunk (one in
         // fourteen) still has to find its length by probing -- two dependent loads that every block used to pay
-        const uint2 record = segments[seg];
         const uint32_t first = record.x;
         uint32_t len = record.y & 0x7fffffffu;
         if (len == 0u) len = run_length(codes, first, n, codes[first] >> 6, lane);
@@ -639,6 +638,31 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
             normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
         }
         __syncthreads();
+    };
+
+    if (!frame_is_sparse(h)) {  // dense frame: one wave per point block
+        for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) estimate_block(segments[seg]);
+        return;
+    }
+    // Sparse frame (about one point per block, e.g. 2 cm voxels outdoors): a block with fewer than kMinPoints points cannot
+    // form a neighbourhood (normals.hpp:88: the walk never leaves the block), so all its points get the per-point
+    // fallback normal -- one LANE per such block, 64 blocks per wave step, instead of a wave per block (334 k blocks
+    // per cfg5 frame: 167 us).  The few larger blocks go through the wave path afterwards.
+    for (uint32_t base = blockIdx.x * 64u; base < nseg; base += gridDim.x * 64u) {
+        const uint32_t mine = base + lane;
+        const uint2 record = mine < nseg ? segments[mine] : make_uint2(0u, 0u);
+        const uint32_t len = record.y & 0x7fffffffu;
+        const bool small = mine < nseg && len != 0u && len < kMinPoints;
+        if (small)
+            for (uint32_t k = 0; k < len; k++) {
+                const float4 q = pts[record.x + k];
+                const F3 nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
+                normals[record.x + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+            }
+        for (uint64_t big = __ballot(mine < nseg && !small); big; big &= big - 1ull) {
+            const uint32_t l = uint32_t(__ffsll((unsigned long long)big)) - 1u;
+            estimate_block(make_uint2(read_lane(record.x, l), read_lane(record.y, l)));
+        }
     }
 }
 
