@@ -648,8 +648,11 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
     // form a neighbourhood (normals.hpp:88: the walk never leaves the block), so all its points get the per-point
     // fallback normal -- one LANE per such block, 64 blocks per wave step, instead of a wave per block (334 k blocks
     // per cfg5 frame: 167 us).  The few larger blocks go through the wave path afterwards.
-    for (uint32_t base = blockIdx.x * 64u; base < nseg; base += gridDim.x * 64u) {
-        const uint32_t mine = base + lane;
+    // Batch t holds the blocks lane * batches + t: the larger blocks cluster (next to the sensor), and sixty-four
+    // neighbours in one batch would be worked off one after the other by a single wave.
+    const uint32_t batches = (nseg + 63u) / 64u;
+    for (uint32_t t = blockIdx.x; t < batches; t += gridDim.x) {
+        const uint32_t mine = lane * batches + t;
         const uint2 record = mine < nseg ? segments[mine] : make_uint2(0u, 0u);
         const uint32_t len = record.y & 0x7fffffffu;
         const bool small = mine < nseg && len != 0u && len < kMinPoints;
