@@ -489,12 +489,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
     if (o.stream) m->stream = hipStream_t(o.stream);
-    else {  // the update is what the map waits for: its stream gets the highest priority, the preparation streams the lowest
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        CREATE_TRY(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, greatest));
-        m->own_stream = true;
-    }
+    else { CREATE_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     if (const char* e = std::getenv("CHAD_SLOTS")) m->n_slots = std::min<uint32_t>(chad_map::kMaxSlots, std::max(1, std::atoi(e)));
     m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr;
 
@@ -507,12 +502,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     for (uint32_t k = 0; k < m->n_slots; k++) {
         FrameSlot& f = m->slot[k];
         if (m->serial) f.prep = m->stream;
-        else {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (std::getenv("CHAD_DEBUG_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&f.prep, hipStreamNonBlocking));
-            else CREATE_TRY(hipStreamCreateWithPriority(&f.prep, hipStreamNonBlocking, least));
-        }
+        else CREATE_TRY(hipStreamCreateWithFlags(&f.prep, hipStreamNonBlocking));  // (stream priorities measured: no gain at three slots, a collapse at four)
         CREATE_TRY(hipEventCreateWithFlags(&f.prep_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.update_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.stage_done, hipEventDisableTiming));

@@ -48,12 +48,15 @@ __device__ __forceinline__ size_t tile_index(uint32_t tile, uint32_t wave, uint3
 struct IndexPayload {
     using T = uint32_t;
     static constexpr uint32_t kResident = 1024;   // workgroups of the pass kernel resident at once: 4 per CU (28 KB of LDS each)
+    static constexpr bool kStaged = true;         // the payload is reordered through LDS together with its key
     static __device__ __forceinline__ T first(const void*, size_t i) { return uint32_t(i); }
     static __device__ __forceinline__ T none() { return 0u; }
 };
 struct PointPayload {
     using T = uint4;
-    static constexpr uint32_t kResident = 768;    // 3 per CU (52 KB of LDS each)
+    static constexpr uint32_t kResident = 1024;   // 4 per CU: only the keys go through LDS (20 KB).  Staging the 16-byte payload too costs
+                                                  // 32 KB more per workgroup, and three frames' passes then queue for LDS instead of overlapping
+    static constexpr bool kStaged = false;        // the payload goes from registers straight to its slot (16 bytes per lane, runs of equal digits adjacent)
     static __device__ __forceinline__ T first(const void* xyz, size_t i) {
         const float* p = static_cast<const float*>(xyz) + 3 * i;
         return make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), uint32_t(i));
@@ -132,7 +135,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     __shared__ uint32_t wave_total[kSortWaves], wave_total_all[kSortWaves];
     __shared__ uint32_t my_tile;
     __shared__ uint64_t sorted_key[kSortTile];
-    __shared__ typename P::T sorted_val[kSortTile];
+    __shared__ typename P::T sorted_val[P::kStaged ? kSortTile : 1];
 
     for (uint32_t k = threadIdx.x; k < kSortWaves * kRadix; k += kSortThreads) (&wave_count[0][0])[k] = 0;
     // A tile waits for the tiles before it.  With at most kResidentTiles tiles every workgroup of the grid is
@@ -239,7 +242,8 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
             const uint32_t digit = uint32_t(key[j] >> shift) & (kRadix - 1);
             const uint32_t s = wave_count[wave][digit] + rank[j];
             sorted_key[s] = key[j];
-            sorted_val[s] = val[j];
+            if (P::kStaged) sorted_val[s] = val[j];
+            else pay_out[uint32_t(offset[digit] + int(s))] = val[j];
         }
     }
     __syncthreads();
@@ -248,7 +252,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
         const uint64_t k = sorted_key[s];
         const uint32_t slot = uint32_t(offset[uint32_t(k >> shift) & (kRadix - 1)] + int(s));
         keys_out[slot] = k;
-        pay_out[slot] = sorted_val[s];
+        if (P::kStaged) pay_out[slot] = sorted_val[s];
     }
 }
 

@@ -1,0 +1,2 @@
+#!/bin/bash
+for i in 1 2 3 4 5 6; do python bench.py --cpu-seconds 0 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(round(d['ms_per_step'],4), d['roofline']['kernel_ms'], d['host_enqueue_ms_per_step'])"; done 2>&1 | grep -v amdgpu
