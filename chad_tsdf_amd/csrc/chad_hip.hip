@@ -489,7 +489,16 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
     if (o.stream) m->stream = hipStream_t(o.stream);
-    else { CREATE_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    else {
+        // The update is what every frame -- and every other operation on the map -- waits for: its stream gets the highest
+        // priority (0.155 -> 0.13 ms per 1 M-point frame with three frames in flight); the preparation streams stay at the
+        // default (lowest priority for them: no further gain at three slots, a collapse at four).
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (std::getenv("CHAD_DEBUG_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        else CREATE_TRY(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, greatest));
+        m->own_stream = true;
+    }
     if (const char* e = std::getenv("CHAD_SLOTS")) m->n_slots = std::min<uint32_t>(chad_map::kMaxSlots, std::max(1, std::atoi(e)));
     m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr;
 
@@ -502,7 +511,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     for (uint32_t k = 0; k < m->n_slots; k++) {
         FrameSlot& f = m->slot[k];
         if (m->serial) f.prep = m->stream;
-        else CREATE_TRY(hipStreamCreateWithFlags(&f.prep, hipStreamNonBlocking));  // (stream priorities measured: no gain at three slots, a collapse at four)
+        else CREATE_TRY(hipStreamCreateWithFlags(&f.prep, hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&f.prep_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.update_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.stage_done, hipEventDisableTiming));
