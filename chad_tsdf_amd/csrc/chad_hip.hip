@@ -94,7 +94,7 @@ struct chad_map {
     uint32_t last_slot = 0;             // slot of the last insert
     uint32_t sort_passes_forced = 0;    // CHAD_DEBUG_SORT_PASSES: single-pass sort launches per frame (tests of the guarded tail kernel)
     uint32_t flags = 0, update_mode = CHAD_UPDATE_AUTO;
-    uint32_t ablate = 0;  // CHAD_DEBUG_ABLATE: timing experiments only
+    uint32_t ablate = 0;  // CHAD_DEBUG_ABLATE: timing experiments on the normals kernel only (scripts/ablate_normals.sh)
     unsigned long long* d_stamps = nullptr;  // CHAD_DEBUG_STAMPS: per-phase cycle stamps of the update kernel
 
     MapView view{};

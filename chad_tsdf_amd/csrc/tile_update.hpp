@@ -46,14 +46,6 @@ constexpr uint32_t kCountShift = 44;        // tile cell = [count : 20 | sum of 
                                             // +trunc carried into its own count: found by test_sort_survives_..., whose small frames put
                                             // thousands of points into the voxels next to the sensor)
 
-// Order this wave's LDS accesses (issued in order by the hardware) without a workgroup barrier and without
-// draining the global atomics still in flight, which __syncthreads() would do.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 __device__ __forceinline__ lds_u64_t* lds_cell(uint32_t byte_address) { return reinterpret_cast<lds_u64_t*>(byte_address); }
 
@@ -314,23 +306,19 @@ inline void tile_update_enqueue(const float4* points0, const float4* points1, co
     const uint32_t d = 8 + 2 * reach;
     const size_t lds = ((size_t(d) * d * d + 2) & ~size_t(1)) * 8 + 16;   // tile + spare zero cell (padded to 16 bytes) + next item's record
     // persistent workgroups: as many as are resident at once (registers and LDS decide), on every CU
-    static int resident[3] = {0, 0, 0};
+    static int resident[2] = {0, 0};
     static size_t resident_lds = 0;
-    static int variant = 0;  // 0: 5 waves per SIMD (96 VGPRs), 1: 6 waves per SIMD (80 VGPRs, a few spills)
     if (resident_lds != lds) {
-        if (const char* e = std::getenv("CHAD_DEBUG_TILE_VARIANT")) variant = std::atoi(e) ? 1 : 0;
-        resident[0] = resident[1] = resident[2] = 1;
+        resident[0] = resident[1] = 1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[0], k_update_tiled<false, 5>, kTileThreads, lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[1], k_update_tiled<false, 6>, kTileThreads, lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[2], k_update_tiled<true, 5>, kTileThreads, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[1], k_update_tiled<true, 5>, kTileThreads, lds);
         resident_lds = lds;
     }
-    uint32_t per_cu = uint32_t(std::max(1, std::min(8, resident[stamps ? 2 : variant])));
+    uint32_t per_cu = uint32_t(std::max(1, std::min(8, resident[stamps ? 1 : 0])));
     if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::atoi(e));
+    // 5 waves per SIMD (<= 96 VGPRs): a 6-wave build (80 VGPRs) spills and measured slower
     if (stamps)
         hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
-    else if (variant)
-        hipLaunchKernelGGL((k_update_tiled<false, 6>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
     else
         hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
 }
