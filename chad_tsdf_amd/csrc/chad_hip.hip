@@ -421,16 +421,25 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         // CHAD_UPDATE_AUTO enqueues both forms; each looks at the frame's points-per-block ratio (device memory)
         // and exactly one of them does the work
         const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
-        if (!times_stages(m) && m->update_mode == CHAD_UPDATE_SCATTER) record(m, T_NORM, m->stream);
-        if (m->update_mode != CHAD_UPDATE_TILED)
-            hipLaunchKernelGGL(k_update_scatter, grid_for(count), dim3(256), 0, m->stream, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
-        // CHAD_FLAG_TIME_UPDATE brackets the dominant kernel alone: in auto mode the scatter launch (which returns at
-        // once for a dense frame) stays outside the bracket
-        if (!times_stages(m) && m->update_mode != CHAD_UPDATE_SCATTER) record(m, T_NORM, m->stream);
+        // CHAD_FLAG_TIME_UPDATE times the dominant kernel alone, with the dispatch's own begin / end time stamps
+        // (hipExtLaunchKernel): in auto mode the scatter launch, which returns at once for a dense frame, stays outside
+        const bool time_kernel = !times_stages(m) && (m->flags & CHAD_FLAG_TIME_UPDATE);
+        hipEvent_t* ev = m->ev[m->timed_end % chad_map::kTimingRing];
+        if (m->update_mode != CHAD_UPDATE_TILED) {
+            const dim3 grid = grid_for(count);
+            if (time_kernel && m->update_mode == CHAD_UPDATE_SCATTER)
+                hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, m->stream, ev[T_NORM], ev[T_UPD], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, 0u);
+            else
+                hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, m->stream, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
+        }
         if (m->update_mode != CHAD_UPDATE_SCATTER)
-            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, uint32_t(f.cap_points), m->d_stamps);
-    } else if (!times_stages(m)) record(m, T_NORM, m->stream);
-    record(m, T_UPD, m->stream);
+            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, uint32_t(f.cap_points), m->d_stamps,
+                                time_kernel ? ev[T_NORM] : nullptr, time_kernel ? ev[T_UPD] : nullptr);
+        if (times_stages(m)) record(m, T_UPD, m->stream);
+    } else {
+        if (!times_stages(m)) record(m, T_NORM, m->stream);
+        record(m, T_UPD, m->stream);
+    }
     HIP_TRY(hipEventRecord(f.update_done, m->stream));
     f.used = true;
     HIP_TRY(hipGetLastError());

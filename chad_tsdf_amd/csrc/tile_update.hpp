@@ -33,6 +33,8 @@
 // returning atomic on ONE shared address serialises at ~25 ns per dequeue).  Sparse frames (few points per block)
 // skip this kernel and take k_update_scatter instead: with one point per block the staging is pure overhead.
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "map_kernels.hpp"
 
 namespace chadhip {
@@ -301,7 +303,8 @@ inline uint32_t tile_reach(float res, float trunc) {
 }
 
 inline void tile_update_enqueue(const float4* points0, const float4* points1, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
-                                const MapView& m, hipStream_t stream, bool adaptive, uint32_t items_capacity, unsigned long long* stamps = nullptr) {
+                                const MapView& m, hipStream_t stream, bool adaptive, uint32_t items_capacity, unsigned long long* stamps = nullptr,
+                                hipEvent_t started = nullptr, hipEvent_t stopped = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
     const uint32_t d = 8 + 2 * reach;
     const size_t lds = ((size_t(d) * d * d + 2) & ~size_t(1)) * 8 + 16;   // tile + spare zero cell (padded to 16 bytes) + next item's record
@@ -319,6 +322,9 @@ inline void tile_update_enqueue(const float4* points0, const float4* points1, co
     // 5 waves per SIMD (<= 96 VGPRs): a 6-wave build (80 VGPRs) spills and measured slower
     if (stamps)
         hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
+    else if (started && stopped)  // the events take the dispatch's own begin and end time stamps: the kernel's execution, without marker packets around it
+        hipExtLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), uint32_t(lds), stream, started, stopped, 0u, points0, points1, normals, items, h, pos,
+                              res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
     else
         hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
 }
