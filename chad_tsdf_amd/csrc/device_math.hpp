@@ -100,10 +100,10 @@ struct RayWalk {
     }
 
     static __device__ __forceinline__ float first_crossing(int s, float a, float inv, float res, float recip) {
-        float edge;
-        if (s < 0) edge = res * floorf(a * recip);
-        else if (s > 0) edge = res * ceilf(a * recip);
-        else edge = 3.402823466e+38f;  // FLT_MAX, :108
+        // selects, not branches: three divergent if/else chains per ray cost more than computing both roundings
+        const float scaled = a * recip;
+        const float grid = s < 0 ? floorf(scaled) : ceilf(scaled);
+        const float edge = s == 0 ? 3.402823466e+38f : res * grid;  // FLT_MAX, :108
         return fabsf((edge - a) * inv);
     }
 };

@@ -48,6 +48,18 @@ constexpr uint32_t kCountShift = 44;        // tile cell = [count : 20 | sum of 
                                             // +trunc carried into its own count: found by test_sort_survives_..., whose small frames put
                                             // thousands of points into the voxels next to the sensor)
 
+// b where the lane's bit of `mask` is set, a elsewhere: v_cndmask_b32 with the lane mask in a scalar register pair
+__device__ __forceinline__ float select_f(float a, float b, uint64_t mask) {
+    float out;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
+    return out;
+}
+__device__ __forceinline__ uint32_t select_u(uint32_t a, uint32_t b, uint64_t mask) {
+    uint32_t out;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
+    return out;
+}
+
 typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 __device__ __forceinline__ lds_u64_t* lds_cell(uint32_t byte_address) { return reinterpret_cast<lds_u64_t*>(byte_address); }
 
@@ -178,6 +190,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
                     LeanRay r;
                     r.tx = w.tmax.x; r.ty = w.tmax.y; r.tz = w.tmax.z;
                     r.dx = w.delta.x; r.dy = w.delta.y; r.dz = w.delta.z;
+                    asm("" : "+v"(r.dx), "+v"(r.dy), "+v"(r.dz));   // |res * inv| as values: keeps the fabs out of the step loop
                     const float scale = res * to_fixed;
                     r.d = dot3(nrm, F3{float(w.cur.x) * res - p.x, float(w.cur.y) * res - p.y, float(w.cur.z) * res - p.z}) * to_fixed;  // octree.hpp:157-158
                     r.ddx = float(w.step.x) * scale * nrm.x; r.ddy = float(w.step.y) * scale * nrm.y; r.ddz = float(w.step.z) * scale * nrm.z;
@@ -189,13 +202,16 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
                         const float clamped = __builtin_amdgcn_fmed3f(r.d, -kFixedOne, kFixedOne);  // octree.hpp:159
                         const uint32_t fixed = uint32_t(int(clamped)) + (1u << 30);
                         __hip_atomic_fetch_add(lds_cell(r.s >> 16), (1ull << kCountShift) | fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const bool xy = r.tx < r.ty, xz = r.tx < r.tz, yz = r.ty < r.tz;   // comparison tree of octree.hpp:126-150
-                        const bool sx = xy && xz, sy = !xy && yz, sz = !(sx || sy);
-                        r.tx += sx ? r.dx : 0.0f;   // tmax >= 0 (or NaN/inf): adding +0.0f leaves it unchanged
-                        r.ty += sy ? r.dy : 0.0f;
-                        r.tz += sz ? r.dz : 0.0f;
-                        r.d += sx ? r.ddx : (sy ? r.ddy : r.ddz);
-                        r.s += sx ? r.kx : (sy ? r.ky : r.kz);
+                        // comparison tree of octree.hpp:126-150 as lane masks in scalar registers: x steps where tx < ty and
+                        // tx < tz, y where not (tx < ty) and ty < tz, z elsewhere.  The selects take the mask as their SGPR
+                        // operand directly (hipcc turns "neither x nor y" into a five-instruction detour through VGPRs)
+                        const uint64_t bxy = __ballot(r.tx < r.ty), bxz = __ballot(r.tx < r.tz), byz = __ballot(r.ty < r.tz);
+                        const uint64_t mx = bxy & bxz, my = ~bxy & byz, mz = ~(mx | my);
+                        r.tx += select_f(0.0f, r.dx, mx);   // tmax >= 0 (or NaN/inf): adding +0.0f leaves it unchanged
+                        r.ty += select_f(0.0f, r.dy, my);
+                        r.tz += select_f(0.0f, r.dz, mz);
+                        r.d += select_f(select_f(r.ddz, r.ddy, my), r.ddx, mx);
+                        r.s += select_u(select_u(r.kz, r.ky, my), r.kx, mx);
                     } while ((r.s & 0x888u) == 0x888u);
                 } else {  // straight to HBM, one observation at a time (rare)
                     uint64_t far_key = kEmptyKey;
