@@ -314,16 +314,24 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
         // work items: every mark opens an item that runs to the next mark, or to the end of the chunk (chunks start at a
         // multiple of kItemPoints, i.e. at a mark, so items never span chunks)
         const uint32_t chunk_len = min(uint32_t(kGatherChunk), n - c * kGatherChunk);
-        // rank of every mark among the chunk's marks and position of the next one: thread 0 for the items, thread 64 (another
-        // wave) for the point blocks
-        if (threadIdx.x == 0 || threadIdx.x == 64) {
-            const uint32_t which = threadIdx.x ? 1u : 0u;
-            const uint32_t* bits = which ? head_bits : mark_bits;
-            uint32_t run = 0;
-            for (uint32_t w = 0; w < kWords; w++) { word_rank[which][w] = run; run += __popc(bits[w]); }
-            uint32_t later = chunk_len;  // position of the first mark in a later word
-            for (int w = int(kWords) - 1; w >= 0; w--) { word_next[which][w] = later; if (bits[w]) later = uint32_t(w) * 32u + uint32_t(__ffs(int(bits[w])) - 1); }
-            if (which) base_heads = run ? atomicAdd(&h->n_segments, run) : 0u;
+        // rank of every mark among the chunk's marks and position of the next one, by word of the bit masks (kWords = 64 = one
+        // word per lane): wave 0 for the items, wave 1 for the point blocks -- a prefix sum of the popcounts and a suffix
+        // minimum of the words' first marks (two serial 64-step loops per list before)
+        static_assert(kWords == 64, "one bit-mask word per lane");
+        if (threadIdx.x < 128) {
+            const uint32_t which = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+            const uint32_t word = (which ? head_bits : mark_bits)[lane];
+            const uint32_t count = uint32_t(__popc(word));
+            uint32_t incl = count;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (int(lane) >= o) incl += t; }
+            word_rank[which][lane] = incl - count;
+            uint32_t first_mark = word ? lane * 32u + uint32_t(__ffs(int(word)) - 1) : chunk_len;   // chunk_len = "none"
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_down(first_mark, o); if (int(lane) + o < 64) first_mark = min(first_mark, t); }
+            const uint32_t after = __shfl_down(first_mark, 1);   // first mark in a later word
+            word_next[which][lane] = lane == 63u ? chunk_len : after;
+            if (which && lane == 63u) base_heads = incl ? atomicAdd(&h->n_segments, incl) : 0u;
         }
         __syncthreads();
         // the items of this chunk, long and short ones counted apart (order inside a class does not matter) ...
