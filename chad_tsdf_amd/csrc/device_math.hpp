@@ -60,9 +60,12 @@ __device__ __forceinline__ I3 voxel_of(F3 p, float recip) { return {int(floorf(p
 // A point takes part in a frame iff its ray direction is finite and its voxel is far from the int range
 // (the reference has undefined behaviour otherwise: octree.hpp:92-97 converts NaN to int).
 __device__ __forceinline__ bool point_usable(F3 p, F3 pos, float recip) {
-    const F3 d = unit3(sub3(p, pos));
+    // "the unit vector towards the point is finite", without computing it: v * (1 / sqrt(dot(v, v))) is finite exactly when
+    // v is finite and dot(v, v) > 0 -- a zero dot (point at the sensor, or an underflow) gives 0 * inf or x * inf, an infinite
+    // dot gives a finite 0 * x -- so the square root and the division are not needed (the frame kernels test every point twice)
+    const F3 v = sub3(p, pos);
     const float lim = 1073741824.0f;  // 2^30 voxels
-    return finite3(d) && fabsf(p.x * recip) < lim && fabsf(p.y * recip) < lim && fabsf(p.z * recip) < lim;
+    return finite3(v) && dot3(v, v) > 0.0f && fabsf(p.x * recip) < lim && fabsf(p.y * recip) < lim && fabsf(p.z * recip) < lim;
 }
 
 // ---- truncated-ray traversal (octree.hpp:86-152) -------------------------------------------------------------
