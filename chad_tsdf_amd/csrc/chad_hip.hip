@@ -60,15 +60,16 @@ enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
 }  // namespace
 
 // Everything one frame needs on its way from raw points to (points, normals, work items) in processing order.  A few
-// slots, used in turn, each with a stream of its own: the preparation of the next frames (bounds, keys, sort, gather,
-// normals -- none of which touches the map; every kernel of it is latency-bound and leaves most of the chip idle)
-// runs beside the update of frame k, which stays on the map's stream together with every other operation on the map
-// (clear, roll-over, growth, export), in call order.
+// slots, used in turn, each with a stream of its own, on which the whole frame runs: preparation (bounds, keys, sort,
+// gather, normals -- none of which touches the map; every kernel of it is latency-bound and leaves most of the chip
+// idle) and then the update.  Updates of different frames commute (sums and counts, added atomically), so the streams
+// need no ordering among themselves.  What does need the map to itself -- clearing it, a roll-over, growth, an export --
+// waits for the updates enqueued so far and makes the later ones wait for it (exclusive_begin / exclusive_end below).
 struct FrameSlot {
     hipStream_t prep = nullptr;
-    hipEvent_t prep_done = nullptr;     // recorded on `prep` behind the normals kernel: the update may start
-    hipEvent_t update_done = nullptr;   // recorded on the map's stream behind the update: the slot's buffers are free again
+    hipEvent_t update_done = nullptr;   // recorded on `prep` behind the update: an exclusive operation on the map waits for it
     bool used = false;
+    uint64_t seen_epoch = 0;            // the last exclusive operation this stream has been made to wait for
     FrameHeader* d_hdr = nullptr;
     FramePartial* d_part = nullptr;     // kFrameBlocks partial reductions of the frame kernels
     size_t cap_points = 0;
@@ -84,7 +85,11 @@ struct FrameSlot {
 struct chad_map {
     float res = 0, trunc = 0, recip = 0;
     int device = 0;
-    hipStream_t stream = nullptr;       // the map's stream: updates and every other operation on the map
+    hipStream_t stream = nullptr;       // the map's stream: every operation that needs the map to itself
+    hipEvent_t excl_done = nullptr;     // recorded behind the last such operation
+    uint64_t excl_epoch = 0;            // ... and counted
+    bool pending_clear = false;         // chad_map_reset is lazy: the clear runs on the next insert's stream, right before its update
+    bool pending_clear_overflow = false;
     bool own_stream = false;
     hipEvent_t caller_ready = nullptr;  // caller-supplied stream only: the frame's input is ready once this has passed
     static constexpr uint32_t kMaxSlots = 8;
@@ -159,6 +164,22 @@ chad_status join_streams(chad_map* m) {
     return CHAD_OK;
 }
 
+// The map stream is about to do something that needs the map to itself: it waits (on the device) for every update
+// enqueued so far.
+chad_status exclusive_begin(chad_map* m) {
+    for (uint32_t k = 0; k < m->n_slots; k++) {
+        FrameSlot& f = m->slot[k];
+        if (f.used && f.prep != m->stream) HIP_TRY(hipStreamWaitEvent(m->stream, f.update_done, 0));
+    }
+    return CHAD_OK;
+}
+// ... and is done with it: updates enqueued from now on wait for this point (insert_device checks the epoch).
+chad_status exclusive_end(chad_map* m, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(m->excl_done, stream));
+    m->excl_epoch++;
+    return CHAD_OK;
+}
+
 chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     if (n <= f.cap_points) return CHAD_OK;
     TRY(join_streams(m));
@@ -212,13 +233,23 @@ chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream, u
 
 // Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  Fully asynchronous.
 chad_status clear_active(chad_map* m, bool clear_overflow = false) {
+    TRY(exclusive_begin(m));
     hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, clear_overflow ? 1u : 0u);
     HIP_TRY(hipGetLastError());
-    return CHAD_OK;
+    m->pending_clear = false; m->pending_clear_overflow = false;   // whatever was pending has just happened
+    return exclusive_end(m, m->stream);
+}
+
+// A reset not yet carried out (chad_map_reset defers it to the next insert) is carried out now, on the map's stream.
+chad_status flush_pending_clear(chad_map* m) {
+    if (!m->pending_clear) return CHAD_OK;
+    return clear_active(m, m->pending_clear_overflow);
 }
 
 chad_status read_block_count(chad_map* m, uint32_t* blocks) {
     uint32_t stripes[kCountStripes * 16];
+    TRY(flush_pending_clear(m));
+    TRY(join_streams(m));   // updates run on the slots' streams
     HIP_TRY(hipMemcpyAsync(stripes, m->view.brick_count, sizeof(stripes), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     uint32_t v = 0;
@@ -351,13 +382,12 @@ void collect_timing(chad_map* m) {
     m->timed_begin = m->timed_end;
 }
 
-// The slot of the next insert, with room for n points and its buffers free: its stream waits until the update of the
-// frame that used the slot before (n_slots inserts ago) has finished with them.
+// The slot of the next insert, with room for n points.  Its buffers are free when its stream gets there: the frame that
+// used the slot before (n_slots inserts ago) ran on the same stream, update included.
 chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
     const uint32_t turn = uint32_t(m->frames % m->n_slots);
     FrameSlot& f = m->slot[turn];
     TRY(ensure_frame_capacity(m, f, n));
-    if (f.used) HIP_TRY(hipStreamWaitEvent(f.prep, f.update_done, 0));
     if (m->caller_ready) {  // caller-supplied stream: the caller's work enqueued so far (it may produce the points) comes first
         HIP_TRY(hipEventRecord(m->caller_ready, m->stream));
         HIP_TRY(hipStreamWaitEvent(f.prep, m->caller_ready, 0));
@@ -412,35 +442,42 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
     }
-    HIP_TRY(hipEventRecord(f.prep_done, prep));
-    // ... the update on the map's stream, behind whatever the caller has done to the map before this insert
-    HIP_TRY(hipStreamWaitEvent(m->stream, f.prep_done, 0));
+    // ... then the update, on the same stream.  It has to wait for whatever has needed the map to itself since this
+    // stream last looked (a roll-over, growth ...), and a deferred reset is carried out here: behind the updates of the
+    // other streams enqueued so far, in front of this one and -- through the epoch -- of every later one.
+    if (f.seen_epoch != m->excl_epoch) { HIP_TRY(hipStreamWaitEvent(prep, m->excl_done, 0)); f.seen_epoch = m->excl_epoch; }
+    if (m->pending_clear) {
+        for (uint32_t k = 0; k < m->n_slots; k++) {
+            FrameSlot& o = m->slot[k];
+            if (&o != &f && o.used && o.prep != prep) HIP_TRY(hipStreamWaitEvent(prep, o.update_done, 0));
+        }
+        hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, prep, m->view, m->pending_clear_overflow ? 1u : 0u);
+        m->pending_clear = false; m->pending_clear_overflow = false;
+        TRY(exclusive_end(m, prep));
+        f.seen_epoch = m->excl_epoch;
+    }
     if (count) {
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
-        // CHAD_UPDATE_AUTO enqueues both forms; each looks at the frame's points-per-block ratio (device memory)
-        // and exactly one of them does the work
         const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
-        // CHAD_FLAG_TIME_UPDATE times the dominant kernel alone, with the dispatch's own begin / end time stamps
-        // (hipExtLaunchKernel): in auto mode the scatter launch, which returns at once for a dense frame, stays outside
+        // CHAD_FLAG_TIME_UPDATE times the update kernel alone, with the dispatch's own begin / end time stamps (hipExtLaunchKernel)
         const bool time_kernel = !times_stages(m) && (m->flags & CHAD_FLAG_TIME_UPDATE);
         hipEvent_t* ev = m->ev[m->timed_end % chad_map::kTimingRing];
-        if (m->update_mode != CHAD_UPDATE_TILED) {
+        if (m->update_mode == CHAD_UPDATE_SCATTER) {
             const dim3 grid = grid_for(count);
-            if (time_kernel && m->update_mode == CHAD_UPDATE_SCATTER)
-                hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, m->stream, ev[T_NORM], ev[T_UPD], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, 0u);
+            if (time_kernel)
+                hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, prep, ev[T_NORM], ev[T_UPD], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
             else
-                hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, m->stream, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, adaptive ? 1u : 0u);
-        }
-        if (m->update_mode != CHAD_UPDATE_SCATTER)
-            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, m->stream, adaptive, uint32_t(f.cap_points), m->d_stamps,
+                hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
+        } else  // the tiled kernel; in automatic mode it takes the scatter form itself when the frame is sparse (decided on the device)
+            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, uint32_t(f.cap_points), m->d_stamps,
                                 time_kernel ? ev[T_NORM] : nullptr, time_kernel ? ev[T_UPD] : nullptr);
-        if (times_stages(m)) record(m, T_UPD, m->stream);
+        if (times_stages(m)) record(m, T_UPD, prep);
     } else {
-        if (!times_stages(m)) record(m, T_NORM, m->stream);
-        record(m, T_UPD, m->stream);
+        if (!times_stages(m)) record(m, T_NORM, prep);
+        record(m, T_UPD, prep);
     }
-    HIP_TRY(hipEventRecord(f.update_done, m->stream));
+    HIP_TRY(hipEventRecord(f.update_done, prep));
     f.used = true;
     HIP_TRY(hipGetLastError());
     m->frames++;
@@ -521,13 +558,13 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         FrameSlot& f = m->slot[k];
         if (m->serial) f.prep = m->stream;
         else CREATE_TRY(hipStreamCreateWithFlags(&f.prep, hipStreamNonBlocking));
-        CREATE_TRY(hipEventCreateWithFlags(&f.prep_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.update_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.stage_done, hipEventDisableTiming));
         CREATE_TRY(hipMalloc(&f.d_hdr, sizeof(FrameHeader)));
         CREATE_TRY(hipMemsetAsync(f.d_hdr, 0, sizeof(FrameHeader), m->stream));
         CREATE_TRY(hipMalloc(&f.d_part, sizeof(FramePartial) * kFrameBlocks));
     }
+    CREATE_TRY(hipEventCreateWithFlags(&m->excl_done, hipEventDisableTiming));
     if (!m->own_stream) CREATE_TRY(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
     CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
@@ -572,12 +609,12 @@ void chad_map_destroy(chad_map* m) {
     for (auto& f : m->slot) {
         free_frame_buffers(f);
         (void)hipFree(f.d_hdr); (void)hipFree(f.d_part);
-        if (f.prep_done) (void)hipEventDestroy(f.prep_done);
         if (f.update_done) (void)hipEventDestroy(f.update_done);
         if (f.stage_done) (void)hipEventDestroy(f.stage_done);
         if (f.prep && f.prep != m->stream) (void)hipStreamDestroy(f.prep);
     }
     if (m->caller_ready) (void)hipEventDestroy(m->caller_ready);
+    if (m->excl_done) (void)hipEventDestroy(m->excl_done);
     for (auto& s : m->closed) free_submap(s);
     free_submap(m->active_copy);
     free_map_storage(m->view);
@@ -622,6 +659,7 @@ chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float
 
 // the last insert's header (stage read-back, statistics) and the sticky overflow flag, after everything has finished
 chad_status read_back_header(chad_map* m, uint32_t* overflow) {
+    TRY(flush_pending_clear(m));
     TRY(join_streams(m));
     HIP_TRY(hipMemcpy(m->h_hdr, m->slot[m->last_slot].d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(overflow, m->d_overflow, 4, hipMemcpyDeviceToHost));
@@ -641,12 +679,16 @@ chad_status chad_map_reset(chad_map* m) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
     if (!m->closed.empty()) {
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        TRY(join_streams(m));
         for (auto& s : m->closed) free_submap(s);
         m->closed.clear();
     }
     m->positions.clear();
-    return clear_active(m, true);
+    // The clear itself is deferred to the stream of the next insert (right in front of its update), so that the next
+    // frame's preparation does not queue behind it; anything else that looks at the map first carries it out (flush_pending_clear).
+    m->pending_clear = true;
+    m->pending_clear_overflow = true;
+    return CHAD_OK;
 }
 
 chad_status chad_map_close_submap(chad_map* m) {

@@ -75,11 +75,10 @@ __device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint6
 }
 
 // ---- update, general form: one lane per point, global atomics per observation (octree.hpp:86-164) -----------
-__global__ void __launch_bounds__(256)
-k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
-                 F3 pos, float res, float recip, float trunc, MapView m, uint32_t adaptive) {
-    if (adaptive && !frame_is_sparse(h)) return;  // dense frame: k_update_tiled handles it
-    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
+// The body is shared: k_update_scatter runs it alone; k_update_tiled (tile_update.hpp) runs it instead of its own loop when
+// the frame turns out to be sparse, so that the automatic mode needs one launch, not two.
+__device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
+                                               F3 pos, float res, float recip, float trunc, const MapView& m) {
     const uint32_t n = h->n_usable;
     unsigned long long applied = 0;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -104,6 +103,13 @@ k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) applied += __shfl_xor(applied, o);
     if ((threadIdx.x & 63) == 0 && applied) atomicAdd(&h->n_updates[(blockIdx.x & 31u) * 16u], applied);
+}
+
+__global__ void __launch_bounds__(256)
+k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
+                 F3 pos, float res, float recip, float trunc, MapView m) {
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
+    scatter_update(pts, normals, h, pos, res, recip, trunc, m);
 }
 
 // ---- stage entries for parity tests ----------------------------------------------------------------------------

@@ -91,8 +91,11 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
                FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t items_capacity,
                unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
-    if (adaptive && frame_is_sparse(h)) return;
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
+    if (adaptive && frame_is_sparse(h)) {  // about one point per block: staging tiles is pure overhead, take the general form
+        scatter_update(pts, normals, h, pos, res, recip, trunc, m);
+        return;
+    }
     const int R = int(reach), D = 8 + 2 * R;
     const uint32_t cells = uint32_t(D * D * D);
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
