@@ -40,17 +40,20 @@ typedef struct chad_options {
     uint64_t max_blocks; /* initial capacity of the active submap in 4x4x4-voxel blocks (532 B of HBM each); 0 = default (1<<21).
                             Doubles automatically between frames when half full, unless CHAD_FLAG_FIXED_CAPACITY */
     uint64_t max_points; /* initial per-frame point capacity (grows on demand); 0 = default (1<<20) */
-    void* stream;        /* hipStream_t to enqueue on; NULL = a stream owned by the map */
+    void* stream;        /* hipStream_t of the caller: frames wait for the work enqueued on it before the insert, and operations
+                            that need the map to itself run on it; NULL = a stream owned by the map.  Frames always run on
+                            streams owned by the map (three in flight) */
     uint32_t flags;      /* CHAD_FLAG_* */
     uint32_t update_mode; /* CHAD_UPDATE_* */
 } chad_options;
 
 enum {
     CHAD_FLAG_VERBOSE = 1u, /* print the reference's five stage-timer lines per insert (morton.hpp:78,100; normals.hpp:146; octree.hpp:169; tsdf.cpp:74) */
-    CHAD_FLAG_TIMING = 2u,  /* record per-stage device times with HIP events on the map's stream (no extra synchronisation);
-                               chad_map_stats reports their mean over the inserts since the previous stats call (at most 64).
-                               Each event costs ~6 us of stream time: five per insert */
-    CHAD_FLAG_TIME_UPDATE = 4u, /* as CHAD_FLAG_TIMING, but only the TSDF-update kernel is bracketed (ms_oct_upd): two events per insert */
+    CHAD_FLAG_TIMING = 2u,  /* record per-stage device times with HIP events (no extra synchronisation); the frames then run one
+                               after the other on one stream, so that stage times do not overlap.  chad_map_stats reports their mean
+                               over the inserts since the previous stats call (at most 64) */
+    CHAD_FLAG_TIME_UPDATE = 4u, /* only the TSDF-update kernel is timed (ms_oct_upd), by the begin / end time stamps of its own dispatch;
+                                   frames stay pipelined (up to three in flight) */
     CHAD_FLAG_FIXED_CAPACITY = 8u /* never grow the block pool beyond max_blocks (default: it doubles between frames when half full) */
 };
 enum {
