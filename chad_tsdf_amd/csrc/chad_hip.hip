@@ -763,6 +763,17 @@ static chad_status export_blocks(chad_map* m, int32_t submap, uint64_t* keys_dev
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
     uint32_t nb = 0;
+    if (submap < 0 && !sorted) {  // the multi-GPU merge's path: the live bricks straight into the caller's buffers, no intermediate copy
+        TRY(read_block_count(m, &nb));
+        if (nb > capacity_blocks) return fail(CHAD_ERR_INVALID_ARG, "capacity_blocks too small");
+        if (!nb) return CHAD_OK;
+        if (!keys_device || !sum_device || !cnt_device) return fail(CHAD_ERR_INVALID_ARG, "null output");
+        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
+        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, nb, keys_device, sum_device, cnt_device);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return CHAD_OK;
+    }
     const uint64_t* keys; const float* sum; const uint32_t* cnt;
     TRY(select_submap(m, submap, &nb, &keys, &sum, &cnt));
     if (nb > capacity_blocks) return fail(CHAD_ERR_INVALID_ARG, "capacity_blocks too small");
