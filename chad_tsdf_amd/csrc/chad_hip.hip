@@ -87,6 +87,8 @@ struct chad_map {
     int device = 0;
     hipStream_t stream = nullptr;       // the map's stream: every operation that needs the map to itself
     hipEvent_t excl_done = nullptr;     // recorded behind the last such operation
+    hipEvent_t sort_turn = nullptr;     // behind the last sort launch that may run on behind grid barriers: those take turns (radix_sort.hpp)
+    bool sort_turn_used = false;
     uint64_t excl_epoch = 0;            // ... and counted
     bool pending_clear = false;         // chad_map_reset is lazy: the clear runs on the next insert's stream, right before its update
     bool pending_clear_overflow = false;
@@ -430,7 +432,8 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
         // last of them covering whatever else the frame turns out to need (radix_sort.hpp, k_radix_onesweep to_limit)
         const uint32_t hint = m->sort_passes_forced ? m->sort_passes_forced : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1])));
-        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint);
+        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used);
+        m->sort_turn_used = true;   // (recorded by the hinted path only; an unrecorded event makes the wait a no-op)
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         hipLaunchKernelGGL(k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
@@ -565,6 +568,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         CREATE_TRY(hipMalloc(&f.d_part, sizeof(FramePartial) * kFrameBlocks));
     }
     CREATE_TRY(hipEventCreateWithFlags(&m->excl_done, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&m->sort_turn, hipEventDisableTiming));
     if (!m->own_stream) CREATE_TRY(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
     CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
@@ -615,6 +619,7 @@ void chad_map_destroy(chad_map* m) {
     }
     if (m->caller_ready) (void)hipEventDestroy(m->caller_ready);
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
+    if (m->sort_turn) (void)hipEventDestroy(m->sort_turn);
     for (auto& s : m->closed) free_submap(s);
     free_submap(m->active_copy);
     free_map_storage(m->view);

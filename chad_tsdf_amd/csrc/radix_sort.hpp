@@ -293,7 +293,7 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
 // the first pass reading the raw points `first_src` (float xyz[n][3]) in input order.
 template <class P>
 inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                  uint32_t hist_blocks, uint32_t launch_passes, const void* first_src) {
+                                  uint32_t hist_blocks, uint32_t launch_passes, const void* first_src, hipEvent_t one_at_a_time = nullptr, bool wait_for_it = false) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
     uint32_t* ticket = b.tile_status + size_t(kMaxPasses) * tiles * kRadix;
@@ -305,17 +305,24 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, hist_blocks, passes, pass_limit, b.digit_base);
     const bool hinted = pass_limit && launch_passes && launch_passes < passes && tiles <= P::kResident;
     const uint32_t launches = hinted ? launch_passes : passes;
-    for (uint32_t p = 0; p < launches; p++)
+    for (uint32_t p = 0; p < launches; p++) {
+        const bool to_limit = hinted && p + 1 == launches;
+        // A launch that may end up behind grid barriers must not share the chip with another one like it (two grids that
+        // each hold part of the CUs while waiting for the rest of their workgroups would wait forever): sorts running on
+        // different streams take turns for this one launch.
+        if (to_limit && one_at_a_time && wait_for_it) (void)hipStreamWaitEvent(stream, one_at_a_time, 0);
         hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                           hinted && p + 1 == launches ? 1u : 0u, tiles, b.digit_base, b.tile_status, ticket, pass_limit, first_src);
+                           to_limit ? 1u : 0u, tiles, b.digit_base, b.tile_status, ticket, pass_limit, first_src);
+        if (to_limit && one_at_a_time) (void)hipEventRecord(one_at_a_time, stream);
+    }
 }
 inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
                                uint32_t launch_passes = 0) {
     radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr);
 }
 inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                      uint32_t hist_blocks, uint32_t launch_passes) {
-    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz);
+                                      uint32_t hist_blocks, uint32_t launch_passes, hipEvent_t one_at_a_time, bool wait_for_it) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, one_at_a_time, wait_for_it);
 }
 
 }  // namespace chadhip

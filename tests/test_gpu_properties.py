@@ -209,3 +209,35 @@ def test_thousands_of_observations_of_one_voxel_in_one_frame(chad, oracle):
         few = want[2] < 200   # where the reference's own rounding is small, the usual bar holds
         assert rel_err(got[1][few], want[1][few], 0.10) <= SD_TOL
         m.close()
+
+
+def test_three_frames_in_flight_all_outgrow_the_enqueued_sort_passes(chad):
+    """Three consecutive large frames whose extent needs more sort passes than the previous frames' hint: each is finished
+    by its last pass launch running on behind grid barriers, and those launches take turns (three such grids at once
+    would not fit the chip together).  Device-resident, back to back, no synchronisation in between."""
+    import torch
+
+    small = [torch.from_numpy((synth.cfg2_frame(400_000, seed=31 + k)[0] * np.float32(0.1))).cuda() for k in range(3)]
+    wide = [synth.cfg3_frame(k, 1_000_000) for k in range(3)]   # 489 sort tiles each: three such grids exceed what the chip holds at once
+    wide_dev = [torch.from_numpy(p).cuda() for p, _ in wide]
+    pos = np.array([0.03, -0.02, 0.01], dtype=np.float32)
+    m = chad.TSDFMap(0.05, 0.10)
+    for d in small:
+        m.insert(d, pos)
+    m.sync()
+    few = m.stats()["sort_passes"]
+    for (_, p), d in zip(wide, wide_dev):
+        m.insert(d, p)
+    m.sync()
+    st = m.stats()
+    assert st["sort_passes"] > few and st["overflow"] == 0
+    # the three wide frames again, one at a time: same voxels, doubled weights
+    mc, sd, w = m.export_leaves()
+    ref = chad.TSDFMap(0.05, 0.10)
+    for d in small:
+        ref.insert(d, pos); ref.sync()
+    for (_, p), d in zip(wide, wide_dev):
+        ref.insert(d, p); ref.sync()
+    mc2, sd2, w2 = ref.export_leaves()
+    assert np.array_equal(mc, mc2) and np.array_equal(w, w2)
+    m.close(); ref.close()
