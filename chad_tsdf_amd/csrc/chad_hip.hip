@@ -118,6 +118,7 @@ struct chad_map {
     Submap active_copy;                           // dense snapshot of the active submap made for the last export call
     uint32_t* d_cursor = nullptr;                 // output cursor of k_compact_bricks
     uint64_t frames = 0, last_points_in = 0;
+    uint64_t frames_empty_tail = 0;               // empty inserts since the last one with points (they use no slot)
     // stage timing (CHAD_FLAG_TIMING): a ring of event sets, one per insert, read back lazily by chad_map_stats so
     // that timing adds no synchronisation to insert()
     static constexpr int kTimingRing = 64;
@@ -399,11 +400,10 @@ chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
     return CHAD_OK;
 }
 
-// tsdf.cpp:39-75 with the points already on the device
-chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t n, const float position[3]) {
-    if (n >= (1ull << 30)) return fail(CHAD_ERR_INVALID_ARG, "more than 2^30 points in one frame");
-    // submap bookkeeping, tsdf.cpp:46-61 (f32 distance in the reference's operation order; this file is built
-    // with -ffp-contract=off)
+// Submap bookkeeping of an insert, tsdf.cpp:46-61 (f32 distance in the reference's operation order; this file is built
+// with -ffp-contract=off): the first pose of a submap is remembered, and a frame taken more than 5 m from it closes the
+// submap and opens the next one.
+chad_status note_pose(chad_map* m, const float position[3]) {
     const std::array<float, 3> pose{position[0], position[1], position[2]};
     if (m->positions.empty()) m->positions.push_back(pose);
     else {
@@ -415,6 +415,23 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             m->positions.push_back(pose);
         } else m->positions.push_back(pose);
     }
+    return CHAD_OK;
+}
+
+// An insert without points is bookkeeping only (the frame-sharded multi-GPU map sends one to every rank that does not own
+// the frame): nothing is enqueued.
+chad_status insert_nothing(chad_map* m, const float position[3]) {
+    TRY(note_pose(m, position));
+    m->frames_empty_tail++;
+    m->last_points_in = 0;
+    return CHAD_OK;
+}
+
+// tsdf.cpp:39-75 with the points already on the device (n > 0)
+chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t n, const float position[3]) {
+    if (n >= (1ull << 30)) return fail(CHAD_ERR_INVALID_ARG, "more than 2^30 points in one frame");
+    TRY(note_pose(m, position));
+    m->frames_empty_tail = 0;
 
     TRY(grow_if_needed(m));
     const F3 pos{position[0], position[1], position[2]};
@@ -634,6 +651,7 @@ void chad_map_destroy(chad_map* m) {
 chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t n, const float position[3]) {
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
+    if (!n) return insert_nothing(m, position);
     FrameSlot* f = nullptr;
     TRY(prepare_slot(m, n, &f));
     return insert_device(m, *f, xyz_device, n, position);
@@ -642,6 +660,7 @@ chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t 
 chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float position[3]) {
     if (!m || !position || (n && !xyz)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
+    if (!n) return insert_nothing(m, position);
     FrameSlot* fp = nullptr;
     TRY(prepare_slot(m, n, &fp));
     FrameSlot& f = *fp;
@@ -740,12 +759,13 @@ chad_status chad_map_stats(chad_map* m, chad_stats* out) {
     TRY(read_block_count(m, &blocks));
     collect_timing(m);
     std::memset(out, 0, sizeof(*out));
-    out->frames = m->frames; out->points_in = m->last_points_in; out->points_used = m->h_hdr->n_usable;
+    const bool last_empty = m->frames_empty_tail != 0;   // the last insert had no points: its frame counters are zero
+    out->frames = m->frames + m->frames_empty_tail; out->points_in = m->last_points_in; out->points_used = last_empty ? 0 : m->h_hdr->n_usable;
     out->updates = 0;
-    for (int k = 0; k < 32; k++) out->updates += m->h_hdr->n_updates[k * 16];
+    if (!last_empty) for (int k = 0; k < 32; k++) out->updates += m->h_hdr->n_updates[k * 16];
     out->blocks = blocks; out->block_capacity = m->brick_capacity;
     out->hash_capacity = m->hash_capacity; out->closed_submaps = m->closed.size();
-    out->sort_passes = m->h_hdr->sort_passes; out->overflow = overflow;
+    out->sort_passes = last_empty ? 0 : m->h_hdr->sort_passes; out->overflow = overflow;
     out->ms_mc_calc = m->ms[T_CALC]; out->ms_mc_sort = m->ms[T_SORT]; out->ms_norm_est = m->ms[T_NORM];
     out->ms_oct_upd = m->ms[T_UPD]; out->ms_total = m->ms[T_BEGIN];
     return CHAD_OK;
@@ -835,7 +855,7 @@ chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, floa
     uint32_t overflow = 0;
     TRY(read_back_header(m, &overflow));
     const FrameSlot& f = m->slot[m->last_slot];
-    const size_t n = m->frames ? m->h_hdr->n_usable : 0;
+    const size_t n = m->frames && !m->frames_empty_tail ? m->h_hdr->n_usable : 0;
     *count = n;
     const size_t k = std::min(n, capacity);
     if (!k) return CHAD_OK;
