@@ -241,3 +241,23 @@ def test_three_frames_in_flight_all_outgrow_the_enqueued_sort_passes(chad):
     mc2, sd2, w2 = ref.export_leaves()
     assert np.array_equal(mc, mc2) and np.array_equal(w, w2)
     m.close(); ref.close()
+
+
+def test_sharded_map_with_one_rank_equals_the_plain_map(chad):
+    """ShardedTSDFMap (sharded.py) without a process group is a one-rank world: its roll-over goes through the merge path
+    (unordered block export -> close_submap_with_blocks) and must leave the same submaps as the plain map's own roll-over."""
+    from chad_tsdf_amd.sharded import ShardedTSDFMap
+
+    plain = chad.TSDFMap(0.05, 0.10)
+    shard = ShardedTSDFMap(0.05, 0.10)
+    for k in range(26):   # poses 0.25 m apart: roll-over when frame 21 arrives (5.25 m > 5.0 m)
+        pts, _ = synth.cfg3_frame(5 * k, 20_000)
+        pos = np.array([-12.0 + 0.25 * k, 0.1, 0.0], dtype=np.float32)
+        plain.insert(pts, pos)
+        shard.insert(pts, pos)
+    plain.sync(); shard.local.sync()
+    assert plain.closed_submaps == shard.closed_submaps == 1
+    for got, want in ((shard.export_leaves(0), plain.export_leaves(0)), (shard.local.export_leaves(-1), plain.export_leaves(-1))):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+        assert rel_err(got[1], want[1], 0.10) <= SD_TOL   # f32 atomic sums: the order of arrival differs from run to run
+    plain.close(); shard.local.close()
