@@ -30,8 +30,9 @@
 // every wave loads the NEXT item's first chunk of points and the home hash slots of its 16 bricks (speculative,
 // nothing is created), and the next item's record itself was fetched by wave 0 during the walk.
 // Work items: the first one is static (workgroup index), the rest are pulled from 256 separate counters (a
-// returning atomic on ONE shared address serialises at ~25 ns per dequeue).  Sparse frames (few points per block)
-// skip this kernel and take k_update_scatter instead: with one point per block the staging is pure overhead.
+// returning atomic on ONE shared address serialises at ~25 ns per dequeue).  Sparse frames (few points per block): in
+// automatic mode the kernel notices (device memory) and runs the scatter form (map_kernels.hpp, scatter_update) on its
+// own grid instead -- with one point per block the staging is pure overhead.
 #pragma once
 #include <hip/hip_ext.h>
 
