@@ -1,0 +1,65 @@
+"""The N > 1 path with the real single-device map: two processes share the one GPU of the test box, exchange over gloo
+(sharded.py then runs its collectives on host copies), frames dealt round-robin, one merge at the roll-over.  Every rank
+must end up with the submaps a single process builds from the whole stream."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    from chad_tsdf_amd import synth
+
+    out = []
+    for k in range(26):   # poses 0.25 m apart: roll-over when frame 21 arrives (5.25 m > 5.0 m)
+        pts, _ = synth.cfg3_frame(5 * k, 20_000)
+        out.append((pts, np.array([-12.0 + 0.25 * k, 0.1, 0.0], dtype=np.float32)))
+    return out
+
+
+def _rank(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chad_tsdf_amd.sharded import ShardedTSDFMap
+
+    sm = ShardedTSDFMap(0.05, 0.10)
+    for k, (pts, pos) in enumerate(_stream()):
+        sm.insert(pts if k % world == rank else None, pos)
+    sm.merge_and_close()   # the active submap (5 frames) as well
+    assert sm.closed_submaps == 2
+    for s in (0, 1):
+        mc, sd, w = sm.export_leaves(s)
+        np.savez(os.path.join(outdir, f"rank{rank}_submap{s}.npz"), mc=mc, sd=sd, w=w)
+    sm.local.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_build_the_single_process_submaps(tmp_path):
+    import torch.multiprocessing as mp
+
+    import chad_tsdf_amd
+    from tests.util import SD_TOL
+
+    world, port = 2, 29533
+    mp.spawn(_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    single = chad_tsdf_amd.TSDFMap(0.05, 0.10)
+    for pts, pos in _stream():
+        single.insert(pts, pos)
+    single.close_submap()
+    for s in (0, 1):
+        want = single.export_leaves(s)
+        for rank in range(world):
+            got = np.load(tmp_path / f"rank{rank}_submap{s}.npz")
+            assert np.array_equal(got["mc"], want[0]) and np.array_equal(got["w"], want[2]), f"rank {rank} submap {s}"
+            err = np.abs(got["sd"] - want[1]) / np.maximum(np.abs(want[1]), 0.10)
+            assert err.max() <= SD_TOL
+    single.close()
