@@ -1,0 +1,51 @@
+"""The drop-in C++ class (include/chad/tsdf.hpp over the C ABI): a program written against the reference's public header
+compiles and links here without a GPU, and on a GPU its map equals the oracle's."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "api_check.cpp")
+LIB_DIR = os.path.join(ROOT, "chad_tsdf_amd", "lib")
+
+
+def _build(out_dir):
+    if not os.path.exists(os.path.join(LIB_DIR, "libchad_hip.so")):
+        subprocess.check_call(["make", "-C", ROOT, "-s"])
+    cxx = shutil.which("g++") or "/opt/rocm/bin/hipcc"
+    exe = os.path.join(out_dir, "api_check")
+    subprocess.check_call([cxx, "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe, "-L", LIB_DIR, "-lchad_hip",
+                           "-L/opt/rocm/lib", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_reference_style_program_compiles_and_links(tmp_path):
+    assert os.path.exists(_build(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_cpp_class_builds_the_oracles_map(tmp_path):
+    from chad_tsdf_amd import synth
+    from oracle import pyoracle
+    from tests.util import SD_TOL
+
+    exe = _build(str(tmp_path))
+    pts, pos = synth.cfg2_frame(90_000, seed=13)
+    pts.tofile(tmp_path / "points.f32")
+    out = tmp_path / "leaves.bin"
+    run = subprocess.run([exe, str(tmp_path / "points.f32"), repr(float(pos[0])), repr(float(pos[1])), repr(float(pos[2])), str(out)],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    raw = out.read_bytes()
+    n = int(np.frombuffer(raw[:8], np.uint64)[0])
+    mc = np.frombuffer(raw[8:8 + 8 * n], np.uint64)
+    sd = np.frombuffer(raw[8 + 8 * n:8 + 12 * n], np.float32)
+    w = np.frombuffer(raw[8 + 12 * n:8 + 16 * n], np.uint32)
+    o = pyoracle.OracleMap(0.05, 0.10)
+    o.insert(pts, pos)
+    omc, osd, ow = o.export_leaves()
+    assert np.array_equal(mc, omc) and np.array_equal(w, ow)
+    assert (np.abs(sd - osd) / np.maximum(np.abs(osd), 0.10)).max() <= SD_TOL
