@@ -116,6 +116,15 @@ struct chad_map {
     std::vector<std::array<float, 3>> positions;  // poses of the active submap (submap.hpp:110)
     std::vector<Submap> closed;                   // tsdf.cpp:54
     Submap active_copy;                           // dense snapshot of the active submap made for the last export call
+    // Roll-over without a pipeline stall: the active table is swapped for an empty spare one of the same size and is
+    // archived (counted, compacted into a dense closed submap, cleared) on the map's stream behind the frames, the host
+    // part of it -- sizing the archive -- whenever the count has arrived.  At most one submap is closing at a time.
+    MapView spare{};
+    bool has_spare = false;
+    MapView closing_view{};
+    bool closing = false;
+    hipEvent_t closing_counted = nullptr;         // the closing table's block count has reached closing_count
+    uint32_t* closing_count = nullptr;            // pinned: the counter stripes of the closing table
     uint32_t* d_cursor = nullptr;                 // output cursor of k_compact_bricks
     uint64_t frames = 0, last_points_in = 0;
     uint64_t frames_empty_tail = 0;               // empty inserts since the last one with points (they use no slot)
@@ -285,14 +294,56 @@ chad_status compact_active(chad_map* m, Submap& s, uint32_t blocks) {
     return CHAD_OK;
 }
 
-// Submap roll-over (tsdf.cpp:52-57): archive the active submap's bricks and start an empty one.
-chad_status close_active(chad_map* m) {
+// Second half of a roll-over: the closing table's block count is on the host (or is waited for if `block`): size the
+// archive, compact the table into it and clear it -- all on the map's stream, beside the frames that already fill the new
+// active table -- and keep the cleared table as the next spare.
+chad_status finish_closing(chad_map* m, bool block) {
+    if (!m->closing) return CHAD_OK;
+    if (block) HIP_TRY(hipEventSynchronize(m->closing_counted));
+    else if (hipEventQuery(m->closing_counted) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
     uint32_t blocks = 0;
-    TRY(read_block_count(m, &blocks));
+    for (uint32_t k = 0; k < kCountStripes; k++) blocks += m->closing_count[k * 16];
     Submap s;
-    TRY(compact_active(m, s, blocks));
+    TRY(alloc_submap(s, blocks));
+    if (blocks) {
+        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
+        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, m->d_cursor, blocks, s.keys, s.sum, s.cnt);
+    }
+    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, 0u);
+    HIP_TRY(hipGetLastError());
     m->closed.push_back(s);
-    return clear_active(m);
+    m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: whoever swaps it in does so on this stream
+    m->closing_view = MapView{}; m->closing = false;
+    return CHAD_OK;
+}
+
+// Submap roll-over (tsdf.cpp:52-57): archive the active submap's bricks and start an empty one -- by swapping tables, so
+// that the frames behind the roll-over do not wait for the archive (a synchronous roll-over drained the three frames in
+// flight, sized the archive on the host and compacted: ~1 ms per roll-over, 13 % of the cfg3 stream).
+chad_status close_active(chad_map* m) {
+    TRY(finish_closing(m, true));          // at most one submap closes at a time (roll-overs are many frames apart)
+    TRY(flush_pending_clear(m));
+    if (!m->has_spare) {                   // first roll-over, or the table has grown since: an empty table of the same size
+        if (alloc_map_storage(m->spare, m->brick_capacity, m->stream, m->d_overflow) != CHAD_OK) {
+            // no room for a second table: the synchronous way
+            free_map_storage(m->spare);
+            g_error.clear();
+            uint32_t blocks = 0;
+            TRY(read_block_count(m, &blocks));
+            Submap s;
+            TRY(compact_active(m, s, blocks));
+            m->closed.push_back(s);
+            return clear_active(m);
+        }
+        m->has_spare = true;
+    }
+    TRY(exclusive_begin(m));               // the map's stream waits for every update enqueued so far ...
+    HIP_TRY(hipMemcpyAsync(m->closing_count, m->view.brick_count, kCountStripes * 64, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipEventRecord(m->closing_counted, m->stream));
+    m->closing_view = m->view; m->closing = true;
+    m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
+    *m->h_live_blocks = 0;
+    return exclusive_end(m, m->stream);    // ... and later updates (into the new table) wait for this point: the spare is ready
 }
 
 chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const uint64_t** keys, const float** sum, const uint32_t** cnt) {
@@ -304,6 +355,7 @@ chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const u
         *keys = m->active_copy.keys; *sum = m->active_copy.sum; *cnt = m->active_copy.cnt;
         return CHAD_OK;
     }
+    TRY(finish_closing(m, true));
     if (size_t(submap) >= m->closed.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
     HIP_TRY(hipStreamSynchronize(m->stream));
     const Submap& s = m->closed[size_t(submap)];
@@ -344,6 +396,9 @@ chad_status grow_if_needed(chad_map* m) {
     uint32_t live = 0;
     TRY(read_block_count(m, &live));
     if (live < m->brick_capacity / 2) return CHAD_OK;
+    TRY(finish_closing(m, true));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->has_spare) { free_map_storage(m->spare); m->has_spare = false; }   // the next roll-over allocates one of the new size
     MapView bigger;
     const uint64_t blocks = std::min<uint64_t>(uint64_t(m->brick_capacity) * 2, 1ull << 30);
     const chad_status s = alloc_map_storage(bigger, blocks, m->stream, m->d_overflow);
@@ -431,6 +486,7 @@ chad_status insert_nothing(chad_map* m, const float position[3]) {
 chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t n, const float position[3]) {
     if (n >= (1ull << 30)) return fail(CHAD_ERR_INVALID_ARG, "more than 2^30 points in one frame");
     TRY(note_pose(m, position));
+    TRY(finish_closing(m, false));   // a roll-over's archive, once its size is known (never waits)
     m->frames_empty_tail = 0;
 
     TRY(grow_if_needed(m));
@@ -586,6 +642,8 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     }
     CREATE_TRY(hipEventCreateWithFlags(&m->excl_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->sort_turn, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&m->closing_counted, hipEventDisableTiming));
+    CREATE_TRY(hipHostMalloc(&m->closing_count, kCountStripes * 64));
     if (!m->own_stream) CREATE_TRY(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
     CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
@@ -637,6 +695,10 @@ void chad_map_destroy(chad_map* m) {
     if (m->caller_ready) (void)hipEventDestroy(m->caller_ready);
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
     if (m->sort_turn) (void)hipEventDestroy(m->sort_turn);
+    if (m->closing_counted) (void)hipEventDestroy(m->closing_counted);
+    if (m->closing_count) (void)hipHostFree(m->closing_count);
+    if (m->closing) free_map_storage(m->closing_view);
+    if (m->has_spare) free_map_storage(m->spare);
     for (auto& s : m->closed) free_submap(s);
     free_submap(m->active_copy);
     free_map_storage(m->view);
@@ -702,6 +764,7 @@ chad_status chad_map_sync(chad_map* m) {
 chad_status chad_map_reset(chad_map* m) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
+    TRY(finish_closing(m, true));
     if (!m->closed.empty()) {
         TRY(join_streams(m));
         for (auto& s : m->closed) free_submap(s);
@@ -764,7 +827,7 @@ chad_status chad_map_stats(chad_map* m, chad_stats* out) {
     out->updates = 0;
     if (!last_empty) for (int k = 0; k < 32; k++) out->updates += m->h_hdr->n_updates[k * 16];
     out->blocks = blocks; out->block_capacity = m->brick_capacity;
-    out->hash_capacity = m->hash_capacity; out->closed_submaps = m->closed.size();
+    out->hash_capacity = m->hash_capacity; out->closed_submaps = m->closed.size() + (m->closing ? 1 : 0);
     out->sort_passes = last_empty ? 0 : m->h_hdr->sort_passes; out->overflow = overflow;
     out->ms_mc_calc = m->ms[T_CALC]; out->ms_mc_sort = m->ms[T_SORT]; out->ms_norm_est = m->ms[T_NORM];
     out->ms_oct_upd = m->ms[T_UPD]; out->ms_total = m->ms[T_BEGIN];
@@ -777,6 +840,7 @@ chad_status chad_map_block_count(chad_map* m, int32_t submap, size_t* blocks) {
     uint32_t nb = 0;
     if (submap < 0) TRY(read_block_count(m, &nb));
     else {
+        TRY(finish_closing(m, true));
         if (size_t(submap) >= m->closed.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
         nb = m->closed[size_t(submap)].blocks;
     }
@@ -835,6 +899,7 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
     if (!m || (blocks && (!keys_device || !sum_device || !cnt_device))) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     if (blocks > 0xffffffffull) return fail(CHAD_ERR_INVALID_ARG, "too many blocks");
     DeviceGuard guard(m->device);
+    TRY(finish_closing(m, true));
     Submap s;
     TRY(alloc_submap(s, uint32_t(blocks)));
     if (blocks) {
