@@ -274,3 +274,21 @@ def test_block_pool_grows_between_frames(chad, oracle):
     assert st["overflow"] == 0 and st["block_capacity"] == 40_000 and st["blocks"] == int(o.stats()["blocks"])
     assert_leaves_match(m.export_leaves(), o.export_leaves(), 0.10)
     m.close()
+
+
+def test_a_roll_over_on_every_frame(chad, oracle):
+    """Poses 6 m apart: every insert closes the previous submap (tsdf.cpp:52-57) while the one before may still be on its way
+    into the archive (the roll-over swaps tables and archives behind the frames).  Each closed submap holds exactly one
+    frame and must equal the oracle's."""
+    m = chad.TSDFMap(0.05, 0.10)
+    o = oracle.OracleMap(0.05, 0.10)
+    for k in range(6):
+        pts, _ = synth.cfg3_frame(40 * k, 30_000)
+        pos = np.array([-12.0 + 6.0 * k, 0.1, 0.0], dtype=np.float32)
+        m.insert(pts, pos)
+        o.insert(pts, pos)
+    m.sync()
+    assert m.closed_submaps == o.closed_submaps == 5
+    for s in (0, 1, 2, 3, 4, -1):
+        assert_leaves_match(m.export_leaves(s), o.export_leaves(s), 0.10)
+    m.close()
