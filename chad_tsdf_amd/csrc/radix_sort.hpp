@@ -25,13 +25,13 @@ constexpr int kSortThreads = 256;                       // 4 waves
 constexpr int kSortItems = 8;                           // keys per thread
 constexpr int kSortTile = kSortThreads * kSortItems;    // 2048 keys per workgroup (1024-key tiles: twice the look-back chain, 11 % slower)
 constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kLookback = 8;                            // predecessor tiles read per round trip of the look-back (32: more traffic, 17 % slower)
+constexpr int kLookback = 8;                            // look-back rows read per round trip (independent loads)
 constexpr int kHistBlocks = 256;                        // workgroups of the histogram kernel (one partial table each)
 constexpr int kMaxHistBlocks = 512;                     // partial tables the buffers have room for
 
-constexpr uint32_t kStatusAggregate = 1u << 30;         // the tile's own digit counts are published
-constexpr uint32_t kStatusInclusive = 2u << 30;         // counts of this tile AND all tiles before it
+constexpr uint32_t kStatusPublished = 1u << 30;         // flag of a look-back word: the count in its low 30 bits is valid
 constexpr uint32_t kStatusValue = (1u << 30) - 1;
+constexpr uint32_t kGroupTiles = 32;                    // tiles per group of the two-level look-back
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -70,13 +70,15 @@ struct RadixSortBuffers {
     uint4* points[2];       // PointPayload ping-pong buffers (null for sorters that only carry indices)
     uint32_t* hist_part;    // [kHistBlocks][kMaxPasses][256] partial digit histograms
     uint32_t* digit_base;   // [kMaxPasses][256] keys per digit (totals; every pass workgroup scans them)
-    uint32_t* tile_status;  // [kMaxPasses][tiles][256] look-back words, zeroed before every sort
+    uint32_t* tile_status;  // [kMaxPasses][tiles + groups][256] look-back words, zeroed before every sort
     uint32_t* tile_ticket;  // [kMaxPasses] next tile to hand out, zeroed with tile_status (stored right behind it)
     uint32_t tiles_capacity;
 };
 
 inline uint32_t radix_tiles(size_t n) { return uint32_t((n + kSortTile - 1) / kSortTile); }
-inline size_t radix_status_words(uint32_t tiles) { return size_t(kMaxPasses) * tiles * kRadix + 64; }
+__host__ __device__ inline uint32_t radix_groups(uint32_t tiles) { return (tiles + kGroupTiles - 1) / kGroupTiles; }
+// look-back words of all passes ([pass][tile rows, then group rows][256]) and 64 ticket / barrier words behind them
+inline size_t radix_status_words(uint32_t tiles) { return size_t(kMaxPasses) * (tiles + radix_groups(tiles)) * kRadix + 64; }
 
 // pass_limit (device word, may be null): passes >= *pass_limit are skipped by every kernel.
 // Also clears the look-back table of the coming passes (saves a memset launch).
@@ -186,8 +188,11 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     uint32_t count = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kSortWaves; w++) { const uint32_t c = wave_count[w][d]; wave_count[w][d] = count; count += c; }
-    uint32_t* status = tile_status + (size_t(pass) * tiles + tile) * kRadix;
-    __hip_atomic_store(&status[d], (tile == 0 ? kStatusInclusive : kStatusAggregate) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this pass's words: one row of 256 per tile (the tile's own digit counts), then one row per group of kGroupTiles tiles
+    // (the group's digit counts)
+    const uint32_t groups = radix_groups(tiles);
+    uint32_t* region = tile_status + size_t(pass) * (tiles + groups) * kRadix;
+    __hip_atomic_store(&region[size_t(tile) * kRadix + d], kStatusPublished | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // exclusive scans over the digits: of the tile's counts (position of digit d's run in the locally sorted tile) and of
     // the whole input's counts (first output slot of digit d; k_radix_bases left the per-digit totals)
@@ -206,30 +211,33 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     uint32_t local_excl = incl - count, first_slot = incl_all - total;
     for (uint32_t w = 0; w < (d >> 6); w++) { local_excl += wave_total[w]; first_slot += wave_total_all[w]; }
 
-    // decoupled look-back: keys of digit d in all earlier tiles.  kLookback predecessors are read per round trip
-    // (independent loads), then consumed nearest first; a word that is not published yet is re-polled alone.
-    uint32_t earlier = 0;
-    for (int t = int(tile) - 1; t >= 0;) {
-        uint32_t word[kLookback];
+    // Keys of digit d in all earlier tiles, in two levels.  The tiles of a launch start together, so a chained look-back
+    // finds only un-summed counts for a long way back (the nearest running total is ~4 r^2 tiles away after r round
+    // trips: ~11 dependent round trips for 489 tiles, 14 us of every pass).  Instead: the last tile of every group of
+    // kGroupTiles sums its group's rows and publishes the group's counts; a tile adds the counts of the lower groups and
+    // of the lower tiles of its own group -- three dependent round trips whatever the number of tiles.  Every wait is for
+    // a lower tile, as before.
+    auto sum_rows = [&](const uint32_t* first_row, uint32_t rows) {   // sum of word d of `rows` consecutive rows, waiting for each to be published
+        uint32_t sum = 0;
+        for (uint32_t r0 = 0; r0 < rows; r0 += kLookback) {
+            uint32_t word[kLookback];
 #pragma unroll
-        for (int k = 0; k < kLookback; k++) {
-            const int tk = t - k;
-            word[k] = tk >= 0 ? __hip_atomic_load(tile_status + (size_t(pass) * tiles + uint32_t(tk)) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusInclusive;
-        }
-        bool done = false;
+            for (uint32_t k = 0; k < kLookback; k++)
+                word[k] = r0 + k < rows ? __hip_atomic_load(first_row + size_t(r0 + k) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusPublished;
 #pragma unroll
-        for (int k = 0; k < kLookback; k++) {
-            if (done) continue;
-            uint32_t w = word[k];
-            while ((w & ~kStatusValue) == 0)
-                w = __hip_atomic_load(tile_status + (size_t(pass) * tiles + uint32_t(t - k)) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            earlier += w & kStatusValue;
-            done = (w & kStatusInclusive) != 0;
+            for (uint32_t k = 0; k < kLookback; k++) {
+                uint32_t w = word[k];
+                while ((w & kStatusPublished) == 0) w = __hip_atomic_load(first_row + size_t(r0 + k) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sum += w & kStatusValue;
+            }
         }
-        if (done) break;
-        t -= kLookback;
-    }
-    if (tile != 0) __hip_atomic_store(&status[d], kStatusInclusive | (earlier + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return sum;
+    };
+    const uint32_t group = tile / kGroupTiles, in_group = tile % kGroupTiles;
+    uint32_t earlier = sum_rows(region + size_t(group) * kGroupTiles * kRadix, in_group);          // lower tiles of this group
+    if (in_group == kGroupTiles - 1 || tile == tiles - 1)                                             // last tile of the group: its counts, for the higher groups
+        __hip_atomic_store(&region[size_t(tiles + group) * kRadix + d], kStatusPublished | (earlier + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    earlier += sum_rows(region + size_t(tiles) * kRadix, group);                                      // lower groups
     offset[d] = int(first_slot + earlier) - int(local_excl);
     // wave_count[w][d] becomes the local sorted position of wave w's first key of digit d
 #pragma unroll
@@ -296,7 +304,7 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
                                   uint32_t hist_blocks, uint32_t launch_passes, const void* first_src, hipEvent_t one_at_a_time = nullptr, bool wait_for_it = false) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
-    uint32_t* ticket = b.tile_status + size_t(kMaxPasses) * tiles * kRadix;
+    uint32_t* ticket = b.tile_status + radix_status_words(tiles) - 64;
     if (hist_blocks == 0) {
         hist_blocks = kHistBlocks;
         hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part, b.tile_status,
