@@ -7,9 +7,9 @@
 //   k_radix_bases       sums the partials -> keys per digit and pass (the pass kernel scans those 256 values itself);
 //   k_radix_onesweep    ONE kernel per pass: a workgroup ranks its tile (wave64 ballot matching inside a wave,
 //                       per-wave digit counters in LDS across waves), learns how many keys of each digit precede
-//                       its tile from its predecessors' published counts (decoupled look-back over 32-bit
-//                       {flag, count} words, so no separate payload needs release/acquire ordering), reorders the
-//                       tile in LDS and writes runs of equal digits to consecutive addresses.
+//                       its tile from the counts its predecessors publish (32-bit {flag, count} words, so no separate
+//                       payload needs release/acquire ordering; two levels: tiles, and groups of 32 tiles), reorders the
+//                       tile's keys in LDS and writes runs of equal digits to consecutive addresses.
 // The number of passes is data dependent (key width of the frame) and lives in device memory: the host enqueues
 // the maximum and surplus passes return at once, so no host round trip sits between the stages of a frame.
 #pragma once
