@@ -77,7 +77,6 @@ struct FrameSlot {
     float* h_stage = nullptr;           // pinned staging buffer for chad_map_insert (host points), cap_points * 12 bytes
     hipEvent_t stage_done = nullptr;    // the H2D copies out of h_stage have completed
     RadixSortBuffers sort{};
-    uint64_t* d_codes = nullptr;
     float4* d_normals = nullptr;
     uint32_t* d_seg = nullptr;
 };
@@ -164,8 +163,8 @@ void free_frame_buffers(FrameSlot& f) {
     (void)hipFree(f.sort.idx[0]); (void)hipFree(f.sort.idx[1]); (void)hipFree(f.sort.hist_part);
     (void)hipFree(f.sort.digit_base); (void)hipFree(f.sort.tile_status);
     (void)hipFree(f.sort.points[0]); (void)hipFree(f.sort.points[1]);
-    (void)hipFree(f.d_codes); (void)hipFree(f.d_normals); (void)hipFree(f.d_seg);
-    f.d_xyz = nullptr; f.sort = RadixSortBuffers{}; f.d_codes = nullptr; f.d_normals = nullptr; f.d_seg = nullptr;
+    (void)hipFree(f.d_normals); (void)hipFree(f.d_seg);
+    f.d_xyz = nullptr; f.sort = RadixSortBuffers{}; f.d_normals = nullptr; f.d_seg = nullptr;
     f.cap_points = 0;
 }
 
@@ -208,7 +207,6 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kMaxPasses) * kRadix * 4));
     HIP_TRY(hipMalloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     f.sort.tiles_capacity = radix_tiles(cap);
-    HIP_TRY(hipMalloc(&f.d_codes, cap * 8));
     HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
     HIP_TRY(hipMalloc(&f.d_seg, cap * 24));  // point blocks uint2 [cap] (start, length | flag), update work items uint4 [cap] (start, length, super-block code)
     f.cap_points = cap;
@@ -510,10 +508,10 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         hipLaunchKernelGGL(k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                           points0, points1, f.d_codes, reinterpret_cast<uint2*>(f.d_seg), item_start, uint32_t(f.cap_points));
+                           points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, uint32_t(f.cap_points));
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.d_codes, reinterpret_cast<const uint2*>(f.d_seg), f.d_hdr, pos, f.d_normals, m->ablate);
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), f.d_hdr, pos, f.d_normals, m->ablate);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -929,7 +927,15 @@ chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, floa
         HIP_TRY(hipMemcpy(tmp.data(), f.sort.points[m->h_hdr->sort_passes & 1u], k * 16, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; i++) std::memcpy(&order[i], &tmp[4 * i + 3], 4);
     }
-    if (mc) HIP_TRY(hipMemcpy(mc, f.d_codes, k * 8, hipMemcpyDeviceToHost));
+    if (mc) {  // the codes are not kept (the frame kernels work from the sort keys): recompute them from the points
+        uint64_t* d_mc = nullptr;
+        HIP_TRY(hipMalloc(&d_mc, k * 8));
+        hipLaunchKernelGGL(k_morton_codes_of_points, grid_for(k, 256, 1 << 22), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(f.sort.points[m->h_hdr->sort_passes & 1u]),
+                           uint32_t(k), m->recip, d_mc);
+        HIP_TRY(hipMemcpyAsync(mc, d_mc, k * 8, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        (void)hipFree(d_mc);
+    }
     if (normals) {
         HIP_TRY(hipMemcpy(tmp.data(), f.d_normals, k * 16, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; i++) std::memcpy(&normals[3 * i], &tmp[4 * i], 12);

@@ -252,8 +252,7 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
     }
 }
 
-// Stage 3 (after the sort, which has carried the points along as float4 (x, y, z, input index)): recompute
-// their global codes, and list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
+// Stage 3 (after the sort, which has carried the points along as float4 (x, y, z, input index)): list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
 // normal estimation and (b) the update work items (start, length, super-block code) in items[]: the super blocks (runs
 // of equal code >> 9) cut again at every kItemPoints-th point, so that no item is longer than kItemPoints.  A workgroup collects its entries in
 // LDS (block heads as a list, item starts as a 2048-bit mask whose next set bit gives an item's length) and
@@ -263,7 +262,7 @@ __global__ void __launch_bounds__(256)
 k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const float4* __restrict__ points0, const float4* __restrict__ points1,
-               uint64_t* codes, uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t items_capacity) {
+               uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t items_capacity) {
     constexpr uint32_t kWords = kGatherChunk / 32;
     __shared__ uint32_t mark_bits[kWords], head_bits[kWords];  // bit k: point k of the chunk starts a work item / a point block
     __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
@@ -285,6 +284,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
         __syncthreads();
     }
     const unsigned long long mc_min = block_mc_min;
+    const I3 v_min = morton_decode(mc_min);   // the voxel of the frame's smallest code (wave-uniform)
     const uint32_t n = h->n_usable;
     const bool odd = h->sort_passes & 1u;
     const uint64_t* keys = odd ? keys1 : keys0;
@@ -302,12 +302,10 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
                 const uint64_t kcur = keys[i], kprev = i ? keys[i - 1] : ~0ull;   // nothing precedes point 0: it opens a block
                 const float4 q = pts[i];
                 const I3 v = voxel_of(F3{q.x, q.y, q.z}, recip);
-                const uint64_t mc = morton_encode(v.x, v.y, v.z);
-                codes[i] = mc;
                 const bool head = (kcur >> 6) != (kprev >> 6), super_head = (kcur >> 9) != (kprev >> 9);
                 if (head) atomicOr(&head_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (super_head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
-                if (mc == mc_min) atomicMax(&h->last_idx, __float_as_uint(q.w));
+                if (v.x == v_min.x && v.y == v_min.y && v.z == v_min.z) atomicMax(&h->last_idx, __float_as_uint(q.w));   // a point of the frame's smallest code
             }
         }
         __syncthreads();
@@ -360,7 +358,9 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             if (k >= chunk_len) continue;
             const uint32_t word = mark_bits[k >> 5], hword = head_bits[k >> 5];
             if (!(((word | hword) >> bit) & 1u)) continue;
-            const uint64_t code = codes[c * kGatherChunk + k];  // written by this very thread above
+            const float4 q = pts[c * kGatherChunk + k];
+            const I3 v = voxel_of(F3{q.x, q.y, q.z}, recip);
+            const uint64_t code = morton_encode(v.x, v.y, v.z);   // only the few threads that open a block or an item get here
             if ((word >> bit) & 1u) {
                 const uint64_t corner = code & ~511ull;  // corner of the 8x8x8 super block
                 const uint32_t at = item_len[j] > kBigItem ? base_big + item_slot[j] : items_capacity - 1u - (base_small + item_slot[j]);
@@ -488,19 +488,19 @@ __device__ __forceinline__ double team_sum_f64(double v) {
     return v;
 }
 
-// Length of the run of points of `block` starting at `first` (codes sorted by block), capped at `limit`.
+// Length of the run of points of `block` (sort key >> 6) starting at `first`, capped at `limit`.
 // Two dependent loads instead of one per 64 points: lanes first probe the starts of the next 64 chunks of 64
 // points, then the points of the chunk where the run ends.  Wave-uniform result.
-__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ codes, uint32_t first, uint32_t limit, uint64_t block, uint32_t lane) {
+__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ keys, uint32_t first, uint32_t limit, uint64_t block, uint32_t lane) {
     uint32_t len = 0;
     for (;;) {
         const uint32_t probe = first + len + 64u * (lane + 1u);                 // first point of chunk lane+1
-        const uint64_t more = __ballot(probe < limit && (codes[probe] >> 6) == block);
+        const uint64_t more = __ballot(probe < limit && (keys[probe] >> 6) == block);
         const uint32_t full = more == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~more)) - 1u;  // chunks 1..full start inside the run
         len += 64u * full;
         if (full == 64u) continue;                                               // the run is longer than 4160 points: go on
         const uint32_t i = first + len + lane;                                   // the chunk where the run ends
-        const uint64_t same = __ballot(i < limit && (codes[i] >> 6) == block);
+        const uint64_t same = __ballot(i < limit && (keys[i] >> 6) == block);
         return len + (same == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~same)) - 1u);
     }
 }
@@ -510,10 +510,13 @@ constexpr int kNormalWavesPerBlock = 1;  // one wave per workgroup: __syncthread
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 
 __global__ void __launch_bounds__(64 * kNormalWavesPerBlock, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
-k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ points1, const uint64_t* __restrict__ codes, const uint2* __restrict__ segments,
+k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ points1, const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+                const uint2* __restrict__ segments,
                 FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
     __shared__ NormalScratch s;
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
+    // ... and their keys: key >> 6 is the point's block, 63 - (key & 63) its voxel in the block (the low 6 code bits)
+    const uint64_t* __restrict__ keys = (h->sort_passes & 1u) ? keys1 : keys0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = h->n_usable, nseg = h->n_segments;
 
@@ -522,7 +525,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
         // fourteen) still has to find its length by probing -- two dependent loads that every block used to pay
         const uint32_t first = record.x;
         uint32_t len = record.y & 0x7fffffffu;
-        if (len == 0u) len = run_length(codes, first, n, codes[first] >> 6, lane);
+        if (len == 0u) len = run_length(keys, first, n, keys[first] >> 6, lane);
         // normals.hpp:100 -- the frame's last point never joins a neighbourhood; it is the last point of this segment
         const bool holds_last = (record.y >> 31) != 0u;
         const uint32_t grouped = holds_last ? len - 1 : len;
@@ -531,7 +534,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
         s.count[lane] = 0;
         __syncthreads();
         for (uint32_t k = lane; k < len; k += 64) {
-            const uint32_t v = uint32_t(codes[first + k]) & 63u;
+            const uint32_t v = 63u - (uint32_t(keys[first + k]) & 63u);
             if (k < kStagePoints) s.stage[k] = pts[first + k];
             if (k < grouped) atomicAdd(&s.count[v], 1u);
         }
@@ -635,7 +638,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
             F3 nrm;
             bool fitted = false;
             if (k < grouped) {
-                const uint32_t g = s.group_of[uint32_t(codes[first + k]) & 63u];
+                const uint32_t g = s.group_of[63u - (uint32_t(keys[first + k]) & 63u)];
                 fitted = s.g_normal[g][3] != 0.0f;
                 nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
             }

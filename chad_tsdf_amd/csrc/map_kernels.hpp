@@ -130,6 +130,15 @@ __global__ void k_walk_rays(const float* __restrict__ xyz, uint32_t n, F3 pos, f
     counts[i] = k;
 }
 
+// Morton codes of a frame's points in processing order (float4 x, y, z, index): the stage read-back of chad_map_last_frame
+__global__ void k_morton_codes_of_points(const float4* __restrict__ pts, uint32_t n, float recip, uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = pts[i];
+    const I3 v = voxel_of(F3{q.x, q.y, q.z}, recip);
+    out[i] = morton_encode(v.x, v.y, v.z);
+}
+
 __global__ void k_morton_codes(const float* __restrict__ xyz, uint32_t n, float recip, uint64_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
