@@ -208,7 +208,9 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     HIP_TRY(hipMalloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     f.sort.tiles_capacity = radix_tiles(cap);
     HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
-    HIP_TRY(hipMalloc(&f.d_seg, cap * 24));  // point blocks uint2 [cap] (start, length | flag), update work items uint4 [cap] (start, length, super-block code)
+    // point blocks uint2 (start, length | flag) and update work items uint4 (start, length, super-block code), each list in
+    // kListStripes stripes of cap / kListStripes + kGatherChunk entries (FrameHeader::list_count)
+    HIP_TRY(hipMalloc(&f.d_seg, (cap + size_t(kListStripes) * kGatherChunk) * 24));
     f.cap_points = cap;
     return CHAD_OK;
 }
@@ -493,7 +495,8 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     // preparation on the slot's own stream (it has already waited for the slot's previous update: prepare_slot) ...
     hipStream_t prep = f.prep;
     record(m, T_BEGIN, prep);
-    uint4* item_start = reinterpret_cast<uint4*>(f.d_seg + 2 * f.cap_points);
+    const uint32_t list_stride = uint32_t(f.cap_points / kListStripes + kGatherChunk);
+    uint4* item_start = reinterpret_cast<uint4*>(f.d_seg + 2 * size_t(list_stride) * kListStripes);
     if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, prep, f.d_hdr);
     if (count) {
         hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part);
@@ -508,10 +511,10 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         hipLaunchKernelGGL(k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                           points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, uint32_t(f.cap_points));
+                           points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride);
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), f.d_hdr, pos, f.d_normals, m->ablate);
+        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -544,7 +547,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             else
                 hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
         } else  // the tiled kernel; in automatic mode it takes the scatter form itself when the frame is sparse (decided on the device)
-            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, uint32_t(f.cap_points), m->d_stamps,
+            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, list_stride, m->d_stamps,
                                 time_kernel ? ev[T_NORM] : nullptr, time_kernel ? ev[T_UPD] : nullptr);
         if (times_stages(m)) record(m, T_UPD, prep);
     } else {

@@ -24,6 +24,8 @@ constexpr int kGatherChunk = 2048;    // points per gather step of one workgroup
 constexpr uint32_t kItemPoints = 1024; // an update work item never holds more points than this
 constexpr uint32_t kBigItem = 384;     // items longer than this are handed out first (longest-first keeps the update kernel's tail short)
 constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of this many counters (blockIdx % kWorkGroups)
+constexpr uint32_t kListStripes = 16; // stripes of the frame's block / work-item lists (FrameHeader::list_count)
+constexpr uint32_t kSparsePointsPerBlock = 6;  // frames with fewer points per block than this take the scatter form of the update
 
 // Per-frame scalars living in device memory (one per map; rewritten every insert).
 struct FrameHeader {
@@ -31,20 +33,54 @@ struct FrameHeader {
     uint32_t n_usable;          // points kept (D2 of the oracle header)
     uint32_t axis_bits;         // bits of a usable sort key
     uint32_t sort_passes;       // radix passes needed: ceil((axis_bits + 1 if any point is unusable) / 8)
-    uint32_t n_segments;        // point blocks (runs of equal code >> 6) found by k_frame_gather
+    uint32_t reserved1;
     unsigned long long mc_min;  // smallest global Morton code of the frame ...
     uint32_t last_idx;          // ... and the largest input index among the points having it (normals.hpp:100)
     uint32_t reserved0;
-    uint32_t n_items;           // update work items longer than kBigItem points (super blocks cut at every kItemPoints-th point): items[0 ..)
-    uint32_t n_items_small;     // the shorter ones: items[capacity - 1], items[capacity - 2], ...  The update kernel starts with the long ones
+    uint32_t reserved2, reserved3;
     unsigned long long n_updates[32 * 16];  // voxel updates applied by the last insert, striped over 32 cache lines
     uint32_t work_cursor[kWorkGroups * 16];  // per-group work counters of the update kernel, one per 64-byte line
+    // Entries of the frame's three lists -- point blocks, update work items longer than kBigItem points, the shorter items --
+    // per stripe, one counter per 64-byte line.  k_frame_gather appends a chunk's entries to stripe (chunk % kListStripes)
+    // with one returning atomic per list: on ONE counter per list the 489 workgroups of a 1 M-point frame queued for
+    // ~25 ns each, half of that kernel's 26 us.  Stripe s of a list owns entries [s * stride, (s + 1) * stride) of its array,
+    // stride = capacity / kListStripes + kGatherChunk; long items fill a stripe's range from the front, short ones from the back.
+    uint32_t list_count[3][kListStripes * 16];
 };
+enum { kListBlocks = 0, kListLongItems = 1, kListShortItems = 2 };
+
+__device__ __forceinline__ uint32_t list_total(const FrameHeader* h, int list) {
+    uint32_t n = 0;
+    for (uint32_t s = 0; s < kListStripes; s++) n += h->list_count[list][s * 16];
+    return n;
+}
+// Entry i of a list, counted through the stripes in order.  The stripe counts are read once (sixteen independent loads,
+// wave-uniform) and the search runs on registers: looked up straight from the header, every entry cost up to sixteen
+// DEPENDENT loads (the update kernel went from 30 to 36 us that way).
+struct ListIndex {
+    uint32_t begin[kListStripes + 1];   // entries in the stripes before stripe s
+    __device__ __forceinline__ void load(const FrameHeader* h, int list) {
+        uint32_t count[kListStripes];
+#pragma unroll
+        for (uint32_t s = 0; s < kListStripes; s++) count[s] = h->list_count[list][s * 16];
+        begin[0] = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kListStripes; s++) begin[s + 1] = begin[s] + count[s];
+    }
+    __device__ __forceinline__ uint32_t total() const { return begin[kListStripes]; }
+    // stripe of entry i (return value) and its index inside the stripe
+    __device__ __forceinline__ uint32_t locate(uint32_t i, uint32_t* index) const {
+        uint32_t stripe = 0, first = 0;
+#pragma unroll
+        for (uint32_t s = 1; s < kListStripes; s++) { const bool later = i >= begin[s]; stripe = later ? s : stripe; first = later ? begin[s] : first; }
+        *index = i - first;
+        return stripe;
+    }
+};
+__device__ __forceinline__ bool frame_is_sparse(const FrameHeader* h) { return h->n_usable < kSparsePointsPerBlock * list_total(h, kListBlocks); }
 
 // Sparse frames (few points per 4x4x4 block, e.g. 2 cm voxels outdoors) take the scatter form of the update: with about
 // one point per block, staging a voxel tile in LDS per block is pure overhead.  Decided on the device, per frame.
-constexpr uint32_t kSparsePointsPerBlock = 6;
-__device__ __forceinline__ bool frame_is_sparse(const FrameHeader* h) { return h->n_usable < kSparsePointsPerBlock * h->n_segments; }
 
 // Partial results of one workgroup, combined by the NEXT kernel's prologue (no same-address atomics: on gfx950
 // those serialise at ~12 ns each, which for thousands of waves costs more than the whole pass).
@@ -59,11 +95,12 @@ struct FramePartial {
 __device__ __forceinline__ void frame_header_reset(FrameHeader* h) {
     for (uint32_t k = threadIdx.x; k < 32 * 16; k += blockDim.x) h->n_updates[k] = 0;
     for (uint32_t k = threadIdx.x; k < kWorkGroups * 16; k += blockDim.x) h->work_cursor[k] = 0;
+    for (uint32_t k = threadIdx.x; k < 3 * kListStripes * 16; k += blockDim.x) (&h->list_count[0][0])[k] = 0;
     if (threadIdx.x == 0) {
         h->vmin[0] = h->vmin[1] = h->vmin[2] = 0x7fffffff;
         h->vmax[0] = h->vmax[1] = h->vmax[2] = int(0x80000000);
-        h->n_usable = 0; h->axis_bits = 0; h->sort_passes = 0; h->n_segments = 0;
-        h->mc_min = ~0ull; h->last_idx = 0; h->reserved0 = 0; h->n_items = 0; h->n_items_small = 0;
+        h->n_usable = 0; h->axis_bits = 0; h->sort_passes = 0; h->reserved1 = 0;
+        h->mc_min = ~0ull; h->last_idx = 0; h->reserved0 = 0; h->reserved2 = 0; h->reserved3 = 0;
     }
 }
 __global__ void k_frame_init(FrameHeader* h) { frame_header_reset(h); }
@@ -262,7 +299,7 @@ __global__ void __launch_bounds__(256)
 k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const float4* __restrict__ points0, const float4* __restrict__ points1,
-               uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t items_capacity) {
+               uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t list_stride) {
     constexpr uint32_t kWords = kGatherChunk / 32;
     __shared__ uint32_t mark_bits[kWords], head_bits[kWords];  // bit k: point k of the chunk starts a work item / a point block
     __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
@@ -291,6 +328,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
     const float4* pts = odd ? points1 : points0;   // the sort carries the points along: its last pass left them in processing order
     const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t stripe = c % kListStripes;
         if (threadIdx.x < kWords) { mark_bits[threadIdx.x] = 0u; head_bits[threadIdx.x] = 0u; }
         if (threadIdx.x == 0) { n_big = 0u; n_small = 0u; }
         __syncthreads();
@@ -329,7 +367,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_down(first_mark, o); if (int(lane) + o < 64) first_mark = min(first_mark, t); }
             const uint32_t after = __shfl_down(first_mark, 1);   // first mark in a later word
             word_next[which][lane] = lane == 63u ? chunk_len : after;
-            if (which && lane == 63u) base_heads = incl ? atomicAdd(&h->n_segments, incl) : 0u;
+            if (which && lane == 63u) base_heads = stripe * list_stride + (incl ? atomicAdd(&h->list_count[kListBlocks][stripe * 16u], incl) : 0u);
         }
         __syncthreads();
         // the items of this chunk, long and short ones counted apart (order inside a class does not matter) ...
@@ -348,8 +386,8 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
         __syncthreads();
         // ... each class reserving its part of the list with one atomic per chunk: long items from the front, short ones from the back
         if (threadIdx.x == 0) {
-            base_big = n_big ? atomicAdd(&h->n_items, n_big) : 0u;
-            base_small = n_small ? atomicAdd(&h->n_items_small, n_small) : 0u;
+            base_big = stripe * list_stride + (n_big ? atomicAdd(&h->list_count[kListLongItems][stripe * 16u], n_big) : 0u);
+            base_small = n_small ? atomicAdd(&h->list_count[kListShortItems][stripe * 16u], n_small) : 0u;
         }
         __syncthreads();
 #pragma unroll
@@ -363,7 +401,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             const uint64_t code = morton_encode(v.x, v.y, v.z);   // only the few threads that open a block or an item get here
             if ((word >> bit) & 1u) {
                 const uint64_t corner = code & ~511ull;  // corner of the 8x8x8 super block
-                const uint32_t at = item_len[j] > kBigItem ? base_big + item_slot[j] : items_capacity - 1u - (base_small + item_slot[j]);
+                const uint32_t at = item_len[j] > kBigItem ? base_big + item_slot[j] : (stripe + 1u) * list_stride - 1u - (base_small + item_slot[j]);
                 items[at] = make_uint4(c * kGatherChunk + k, item_len[j], uint32_t(corner), uint32_t(corner >> 32));
             }
             if ((hword >> bit) & 1u) {
@@ -511,14 +549,21 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t l) { return u
 
 __global__ void __launch_bounds__(64 * kNormalWavesPerBlock, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
 k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ points1, const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
-                const uint2* __restrict__ segments,
+                const uint2* __restrict__ segments, uint32_t list_stride,
                 FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
     __shared__ NormalScratch s;
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
     // ... and their keys: key >> 6 is the point's block, 63 - (key & 63) its voxel in the block (the low 6 code bits)
     const uint64_t* __restrict__ keys = (h->sort_passes & 1u) ? keys1 : keys0;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n = h->n_usable, nseg = h->n_segments;
+    ListIndex blocks;
+    blocks.load(h, kListBlocks);
+    const uint32_t n = h->n_usable, nseg = blocks.total();
+    auto segment = [&](uint32_t i) {   // point block i, counted through the stripes of the list
+        uint32_t index;
+        const uint32_t stripe = blocks.locate(i, &index);
+        return segments[stripe * list_stride + index];
+    };
 
     auto estimate_block = [&](const uint2 record) {
         // (start, length, flag) from k_frame_gather; only a block that runs across the end of a gather chunk (one in
@@ -651,8 +696,8 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
         __syncthreads();
     };
 
-    if (!frame_is_sparse(h)) {  // dense frame: one wave per point block
-        for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) estimate_block(segments[seg]);
+    if (!(n < kSparsePointsPerBlock * nseg)) {  // dense frame (frame_is_sparse): one wave per point block
+        for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) estimate_block(segment(seg));
         return;
     }
     // Sparse frame (about one point per block, e.g. 2 cm voxels outdoors): a block with fewer than kMinPoints points cannot
@@ -664,7 +709,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
     const uint32_t batches = (nseg + 63u) / 64u;
     for (uint32_t t = blockIdx.x; t < batches; t += gridDim.x) {
         const uint32_t mine = lane * batches + t;
-        const uint2 record = mine < nseg ? segments[mine] : make_uint2(0u, 0u);
+        const uint2 record = mine < nseg ? segment(mine) : make_uint2(0u, 0u);
         const uint32_t len = record.y & 0x7fffffffu;
         const bool small = mine < nseg && len != 0u && len < kMinPoints;
         if (small)

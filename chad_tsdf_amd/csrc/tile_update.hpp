@@ -89,7 +89,7 @@ __device__ __forceinline__ void tile_barrier() {
 template <bool kStamps, int kMinWaves>
 __global__ void __launch_bounds__(kTileThreads, kMinWaves)
 k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, const uint4* __restrict__ items,
-               FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t items_capacity,
+               FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t items_capacity /* entries per stripe of items[] */,
                unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
@@ -106,9 +106,32 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     const uint32_t tile_base = uint32_t(uintptr_t(tile));  // LDS byte address (low half of the flat address)
     const float to_fixed = kFixedOne / trunc, from_fixed = trunc / kFixedOne;
     for (uint32_t k = threadIdx.x; k <= cells; k += kTileThreads) tile[k] = 0ull;
-    // the work list: n_long items from the front of items[], then n_short from its back (k_frame_gather); longest first
-    const uint32_t n_long = h->n_items, nitems = n_long + h->n_items_small;
-    auto item_record = [&](uint32_t v) { return items[v < n_long ? v : items_capacity - 1u - (v - n_long)]; };
+    // the work list: the long items of all stripes first, then the short ones (k_frame_gather; FrameHeader::list_count)
+    // Where each stripe's entries begin, in LDS (registers are scarce here): first_long[s], first_short[s], s = 0 .. kListStripes.
+    uint32_t* first_long = reinterpret_cast<uint32_t*>(next_record + 1);
+    uint32_t* first_short = first_long + kListStripes + 1;
+    if (threadIdx.x < 2 * kListStripes) {   // lanes 0..15: long items, 16..31: short items; a 16-lane inclusive scan each
+        const uint32_t list = threadIdx.x / kListStripes, stripe = threadIdx.x % kListStripes;
+        const uint32_t count = h->list_count[list ? kListShortItems : kListLongItems][stripe * 16];
+        uint32_t incl = count;
+#pragma unroll
+        for (int o = 1; o < int(kListStripes); o <<= 1) { const uint32_t t = __shfl_up(incl, o, kListStripes); if (int(stripe) >= o) incl += t; }
+        uint32_t* first = list ? first_short : first_long;
+        first[stripe + 1] = incl;
+        if (stripe == 0) first[0] = 0u;
+    }
+    tile_barrier();
+    const uint32_t n_long = first_long[kListStripes], nitems = n_long + first_short[kListStripes];
+    auto item_record = [&](uint32_t v) {
+        const bool is_long = v < n_long;
+        const uint32_t* first = is_long ? first_long : first_short;
+        const uint32_t i = is_long ? v : v - n_long;
+        uint32_t stripe = 0;
+#pragma unroll
+        for (uint32_t s = 1; s < kListStripes; s++) stripe = i >= first[s] ? s : stripe;
+        const uint32_t index = i - first[stripe];
+        return items[is_long ? stripe * items_capacity + index : (stripe + 1u) * items_capacity - 1u - index];
+    };
     uint32_t applied = 0;
 
     // lane = voxel v of a brick (Morton order of the low 6 code bits).  This wave's bricks: (bx, by) = 0..3 x 0..3 in
@@ -327,7 +350,7 @@ inline void tile_update_enqueue(const float4* points0, const float4* points1, co
                                 hipEvent_t started = nullptr, hipEvent_t stopped = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
     const uint32_t d = 8 + 2 * reach;
-    const size_t lds = ((size_t(d) * d * d + 2) & ~size_t(1)) * 8 + 16;   // tile + spare zero cell (padded to 16 bytes) + next item's record
+    const size_t lds = ((size_t(d) * d * d + 2) & ~size_t(1)) * 8 + 16 + 2 * (kListStripes + 1) * 4 + 8;   // tile + spare zero cell (padded to 16 bytes) + next item's record + list index
     // persistent workgroups: as many as are resident at once (registers and LDS decide), on every CU
     static int resident[2] = {0, 0};
     static size_t resident_lds = 0;
