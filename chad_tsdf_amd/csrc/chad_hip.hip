@@ -826,7 +826,7 @@ chad_status chad_map_stats(chad_map* m, chad_stats* out) {
     const bool last_empty = m->frames_empty_tail != 0;   // the last insert had no points: its frame counters are zero
     out->frames = m->frames + m->frames_empty_tail; out->points_in = m->last_points_in; out->points_used = last_empty ? 0 : m->h_hdr->n_usable;
     out->updates = 0;
-    if (!last_empty) for (int k = 0; k < 32; k++) out->updates += m->h_hdr->n_updates[k * 16];
+    if (!last_empty) for (uint32_t k = 0; k < kUpdateStripes; k++) out->updates += m->h_hdr->n_updates[k * 16];
     out->blocks = blocks; out->block_capacity = m->brick_capacity;
     out->hash_capacity = m->hash_capacity; out->closed_submaps = m->closed.size() + (m->closing ? 1 : 0);
     out->sort_passes = last_empty ? 0 : m->h_hdr->sort_passes; out->overflow = overflow;

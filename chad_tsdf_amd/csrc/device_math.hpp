@@ -11,6 +11,10 @@ namespace chadhip {
 
 constexpr uint64_t kBlockMask = 0xffffffffffffffc0ull;  // octree.hpp:33-35 -- one key per 4x4x4-voxel block
 constexpr uint32_t kWave = 64;
+// Counters that many workgroups add to are striped over separate 64-byte lines: atomics on ONE address are worked off at
+// about 25 ns each, whoever issues them.
+constexpr uint32_t kCountStripes = 256;   // MapView::brick_count[k * 16]: every new brick adds one (9409 per frame in the bench)
+constexpr uint32_t kUpdateStripes = 128;  // FrameHeader::n_updates[k * 16]: one add per wave of the update kernel
 
 struct F3 { float x, y, z; };
 struct I3 { int x, y, z; };

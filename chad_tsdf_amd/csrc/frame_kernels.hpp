@@ -38,7 +38,7 @@ struct FrameHeader {
     uint32_t last_idx;          // ... and the largest input index among the points having it (normals.hpp:100)
     uint32_t reserved0;
     uint32_t reserved2, reserved3;
-    unsigned long long n_updates[32 * 16];  // voxel updates applied by the last insert, striped over 32 cache lines
+    unsigned long long n_updates[kUpdateStripes * 16];  // voxel updates applied by the last insert, striped over cache lines
     uint32_t work_cursor[kWorkGroups * 16];  // per-group work counters of the update kernel, one per 64-byte line
     // Entries of the frame's three lists -- point blocks, update work items longer than kBigItem points, the shorter items --
     // per stripe, one counter per 64-byte line.  k_frame_gather appends a chunk's entries to stripe (chunk % kListStripes)
@@ -93,7 +93,7 @@ struct FramePartial {
 // Per-frame reset of the header.  Runs as its own kernel only for
 // empty frames; otherwise workgroup 0 of k_frame_keys does it (nothing before k_frame_gather reads the header).
 __device__ __forceinline__ void frame_header_reset(FrameHeader* h) {
-    for (uint32_t k = threadIdx.x; k < 32 * 16; k += blockDim.x) h->n_updates[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kUpdateStripes * 16; k += blockDim.x) h->n_updates[k] = 0;
     for (uint32_t k = threadIdx.x; k < kWorkGroups * 16; k += blockDim.x) h->work_cursor[k] = 0;
     for (uint32_t k = threadIdx.x; k < 3 * kListStripes * 16; k += blockDim.x) (&h->list_count[0][0])[k] = 0;
     if (threadIdx.x == 0) {
@@ -233,10 +233,13 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
              uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words,
              const uint32_t* __restrict__ live_blocks, uint32_t* __restrict__ live_blocks_host) {
     if (blockIdx.x == 0) frame_header_reset(h);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // host-mapped: capacity growth hint (the counter is striped over 32 lines)
-        uint32_t live = 0;
-        for (uint32_t k = 0; k < 32; k++) live += live_blocks[k * 16];
-        *live_blocks_host = live;
+    if (blockIdx.x == 0) {  // host-mapped: capacity growth hint (the live-brick counter is striped, one stripe per thread)
+        static_assert(kCountStripes == 256, "one stripe per thread of this workgroup");
+        __shared__ uint32_t live_sum[4];
+        const uint32_t live = wave_sum(live_blocks[threadIdx.x * 16]);
+        if ((threadIdx.x & 63) == 0) live_sum[threadIdx.x >> 6] = live;
+        __syncthreads();
+        if (threadIdx.x == 0) *live_blocks_host = live_sum[0] + live_sum[1] + live_sum[2] + live_sum[3];
     }
     const LocalFrame f = combine_bounds(part);
     __shared__ unsigned long long wave_mc[4];

@@ -30,7 +30,6 @@ namespace chadhip {
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr uint32_t kNoBrick = 0xfffffffeu;   // table too full: updates to this block are dropped (overflow flag set)
 constexpr uint32_t kMaxProbes = 256;         // at load <= 0.5 probe sequences are a handful of slots long
-constexpr uint32_t kCountStripes = 32;       // brick_count[k * 16], k < kCountStripes
 
 struct MapView {
     uint64_t* hash_keys;
@@ -102,7 +101,7 @@ __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, c
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) applied += __shfl_xor(applied, o);
-    if ((threadIdx.x & 63) == 0 && applied) atomicAdd(&h->n_updates[(blockIdx.x & 31u) * 16u], applied);
+    if ((threadIdx.x & 63) == 0 && applied) atomicAdd(&h->n_updates[(blockIdx.x % kUpdateStripes) * 16u], applied);
 }
 
 __global__ void __launch_bounds__(256)

@@ -105,6 +105,9 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     uint4* next_record = reinterpret_cast<uint4*>(tile + ((cells + 2u) & ~1u));
     const uint32_t tile_base = uint32_t(uintptr_t(tile));  // LDS byte address (low half of the flat address)
     const float to_fixed = kFixedOne / trunc, from_fixed = trunc / kFixedOne;
+    // (the stripe counts of the work lists are loaded here so that their latency overlaps the zeroing of the tile)
+    uint32_t stripe_count = 0;
+    if (threadIdx.x < 2 * kListStripes) stripe_count = h->list_count[threadIdx.x / kListStripes ? kListShortItems : kListLongItems][(threadIdx.x % kListStripes) * 16];
     for (uint32_t k = threadIdx.x; k <= cells; k += kTileThreads) tile[k] = 0ull;
     // the work list: the long items of all stripes first, then the short ones (k_frame_gather; FrameHeader::list_count)
     // Where each stripe's entries begin, in LDS (registers are scarce here): first_long[s], first_short[s], s = 0 .. kListStripes.
@@ -112,8 +115,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     uint32_t* first_short = first_long + kListStripes + 1;
     if (threadIdx.x < 2 * kListStripes) {   // lanes 0..15: long items, 16..31: short items; a 16-lane inclusive scan each
         const uint32_t list = threadIdx.x / kListStripes, stripe = threadIdx.x % kListStripes;
-        const uint32_t count = h->list_count[list ? kListShortItems : kListLongItems][stripe * 16];
-        uint32_t incl = count;
+        uint32_t incl = stripe_count;
 #pragma unroll
         for (int o = 1; o < int(kListStripes); o <<= 1) { const uint32_t t = __shfl_up(incl, o, kListStripes); if (int(stripe) >= o) incl += t; }
         uint32_t* first = list ? first_short : first_long;
@@ -337,7 +339,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     unsigned long long total = applied;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-    if (lane == 0 && total) atomicAdd(&h->n_updates[((blockIdx.x * kTileWaves + wave) & 31u) * 16u], total);
+    if (lane == 0 && total) atomicAdd(&h->n_updates[((blockIdx.x * kTileWaves + wave) % kUpdateStripes) * 16u], total);
 }
 
 inline uint32_t tile_reach(float res, float trunc) {
