@@ -41,7 +41,7 @@ struct FrameHeader {
     unsigned long long n_updates[kUpdateStripes * 16];  // voxel updates applied by the last insert, striped over cache lines
     uint32_t work_cursor[kWorkGroups * 16];  // per-group work counters of the update kernel, one per 64-byte line
     // Entries of the frame's three lists -- point blocks, update work items longer than kBigItem points, the shorter items --
-    // per stripe, one counter per 64-byte line.  k_frame_gather appends a chunk's entries to stripe (chunk % kListStripes)
+    // per stripe, one counter per 64-byte line.  k_frame_gather appends a chunk's entries to the stripe of its sixteenth of the frame
     // with one returning atomic per list: on ONE counter per list the 489 workgroups of a 1 M-point frame queued for
     // ~25 ns each, half of that kernel's 26 us.  Stripe s of a list owns entries [s * stride, (s + 1) * stride) of its array,
     // stride = capacity / kListStripes + kGatherChunk; long items fill a stripe's range from the front, short ones from the back.
@@ -331,7 +331,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
     const float4* pts = odd ? points1 : points0;   // the sort carries the points along: its last pass left them in processing order
     const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t stripe = c % kListStripes;
+        const uint32_t stripe = c / ((chunks + kListStripes - 1) / kListStripes);   // consecutive chunks share a stripe: the lists keep the frame's order
         if (threadIdx.x < kWords) { mark_bits[threadIdx.x] = 0u; head_bits[threadIdx.x] = 0u; }
         if (threadIdx.x == 0) { n_big = 0u; n_small = 0u; }
         __syncthreads();
