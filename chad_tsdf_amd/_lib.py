@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchad_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_CAPACITY, ERR_HIP = range(6)
-FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY = 1, 2, 4, 8
+FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS = 1, 2, 4, 8, 16
+DAG_NODE_LEVELS, DAG_CLUSTER_LEVEL = 20, 20
 UPDATE_AUTO, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
 
 
@@ -56,6 +57,16 @@ class Stats(C.Structure):
     ]
 
 
+class DagStats(C.Structure):
+    _fields_ = [
+        ("submaps", C.c_uint64),
+        ("uniques", C.c_uint32 * 21),
+        ("dupes", C.c_uint32 * 21),
+        ("ms_device", C.c_float),
+        ("ms_host", C.c_float),
+    ]
+
+
 # every symbol include/chad_hip.h declares: name -> (restype, argtypes)
 _vp, _sz, _i32, _f32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_float
 SYMBOLS = {
@@ -73,6 +84,13 @@ SYMBOLS = {
     "chad_map_export_blocks_device": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
     "chad_map_export_blocks_device_unordered": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
     "chad_map_close_submap_with_blocks_device": (_i32, [_vp, _vp, _vp, _vp, _sz]),
+    "chad_map_finalize": (_i32, [_vp]),
+    "chad_map_dag_roots": (_i32, [_vp, _i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "chad_map_dag_level_words": (_i32, [_vp, C.c_uint32, C.POINTER(_sz)]),
+    "chad_map_dag_level_copy": (_i32, [_vp, C.c_uint32, _vp, _sz]),
+    "chad_map_dag_stats": (_i32, [_vp, C.POINTER(DagStats)]),
+    "chad_map_dag_leaves": (_i32, [_vp, _i32, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "chad_map_export_clusters": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_last_frame": (_i32, [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_walk_rays": (_i32, [_vp, _sz, _vp, _f32, _f32, _vp, _vp, _sz]),
     "chad_morton_codes": (_i32, [_vp, _sz, _f32, _vp]),

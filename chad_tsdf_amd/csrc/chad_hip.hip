@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "dag.hpp"
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
 #include "radix_sort.hpp"
@@ -115,6 +117,9 @@ struct chad_map {
     std::vector<std::array<float, 3>> positions;  // poses of the active submap (submap.hpp:110)
     std::vector<Submap> closed;                   // tsdf.cpp:54
     Submap active_copy;                           // dense snapshot of the active submap made for the last export call
+    Dag dag;                                      // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps, built lazily (chad_map_finalize)
+    std::vector<std::array<uint32_t, 2>> dag_roots;  // submap.hpp:108-109 of the closed submaps folded so far (a prefix of `closed`)
+    float dag_ms_device = 0, dag_ms_host = 0;
     // Roll-over without a pipeline stall: the active table is swapped for an empty spare one of the same size and is
     // archived (counted, compacted into a dense closed submap, cleared) on the map's stream behind the frames, the host
     // part of it -- sizing the archive -- whenever the count has arrived.  At most one submap is closing at a time.
@@ -771,6 +776,8 @@ chad_status chad_map_reset(chad_map* m) {
         for (auto& s : m->closed) free_submap(s);
         m->closed.clear();
     }
+    m->dag = Dag();
+    m->dag_roots.clear();
     m->positions.clear();
     // The clear itself is deferred to the stream of the next insert (right in front of its update), so that the next
     // frame's preparation does not queue behind it; anything else that looks at the map first carries it out (flush_pending_clear).
@@ -912,6 +919,148 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
     m->positions.clear();
     TRY(clear_active(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHAD_OK;
+}
+
+// ---- Submap::finalize (submap.hpp:10-106): leaf clusters on the device, the DAG of NodeLevels on the host ----
+namespace {
+
+struct HostClusters { std::vector<uint64_t> keys, tsdf, weight; };
+
+// Device half: the bricks of a dense submap, ordered by block key, as eight cluster words each.
+chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum, const uint32_t* cnt, uint32_t nb, bool want_weights, HostClusters& hc, float* ms) {
+    hc.keys.resize(nb); hc.tsdf.resize(size_t(nb) * 8); hc.weight.resize(want_weights ? size_t(nb) * 8 : 0);
+    if (!nb) return CHAD_OK;
+    TRY(join_streams(m));  // slot 0's sort buffers are borrowed below
+    FrameSlot& f = m->slot[0];
+    TRY(ensure_frame_capacity(m, f, nb));
+    uint64_t* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))));
+    uint64_t* d_keys = d_out; uint64_t* d_tsdf = d_out + nb; uint64_t* d_weight = want_weights ? d_tsdf + size_t(nb) * 8 : nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, m->stream));
+    // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
+    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, f.sort.keys[0], nb);
+    radix_sort_enqueue(f.sort, nb, kMaxPasses, nullptr, m->stream);
+    hipLaunchKernelGGL(k_leaf_clusters, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)f.sort.idx[0], nb, keys, sum, cnt, 1.0f / m->trunc /* submap.hpp:23 */,
+                       d_keys, d_tsdf, d_weight);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hc.keys.data(), d_keys, size_t(nb) * 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(hc.tsdf.data(), d_tsdf, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
+    if (want_weights) HIP_TRY(hipMemcpyAsync(hc.weight.data(), d_weight, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipEventRecord(e1, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    float t = 0;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    if (ms) *ms += t;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    return CHAD_OK;
+}
+
+// Fold the submaps closed since the last call into the DAG, in closing order (the order the reference finalizes them in).
+chad_status finalize_closed(chad_map* m) {
+    TRY(finish_closing(m, true));
+    if (m->dag_roots.size() >= m->closed.size()) return CHAD_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
+    float ms_device = 0;
+    double ms_host = 0;
+    while (m->dag_roots.size() < m->closed.size()) {
+        const Submap& s = m->closed[m->dag_roots.size()];
+        HostClusters hc;
+        TRY(device_clusters(m, s.keys, s.sum, s.cnt, s.blocks, saturate, hc, &ms_device));
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t root_tsdf = 0, root_weight = 0;
+        dag_add_submap(m->dag, hc.keys.data(), hc.tsdf.data(), saturate ? hc.weight.data() : nullptr, s.blocks, &root_tsdf, &root_weight);
+        ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        m->dag_roots.push_back({root_tsdf, root_weight});
+    }
+    m->dag_ms_device = ms_device; m->dag_ms_host = float(ms_host);
+    return CHAD_OK;
+}
+
+}  // namespace
+
+chad_status chad_map_finalize(chad_map* m) {
+    if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    DeviceGuard guard(m->device);
+    return finalize_closed(m);
+}
+
+chad_status chad_map_dag_roots(chad_map* m, int32_t submap, uint32_t* root_tsdf, uint32_t* root_weight) {
+    if (!m || !root_tsdf || !root_weight) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(finalize_closed(m));
+    if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
+    *root_tsdf = m->dag_roots[size_t(submap)][0]; *root_weight = m->dag_roots[size_t(submap)][1];
+    return CHAD_OK;
+}
+
+chad_status chad_map_dag_level_words(chad_map* m, uint32_t level, size_t* words) {
+    if (!m || !words) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (level > CHAD_DAG_CLUSTER_LEVEL) return fail(CHAD_ERR_INVALID_ARG, "level out of range");
+    DeviceGuard guard(m->device);
+    TRY(finalize_closed(m));
+    *words = level < kDagDepth ? m->dag.nodes[level].raw.size() : m->dag.clusters.raw.size();
+    return CHAD_OK;
+}
+
+chad_status chad_map_dag_level_copy(chad_map* m, uint32_t level, void* out, size_t capacity_words) {
+    size_t words = 0;
+    TRY(chad_map_dag_level_words(m, level, &words));
+    if (capacity_words < words) return fail(CHAD_ERR_INVALID_ARG, "capacity_words too small");
+    if (!out) return fail(CHAD_ERR_INVALID_ARG, "null output");
+    if (level < kDagDepth) std::memcpy(out, m->dag.nodes[level].raw.data(), words * 4);
+    else std::memcpy(out, m->dag.clusters.raw.data(), words * 8);
+    return CHAD_OK;
+}
+
+chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
+    if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(finalize_closed(m));
+    std::memset(out, 0, sizeof(*out));
+    out->submaps = m->dag_roots.size();
+    for (uint32_t l = 0; l < kDagDepth; l++) { out->uniques[l] = m->dag.nodes[l].uniques; out->dupes[l] = m->dag.nodes[l].dupes; }
+    out->uniques[kDagDepth] = m->dag.clusters.uniques; out->dupes[kDagDepth] = m->dag.clusters.dupes;
+    out->ms_device = m->dag_ms_device; out->ms_host = m->dag_ms_host;
+    return CHAD_OK;
+}
+
+chad_status chad_map_dag_leaves(chad_map* m, int32_t submap, uint64_t* mc, float* sd, size_t capacity, size_t* count) {
+    if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(finalize_closed(m));
+    if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
+    size_t k = 0;
+    const float trunc = m->trunc;
+    dag_walk(m->dag, m->dag_roots[size_t(submap)][0], [&](uint64_t code, uint8_t bits) {
+        if (k < capacity) {
+            if (mc) mc[k] = code;
+            if (sd) sd[k] = cluster_sd_of_bits(bits, trunc);
+        }
+        k++;
+    });
+    *count = k;
+    return CHAD_OK;
+}
+
+chad_status chad_map_export_clusters(chad_map* m, int32_t submap, uint64_t* keys_out, uint64_t* tsdf_out, uint64_t* weights_out, size_t capacity_blocks, size_t* blocks) {
+    if (!m || !blocks) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    uint32_t nb = 0;
+    const uint64_t* keys; const float* sum; const uint32_t* cnt;
+    TRY(select_submap(m, submap, &nb, &keys, &sum, &cnt));
+    *blocks = nb;
+    if (!keys_out && !tsdf_out && !weights_out) return CHAD_OK;
+    if (nb > capacity_blocks) return fail(CHAD_ERR_INVALID_ARG, "capacity_blocks too small");
+    HostClusters hc;
+    TRY(device_clusters(m, keys, sum, cnt, nb, weights_out != nullptr, hc, nullptr));
+    if (keys_out) std::memcpy(keys_out, hc.keys.data(), size_t(nb) * 8);
+    if (tsdf_out) std::memcpy(tsdf_out, hc.tsdf.data(), size_t(nb) * 64);
+    if (weights_out) std::memcpy(weights_out, hc.weight.data(), size_t(nb) * 64);
     return CHAD_OK;
 }
 

@@ -52,6 +52,7 @@ TSDFMap::Leaves TSDFMap::leaves(int submap) const {
 void TSDFMap::save(const std::string& filename) {
     // tsdf.cpp:78-85: the active submap is closed if it holds a pose, then the FIRST submap is written.
     check(chad_map_close_submap(_impl), "chad::TSDFMap::save");
+    check(chad_map_finalize(_impl), "chad::TSDFMap::save");  // Submap::finalize of every submap closed so far (tsdf.cpp:53,79)
     if (closed_submaps() == 0) throw std::runtime_error("chad::TSDFMap::save: nothing was inserted");
     const Leaves first = leaves(0);
     std::FILE* f = std::fopen(filename.c_str(), "wb");

@@ -21,7 +21,8 @@ def _np_f32(a, shape_last=3):
 
 class TSDFMap:
     def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, device: int = -1, max_blocks: int = 0,
-                 max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, time_update: bool = False, fixed_capacity: bool = False, update_mode: int = 0):
+                 max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, time_update: bool = False, fixed_capacity: bool = False, update_mode: int = 0,
+                 dag_saturate_weights: bool = False):
         self._lib = _lib.load()
         self._sdf_res = float(sdf_res)
         self._sdf_trunc = float(sdf_trunc)
@@ -31,7 +32,7 @@ class TSDFMap:
         opt.max_blocks = max_blocks
         opt.max_points = max_points
         opt.stream = stream or None
-        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0)
+        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0)
         opt.update_mode = update_mode
         handle = C.c_void_p()
         _lib.check(self._lib.chad_map_create(sdf_res, sdf_trunc, C.byref(opt), C.byref(handle)), "TSDFMap")
@@ -65,6 +66,7 @@ class TSDFMap:
     def save(self, filename: str):
         """TSDFMap::save -- tsdf.cpp:76-86: close the active submap, write the FIRST submap (as PLY voxels here)."""
         self.close_submap()
+        self.finalize()  # Submap::finalize of every submap closed so far (tsdf.cpp:53,79)
         if self.closed_submaps == 0:
             raise RuntimeError("TSDFMap.save: nothing was inserted")
         mc, sd, w = self.export_leaves(0)
@@ -145,6 +147,50 @@ class TSDFMap:
         b = int(keys.numel())
         _lib.check(self._lib.chad_map_close_submap_with_blocks_device(self._h, keys.data_ptr() if b else None, s.data_ptr() if b else None,
                                                                       c.data_ptr() if b else None, b), "TSDFMap.close_submap_with_blocks")
+
+    # ---- Submap::finalize / NodeLevels (submap.hpp:10-106, levels.hpp:141-199) ---------------------------
+    def finalize(self):
+        """Fold every closed submap that is not in the DAG yet into it (lazy; the dag_* calls do it themselves)."""
+        _lib.check(self._lib.chad_map_finalize(self._h), "TSDFMap.finalize")
+
+    def dag_roots(self, submap: int):
+        """(root_addr_tsdf, root_addr_weight) of a closed submap -- submap.hpp:108-109."""
+        rt, rw = C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.chad_map_dag_roots(self._h, submap, C.byref(rt), C.byref(rw)), "TSDFMap.dag_roots")
+        return rt.value, rw.value
+
+    def dag_level(self, level: int) -> np.ndarray:
+        """Raw words of NodeLevels::_nodes[level] (uint32, level 0..19) or of the leaf clusters (uint64, level 20)."""
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_map_dag_level_words(self._h, level, C.byref(n)), "TSDFMap.dag_level")
+        out = np.empty(n.value, dtype=np.uint64 if level == _lib.DAG_CLUSTER_LEVEL else np.uint32)
+        _lib.check(self._lib.chad_map_dag_level_copy(self._h, level, out.ctypes.data, n.value), "TSDFMap.dag_level")
+        return out
+
+    def dag_stats(self) -> dict:
+        st = _lib.DagStats()
+        _lib.check(self._lib.chad_map_dag_stats(self._h, C.byref(st)), "TSDFMap.dag_stats")
+        return {"submaps": int(st.submaps), "uniques": list(st.uniques), "dupes": list(st.dupes), "ms_device": st.ms_device, "ms_host": st.ms_host}
+
+    def dag_leaves(self, submap: int):
+        """(mc u64, sd f32) read back through the DAG (lvr2.cpp:30-90), sd de-quantised from 8 bits, ascending by code."""
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_map_dag_leaves(self._h, submap, None, None, 0, C.byref(n)), "TSDFMap.dag_leaves")
+        mc = np.empty(n.value, dtype=np.uint64)
+        sd = np.empty(n.value, dtype=np.float32)
+        _lib.check(self._lib.chad_map_dag_leaves(self._h, submap, mc.ctypes.data, sd.ctypes.data, n.value, C.byref(n)), "TSDFMap.dag_leaves")
+        return mc, sd
+
+    def export_clusters(self, submap: int = -1, weights: bool = True):
+        """Device half of finalize on its own: (block keys [B] ascending, tsdf words [B,8], weight words [B,8] or None)."""
+        b = C.c_size_t()
+        _lib.check(self._lib.chad_map_export_clusters(self._h, submap, None, None, None, 0, C.byref(b)), "TSDFMap.export_clusters")
+        keys = np.empty(b.value, dtype=np.uint64)
+        tsdf = np.empty((b.value, 8), dtype=np.uint64)
+        wts = np.empty((b.value, 8), dtype=np.uint64) if weights else None
+        _lib.check(self._lib.chad_map_export_clusters(self._h, submap, keys.ctypes.data, tsdf.ctypes.data, wts.ctypes.data if weights else None, b.value, C.byref(b)),
+                   "TSDFMap.export_clusters")
+        return keys, tsdf, wts
 
 
 # ---- stage entry points (parity tests call the device through these) ---------------------------------

@@ -54,7 +54,9 @@ enum {
                                over the inserts since the previous stats call (at most 64) */
     CHAD_FLAG_TIME_UPDATE = 4u, /* only the TSDF-update kernel is timed (ms_oct_upd), by the begin / end time stamps of its own dispatch;
                                    frames stay pipelined (up to three in flight) */
-    CHAD_FLAG_FIXED_CAPACITY = 8u /* never grow the block pool beyond max_blocks (default: it doubles between frames when half full) */
+    CHAD_FLAG_FIXED_CAPACITY = 8u, /* never grow the block pool beyond max_blocks (default: it doubles between frames when half full) */
+    CHAD_FLAG_DAG_SATURATE_WEIGHTS = 16u /* weight clusters hold min(weight, 254).  Default (off) is what the reference stores:
+                                            std::max<uint8_t>(w, 255) at submap.hpp:93 makes every weight byte 0xff */
 };
 enum {
     CHAD_UPDATE_AUTO = 0,    /* chosen per frame on the device from its points-per-block ratio (default) */
@@ -120,6 +122,36 @@ chad_status chad_map_export_blocks_device(chad_map* map, int32_t submap, uint64_
 chad_status chad_map_export_blocks_device_unordered(chad_map* map, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks);
 /* Close the active submap as if a roll-over happened, replacing its content by the given (merged) blocks. */
 chad_status chad_map_close_submap_with_blocks_device(chad_map* map, const uint64_t* keys_device, const float* sum_device, const uint32_t* cnt_device, size_t blocks);
+
+/* Submap::finalize (submap.hpp:10-106) and NodeLevels (levels.hpp:141-199): every closed submap is folded, in closing
+ * order, into one map-wide DAG -- twenty node levels plus the leaf clusters (cluster.hpp:9-108), each storing a node once
+ * and handing out addresses in order of first occurrence, the signed-distance tree before the weight tree.  The device
+ * quantises each brick into its eight leaf clusters and delivers them in Morton order; the host folds that stream into
+ * the levels.  Lazy: chad_map_finalize (and every chad_map_dag_* call) folds the submaps closed since the last call;
+ * the roll-over inside insert() only archives the bricks, so the insert loop never waits for it.
+ * The arrays are address-for-address the reference's NodeLevel::_raw_data[0, _occupied_n) (level 0..19, uint32 words:
+ * child mask, then the addresses of the set bits) and LeafClusterLevel::_raw_data (level 20 = CHAD_DAG_CLUSTER_LEVEL,
+ * uint64 words); word 0 of every level is reserved (levels.hpp:52,118). */
+enum { CHAD_DAG_NODE_LEVELS = 20, CHAD_DAG_CLUSTER_LEVEL = 20 };
+typedef struct chad_dag_stats {
+    uint64_t submaps;               /* closed submaps folded into the DAG so far */
+    uint32_t uniques[21], dupes[21]; /* NodeLevel::_uniques_n/_dupes_n per level (levels.hpp:88); [20] = leaf clusters (levels.hpp:136) */
+    float ms_device, ms_host;       /* of the last chad_map_finalize that had work: cluster kernel (+ key sort, copies) / DAG build */
+} chad_dag_stats;
+chad_status chad_map_finalize(chad_map* map);
+/* Submap::root_addr_tsdf / root_addr_weight (submap.hpp:108-109) of closed submap `submap`: addresses into level 0 */
+chad_status chad_map_dag_roots(chad_map* map, int32_t submap, uint32_t* root_tsdf, uint32_t* root_weight);
+chad_status chad_map_dag_level_words(chad_map* map, uint32_t level, size_t* words);
+/* out: uint32_t[capacity_words] for level 0..19, uint64_t[capacity_words] for level 20 */
+chad_status chad_map_dag_level_copy(chad_map* map, uint32_t level, void* out, size_t capacity_words);
+chad_status chad_map_dag_stats(chad_map* map, chad_dag_stats* out);
+/* Read-back through the DAG, the way the reference's mesh extraction walks it (lvr2.cpp:30-90): the leaves of closed
+ * submap `submap` ascending by Morton code, sd de-quantised from its byte (cluster.hpp:33-52).  mc / sd may be NULL. */
+chad_status chad_map_dag_leaves(chad_map* map, int32_t submap, uint64_t* mc, float* sd, size_t capacity, size_t* count);
+/* Stage read-back for parity tests: the device half on its own.  keys[b]: block key, ascending; tsdf[8*b+o] / weights[8*b+o]:
+ * cluster words of octet o (bits 3..5 of the code) of block b, all ones where the octet holds no leaf.  Host pointers,
+ * weights may be NULL; submap < 0: the active submap. */
+chad_status chad_map_export_clusters(chad_map* map, int32_t submap, uint64_t* keys, uint64_t* tsdf, uint64_t* weights, size_t capacity_blocks, size_t* blocks);
 
 /* Stage read-back for parity tests: intermediates of the LAST insert, copied to host.
  * order[i]: input index of the i-th point in processing order; mc[i]: its Morton code; normals: 3 floats per point.

@@ -29,6 +29,7 @@
 //   D3 (Q2) std::sort leaves the order of equal codes unspecified (morton.hpp:89); here ties are
 //      ordered by ascending input index, which is one of the orders std::sort may produce.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cfloat>
@@ -36,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <unordered_map>
 #include <vector>
 #if defined(__BMI2__)
 #include <immintrin.h>
@@ -301,6 +303,108 @@ struct Octree {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The step right behind the path: Submap::finalize (submap.hpp:10-106) folds the pointer octree into the map-wide
+// DAG of NodeLevels (levels.hpp).  Results depend on insertion order only (addresses are handed out in order of
+// first occurrence); the gtl hash sets are stood in for by std::unordered_map keyed on the node's content.
+struct NodeKey {
+    uint32_t w[9]; uint32_t n;  // mask + children, n words
+    bool operator==(const NodeKey& o) const { return n == o.n && std::memcmp(w, o.w, n * 4) == 0; }
+};
+struct NodeKeyHash {
+    size_t operator()(const NodeKey& k) const {
+        uint64_t h = 0x9E3779B97F4A7C15ULL;
+        for (uint32_t i = 0; i < k.n; i++) { h ^= k.w[i]; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 29; }
+        return size_t(h);
+    }
+};
+struct NodeLevel {  // levels.hpp:8-94
+    std::vector<uint32_t> raw{0};   // :52-53 (address 0 is reserved)
+    uint32_t uniques = 0, dupes = 0;
+    std::unordered_map<NodeKey, uint32_t, NodeKeyHash> set;
+    uint32_t add(const uint32_t children[8]) {  // :56-86
+        NodeKey k{}; k.n = 1;
+        for (uint32_t i = 0; i < 8; i++) if (children[i]) { k.w[k.n++] = children[i]; k.w[0] |= 1u << i; }
+        const uint32_t addr = uint32_t(raw.size());
+        auto [it, fresh] = set.try_emplace(k, addr);
+        if (!fresh) { dupes++; return it->second; }
+        uniques++;
+        raw.insert(raw.end(), k.w, k.w + k.n);
+        return addr;
+    }
+};
+struct LeafClusterLevel {  // levels.hpp:95-139
+    std::vector<uint64_t> raw{0};   // :118-119
+    uint32_t uniques = 0, dupes = 0;
+    std::unordered_map<uint64_t, uint32_t> set;
+    uint32_t add(uint64_t value) {  // :122-134
+        auto [it, fresh] = set.try_emplace(value, uniques + 1);
+        if (!fresh) { dupes++; return it->second; }
+        uniques++;
+        raw.push_back(value);
+        return uniques;
+    }
+};
+struct NodeLevels {  // levels.hpp:141-199
+    static constexpr uint32_t MAX_DEPTH = 20;
+    NodeLevel nodes[MAX_DEPTH];
+    LeafClusterLevel leaf_clusters;
+};
+
+// cluster.hpp:13-26: 8 bits per leaf, signed distance normalised by the truncation distance
+inline uint64_t cluster_sd_bits(float signed_distance, float trunc_recip) {
+    float sd = std::min(std::max(signed_distance * trunc_recip, -1.0f), 1.0f);
+    sd = sd * 127.0f + 127.0f;
+    return uint64_t(sd);
+}
+
+// submap.hpp:10-106 -- depth-first walk of the pointer octree in child order (= ascending Morton order); every octree
+// node whose children are leaves becomes a pair of leaf clusters (signed distances, weights), every node above it a
+// pair of DAG nodes, added child-first, the signed-distance one before the weight one.
+// Q6 (submap.hpp:93): std::max<uint8_t>(w, 255) makes every stored weight 255, which is also the "empty" marker, so
+// every weight cluster is all ones.  saturate_weights = true stores min(w, 254) instead (a documented fix).
+void finalize(const Octree& oct, NodeLevels& lv, float trunc, bool saturate_weights, uint32_t& root_tsdf, uint32_t& root_weight) {
+    constexpr uint32_t D = NodeLevels::MAX_DEPTH;
+    uint8_t path[D] = {};
+    uint32_t nodes_oct[D] = {};
+    uint32_t nodes_tsdf[D][8] = {}, nodes_weight[D][8] = {};
+    nodes_oct[0] = 0;  // the octree's root (octree.hpp:17-20)
+    const float trunc_recip = 1.0f / trunc;  // :23
+    uint32_t depth = 0;
+    while (true) {
+        const uint8_t child_i = path[depth]++;
+        if (child_i >= 8) {  // :29-57
+            const uint32_t a_tsdf = lv.nodes[depth].add(nodes_tsdf[depth]);
+            const uint32_t a_weight = lv.nodes[depth].add(nodes_weight[depth]);
+            std::memset(nodes_tsdf[depth], 0, 32); std::memset(nodes_weight[depth], 0, 32);
+            if (depth == 0) { root_tsdf = a_tsdf; root_weight = a_weight; break; }
+            depth--;
+            const uint32_t at = path[depth] - 1u;
+            nodes_tsdf[depth][at] = a_tsdf; nodes_weight[depth][at] = a_weight;
+        } else if (depth < D - 1) {  // :59-68
+            const uint32_t child = oct.nodes[nodes_oct[depth]].child[child_i];
+            if (!child) continue;
+            depth++; path[depth] = 0; nodes_oct[depth] = child;
+        } else {  // :70-99
+            const uint32_t child = oct.nodes[nodes_oct[depth]].child[child_i];
+            if (!child) continue;
+            const Node& node = oct.nodes[child];
+            uint64_t c_tsdf = 0, c_weight = 0;
+            for (uint32_t leaf_i = 0; leaf_i < 8; leaf_i++) {
+                const uint32_t leaf = node.child[leaf_i];
+                uint64_t sd_bits = 0xff, w_bits = 0xff;  // cluster.hpp:28-31,62-65
+                if (leaf) {
+                    sd_bits = cluster_sd_bits(oct.leaves[leaf].sd, trunc_recip);
+                    if (saturate_weights) w_bits = std::min<uint32_t>(oct.leaves[leaf].w, 254u);
+                }
+                c_tsdf |= sd_bits << (leaf_i * 8); c_weight |= w_bits << (leaf_i * 8);
+            }
+            nodes_tsdf[depth][child_i] = lv.leaf_clusters.add(c_tsdf);
+            nodes_weight[depth][child_i] = lv.leaf_clusters.add(c_weight);
+        }
+    }
+}
+
 struct Snapshot {  // a closed submap's leaves, sorted by code (stands in for the out-of-scope DAG)
     std::vector<uint64_t> mc; std::vector<float> sd; std::vector<uint32_t> w;
 };
@@ -310,6 +414,10 @@ struct Map {
     Octree oct;
     std::vector<V3> positions;        // submap.hpp:110 (active submap)
     std::vector<Snapshot> closed;     // tsdf.cpp:54 (_submaps)
+    NodeLevels levels;                // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps
+    std::vector<std::array<uint32_t, 2>> roots;  // submap.hpp:108-109 per closed submap
+    bool saturate_weights = false;
+    double ms_finalize = 0;
     // scratch reused across frames
     std::vector<PointMc> pmc; std::vector<V3> sorted, normals; std::vector<uint64_t> walked;
     // last-frame stats
@@ -355,6 +463,18 @@ void octree_insert(Map& m, V3 pos) {
     m.updates = updates;
 }
 
+// tsdf.cpp:53-54 / :78-81: Submap::finalize into the shared DAG, then archive (the sorted leaf list is kept beside the
+// DAG for the leaf-level parity tests)
+void close_submap(Map& m) {
+    auto t0 = std::chrono::steady_clock::now();
+    uint32_t rt = 0, rw = 0;
+    finalize(m.oct, m.levels, m.trunc, m.saturate_weights, rt, rw);
+    m.ms_finalize = ms_since(t0);
+    m.roots.push_back({rt, rw});
+    m.closed.emplace_back();
+    snapshot(m.oct, m.closed.back());
+}
+
 // tsdf.cpp:39-75
 void map_insert(Map& m, const float* xyz, size_t n, const float position[3]) {
     auto t_total = std::chrono::steady_clock::now();
@@ -363,8 +483,7 @@ void map_insert(Map& m, const float* xyz, size_t n, const float position[3]) {
     else {
         const V3 d = pos - m.positions.front();
         if (std::sqrt(dot(d, d)) > 5.0f) {  // :52
-            m.closed.emplace_back();
-            snapshot(m.oct, m.closed.back());  // stands in for Submap::finalize, :53-54
+            close_submap(m);                   // :53-54
             m.positions.clear();
             m.positions.push_back(pos);        // :55-56
             m.oct.clear();                     // :57
@@ -393,7 +512,7 @@ void* oracle_map_create(float res, float trunc) { Map* m = new Map(); m->res = r
 void oracle_map_destroy(void* h) { delete static_cast<Map*>(h); }
 void oracle_map_insert(void* h, const float* xyz, size_t n, const float* pos3) { map_insert(*static_cast<Map*>(h), xyz, n, pos3); }
 // empties the active submap without archiving it (what a fresh TSDFMap would hold)
-void oracle_map_reset(void* h) { Map* m = static_cast<Map*>(h); m->oct.clear(); m->positions.clear(); m->closed.clear(); }
+void oracle_map_reset(void* h) { Map* m = static_cast<Map*>(h); m->oct.clear(); m->positions.clear(); m->closed.clear(); m->levels = NodeLevels(); m->roots.clear(); }
 size_t oracle_map_closed_count(void* h) { return static_cast<Map*>(h)->closed.size(); }
 
 // submap < 0: the active octree; otherwise the submap closed at that roll-over.  Leaves sorted by code, ascending.
@@ -419,6 +538,54 @@ void oracle_map_stats(void* h, double* out) {
     out[0] = m->ms_calc; out[1] = m->ms_sort; out[2] = m->ms_norm; out[3] = m->ms_upd; out[4] = m->ms_total;
     out[5] = double(m->updates); out[6] = double(m->oct.leaves.size() - 1); out[7] = double(m->oct.lookup.count);
     out[8] = double(m->oct.nodes.size()); out[9] = double(m->frames);
+}
+
+// ---- Submap::finalize / NodeLevels (submap.hpp, levels.hpp) ----
+void oracle_map_set_saturate_weights(void* h, int on) { static_cast<Map*>(h)->saturate_weights = on != 0; }
+// TSDFMap::save's hand-over (tsdf.cpp:78-81): finalize and archive the active submap if it holds a pose
+void oracle_map_close_submap(void* h) {
+    Map* m = static_cast<Map*>(h);
+    if (m->positions.empty()) return;
+    close_submap(*m);
+    m->positions.clear();
+    m->oct.clear();
+}
+// level 0..19: node levels (u32 words), 20: the leaf clusters (u64 words); counts include the reserved word 0
+size_t oracle_dag_level_words(void* h, uint32_t level) {
+    Map* m = static_cast<Map*>(h);
+    return level < 20 ? m->levels.nodes[level].raw.size() : level == 20 ? m->levels.leaf_clusters.raw.size() : 0;
+}
+void oracle_dag_level_copy(void* h, uint32_t level, void* out) {
+    Map* m = static_cast<Map*>(h);
+    if (level < 20) std::memcpy(out, m->levels.nodes[level].raw.data(), m->levels.nodes[level].raw.size() * 4);
+    else if (level == 20) std::memcpy(out, m->levels.leaf_clusters.raw.data(), m->levels.leaf_clusters.raw.size() * 8);
+}
+// out[0] = uniques, out[1] = dupes (levels.hpp:88,136)
+void oracle_dag_level_counts(void* h, uint32_t level, uint32_t* out) {
+    Map* m = static_cast<Map*>(h);
+    if (level < 20) { out[0] = m->levels.nodes[level].uniques; out[1] = m->levels.nodes[level].dupes; }
+    else { out[0] = m->levels.leaf_clusters.uniques; out[1] = m->levels.leaf_clusters.dupes; }
+}
+int oracle_dag_roots(void* h, uint32_t submap, uint32_t* out) {
+    Map* m = static_cast<Map*>(h);
+    if (submap >= m->roots.size()) return 1;
+    out[0] = m->roots[submap][0]; out[1] = m->roots[submap][1];
+    return 0;
+}
+double oracle_map_finalize_ms(void* h) { return static_cast<Map*>(h)->ms_finalize; }
+// Finalize a submap given as a leaf list (any order): the leaves are put into a fresh octree with the given values and
+// that octree is folded into this map's DAG as its next closed submap.  Lets a test feed the device's own (sd, w).
+void oracle_map_close_submap_from_leaves(void* h, const uint64_t* mc, const float* sd, const uint32_t* w, size_t n) {
+    Map* m = static_cast<Map*>(h);
+    Octree o;
+    for (size_t i = 0; i < n; i++) { Leaf& l = o.find_or_create(mc[i]); l.sd = sd[i]; l.w = w[i]; }
+    uint32_t rt = 0, rw = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    finalize(o, m->levels, m->trunc, m->saturate_weights, rt, rw);
+    m->ms_finalize = ms_since(t0);
+    m->roots.push_back({rt, rw});
+    m->closed.emplace_back();
+    snapshot(o, m->closed.back());
 }
 
 // ---- stage-level entry points for unit parity tests ----

@@ -52,6 +52,17 @@ def lib():
         L.oracle_walk_ray.restype = sz
         L.oracle_walk_ray.argtypes = [vp, vp, f32, f32, vp, sz]
         L.oracle_walk_rays.argtypes = [vp, sz, vp, f32, f32, vp, vp, sz]
+        L.oracle_map_set_saturate_weights.argtypes = [vp, C.c_int]
+        L.oracle_map_close_submap.argtypes = [vp]
+        L.oracle_dag_level_words.restype = sz
+        L.oracle_dag_level_words.argtypes = [vp, C.c_uint32]
+        L.oracle_dag_level_copy.argtypes = [vp, C.c_uint32, vp]
+        L.oracle_dag_level_counts.argtypes = [vp, C.c_uint32, vp]
+        L.oracle_dag_roots.restype = C.c_int
+        L.oracle_dag_roots.argtypes = [vp, C.c_uint32, vp]
+        L.oracle_map_finalize_ms.restype = C.c_double
+        L.oracle_map_finalize_ms.argtypes = [vp]
+        L.oracle_map_close_submap_from_leaves.argtypes = [vp, vp, vp, vp, sz]
         _lib = L
     return _lib
 
@@ -99,6 +110,42 @@ class OracleMap:
         got = lib().oracle_map_export_leaves(self._h, submap, _p(mc), _p(sd), _p(w), n)
         assert got == n
         return mc, sd, w
+
+    # ---- Submap::finalize / NodeLevels (submap.hpp:10-106, levels.hpp) ----
+    def set_saturate_weights(self, on: bool):
+        lib().oracle_map_set_saturate_weights(self._h, int(on))
+
+    def close_submap(self):
+        """TSDFMap::save's hand-over (tsdf.cpp:78-81): finalize + archive the active submap if it holds a pose."""
+        lib().oracle_map_close_submap(self._h)
+
+    def close_submap_from_leaves(self, mc, sd, w):
+        mc = np.ascontiguousarray(mc, dtype=np.uint64)
+        sd = _f32(sd)
+        w = np.ascontiguousarray(w, dtype=np.uint32)
+        lib().oracle_map_close_submap_from_leaves(self._h, _p(mc), _p(sd), _p(w), mc.shape[0])
+
+    def dag_level(self, level: int) -> np.ndarray:
+        """Raw words of NodeLevels::_nodes[level] (u32, level 0..19) or of the leaf clusters (u64, level 20)."""
+        n = lib().oracle_dag_level_words(self._h, level)
+        out = np.empty(n, dtype=np.uint64 if level == 20 else np.uint32)
+        lib().oracle_dag_level_copy(self._h, level, _p(out))
+        return out
+
+    def dag_level_counts(self, level: int):
+        out = np.zeros(2, dtype=np.uint32)
+        lib().oracle_dag_level_counts(self._h, level, _p(out))
+        return int(out[0]), int(out[1])
+
+    def dag_roots(self, submap: int):
+        out = np.zeros(2, dtype=np.uint32)
+        if lib().oracle_dag_roots(self._h, submap, _p(out)):
+            raise IndexError(submap)
+        return int(out[0]), int(out[1])
+
+    @property
+    def finalize_ms(self) -> float:
+        return lib().oracle_map_finalize_ms(self._h)
 
     def stats(self) -> dict:
         out = np.zeros(10, dtype=np.float64)

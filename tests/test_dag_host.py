@@ -1,0 +1,123 @@
+"""Host half of Submap::finalize (chad_tsdf_amd/csrc/dag.hpp) against the oracle's restatement of submap.hpp:10-106 and
+levels.hpp: the same leaves must give the same level arrays, address for address.  Runs without a GPU: the cluster stream
+the device would deliver is made here from the oracle's leaves with the arithmetic of cluster.hpp:13-26."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from chad_tsdf_amd import synth
+from oracle import pyoracle
+from tests.util import clusters_of_leaves
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "dag_check.cpp")
+
+
+@pytest.fixture(scope="module")
+def dagcheck(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dagcheck") / "libdagcheck.so")
+    subprocess.check_call([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-shared", "-fPIC", SRC, "-o", out])
+    lib = C.CDLL(out)
+    vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
+    lib.dagcheck_create.restype = vp
+    lib.dagcheck_destroy.argtypes = [vp]
+    lib.dagcheck_add_submap.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.dagcheck_level_words.restype = sz
+    lib.dagcheck_level_words.argtypes = [vp, u32]
+    lib.dagcheck_level_copy.argtypes = [vp, u32, vp]
+    lib.dagcheck_level_counts.argtypes = [vp, u32, vp]
+    lib.dagcheck_walk.restype = sz
+    lib.dagcheck_walk.argtypes = [vp, u32, vp, vp, sz]
+    lib.dagcheck_sd_of_bits.restype = C.c_float
+    lib.dagcheck_sd_of_bits.argtypes = [C.c_uint8, C.c_float]
+    return lib
+
+
+class HostDag:
+    def __init__(self, lib):
+        self.lib, self.h = lib, lib.dagcheck_create()
+
+    def __del__(self):
+        self.lib.dagcheck_destroy(self.h)
+
+    def add(self, keys, tsdf, wts):
+        roots = np.zeros(2, dtype=np.uint32)
+        self.lib.dagcheck_add_submap(self.h, keys.ctypes.data, tsdf.ctypes.data, wts.ctypes.data if wts is not None else None, len(keys), roots.ctypes.data)
+        return int(roots[0]), int(roots[1])
+
+    def level(self, l):
+        out = np.empty(self.lib.dagcheck_level_words(self.h, l), dtype=np.uint64 if l == 20 else np.uint32)
+        self.lib.dagcheck_level_copy(self.h, l, out.ctypes.data)
+        return out
+
+    def counts(self, l):
+        out = np.zeros(2, dtype=np.uint32)
+        self.lib.dagcheck_level_counts(self.h, l, out.ctypes.data)
+        return int(out[0]), int(out[1])
+
+    def walk(self, root, n):
+        mc = np.empty(n, dtype=np.uint64)
+        bits = np.empty(n, dtype=np.uint8)
+        k = self.lib.dagcheck_walk(self.h, root, mc.ctypes.data, bits.ctypes.data, n)
+        return k, mc, bits
+
+
+def assert_same_dag(host, oracle):
+    for l in range(21):
+        assert np.array_equal(host.level(l), oracle.dag_level(l)), f"level {l}"
+        assert host.counts(l) == oracle.dag_level_counts(l), f"level {l} uniques/dupes"
+
+
+@pytest.mark.parametrize("saturate", [False, True])
+def test_two_submaps_share_one_dag_like_the_reference(dagcheck, saturate):
+    o = pyoracle.OracleMap(0.05, 0.10)
+    o.set_saturate_weights(saturate)
+    host = HostDag(dagcheck)
+    for k, (n, seed) in enumerate([(60_000, 3), (40_000, 4)]):
+        pts, pos = synth.cfg2_frame(n, seed=seed)
+        o.insert(pts, pos)
+        mc, sd, w = o.export_leaves()
+        o.close_submap()
+        roots = host.add(*clusters_of_leaves(mc, sd, w, 0.10, saturate))
+        assert roots == o.dag_roots(k)
+        assert_same_dag(host, o)
+    # the same submap again: nothing new anywhere, every node found
+    before = [len(host.level(l)) for l in range(21)]
+    roots = host.add(*clusters_of_leaves(mc, sd, w, 0.10, saturate))
+    assert roots == o.dag_roots(1) and [len(host.level(l)) for l in range(21)] == before
+
+
+def test_empty_submap_and_single_voxel(dagcheck):
+    o = pyoracle.OracleMap(0.05, 0.10)
+    host = HostDag(dagcheck)
+    o.insert(np.zeros((0, 3), np.float32), (0, 0, 0))       # a pose, no points: finalize of an empty octree
+    o.close_submap()
+    e = np.zeros(0, dtype=np.uint64)
+    assert host.add(e, e.reshape(0, 8), None) == o.dag_roots(0)
+    assert_same_dag(host, o)
+    mc = np.array([0x7000000000000007, 0x0000000000000000], dtype=np.uint64)   # the two ends of the code range, unsorted on purpose
+    sd = np.array([0.1, -0.1], dtype=np.float32)
+    w = np.array([1, 300], dtype=np.uint32)
+    o.close_submap_from_leaves(mc, sd, w)
+    order = np.argsort(mc)
+    assert host.add(*clusters_of_leaves(mc[order], sd[order], w[order], 0.10)) == o.dag_roots(1)
+    assert_same_dag(host, o)
+
+
+def test_walk_returns_every_leaf_in_morton_order(dagcheck):
+    o = pyoracle.OracleMap(0.05, 0.10)
+    pts, pos = synth.cfg2_frame(50_000, seed=9)
+    o.insert(pts, pos)
+    mc, sd, w = o.export_leaves()
+    host = HostDag(dagcheck)
+    root, _ = host.add(*clusters_of_leaves(mc, sd, w, 0.10))
+    k, wmc, bits = host.walk(root, len(mc))
+    assert k == len(mc) and np.array_equal(wmc, mc)
+    back = np.array([dagcheck.dagcheck_sd_of_bits(int(b), 0.10) for b in np.unique(bits)], dtype=np.float32)
+    lut = dict(zip(np.unique(bits).tolist(), back.tolist()))
+    got = np.array([lut[int(b)] for b in bits], dtype=np.float32)
+    assert np.abs(got - sd).max() <= 0.10 / 127 + 1e-6       # one quantisation step (cluster.hpp:13-26: truncation, not rounding)

@@ -1,0 +1,161 @@
+"""Submap::finalize on the device + host: leaf clusters quantised on the GPU, folded into the
+NodeLevels DAG on the host, against the oracle's restatement of submap.hpp:10-106 / levels.hpp / cluster.hpp.
+
+Bar: cluster words, every level array, the uniques/dupes counters and the root addresses bit-exact when the oracle
+finalizes the device's own leaves (same sd, same w).  Against the oracle's own insert the signed distances agree to
+1e-4 (tests/test_gpu_parity.py), so a byte may fall on the other side of a quantisation step: there the leaf sets must
+be identical and every byte within one step."""
+import numpy as np
+import pytest
+
+from chad_tsdf_amd import synth
+from tests.util import assert_leaves_match, clusters_of_leaves
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def chad():
+    import chad_tsdf_amd
+
+    chad_tsdf_amd._lib.load()  # raises if the in-tree HIP library is missing: no fallback
+    return chad_tsdf_amd
+
+
+def corridor(frames, n, step=12):
+    """Every `step`-th frame of the cfg3 corridor: 0.6 m between poses, a roll-over every ninth frame."""
+    return [synth.cfg3_frame(step * k, n) for k in range(frames)]
+
+
+def assert_same_dag(m, o):
+    for l in range(21):
+        assert np.array_equal(m.dag_level(l), o.dag_level(l)), f"level {l}"
+    st = m.dag_stats()
+    for l in range(21):
+        assert (st["uniques"][l], st["dupes"][l]) == o.dag_level_counts(l), f"level {l} uniques/dupes"
+
+
+@pytest.mark.parametrize("res,trunc,n", [(0.05, 0.10, 200_000), (0.02, 0.06, 60_000), (0.10, 0.20, 30_000)])
+def test_leaf_clusters_are_the_quantised_leaves(chad, res, trunc, n):
+    m = chad.TSDFMap(res, trunc)
+    for seed in (5, 6):
+        pts, pos = synth.cfg2_frame(n, seed=seed)
+        m.insert(pts, pos)
+    mc, sd, w = m.export_leaves()
+    keys, tsdf, wts = m.export_clusters()
+    wk, wt, ww = clusters_of_leaves(mc, sd, w, trunc, saturate=True)
+    assert np.array_equal(keys, wk)
+    assert np.array_equal(tsdf, wt)
+    assert np.array_equal(wts, ww)
+    assert (tsdf == np.uint64(0xFFFFFFFFFFFFFFFF)).any() and (tsdf != np.uint64(0xFFFFFFFFFFFFFFFF)).any()   # empty and filled octets
+
+
+@pytest.mark.parametrize("saturate", [False, True])
+def test_dag_equals_the_oracles_finalize_of_the_same_leaves(chad, oracle, saturate):
+    m = chad.TSDFMap(0.05, 0.10, dag_saturate_weights=saturate)
+    o = oracle.OracleMap(0.05, 0.10)
+    o.set_saturate_weights(saturate)
+    for pts, pos in corridor(20, 40_000):
+        m.insert(pts, pos)
+    m.close_submap()                      # TSDFMap::save's hand-over (tsdf.cpp:78-81)
+    closed = m.closed_submaps
+    assert closed == 3
+    for k in range(closed):
+        o.close_submap_from_leaves(*m.export_leaves(k))
+    assert_same_dag(m, o)
+    for k in range(closed):
+        assert m.dag_roots(k) == o.dag_roots(k)
+    assert m.dag_stats()["submaps"] == closed
+    assert m.dag_stats()["dupes"][20] > 0          # clusters are shared across the submaps of one corridor
+
+
+def test_dag_against_the_oracles_own_inserts(chad, oracle):
+    m = chad.TSDFMap(0.05, 0.10)
+    o = oracle.OracleMap(0.05, 0.10)
+    for pts, pos in corridor(12, 30_000):
+        m.insert(pts, pos)
+        o.insert(pts, pos)
+    m.close_submap()
+    o.close_submap()
+    assert m.closed_submaps == o.closed_submaps == 2
+    trees_equal = 0
+    for k in range(2):
+        mc, sd = m.dag_leaves(k)
+        omc, osd, ow = o.export_leaves(k)
+        assert np.array_equal(mc, omc)                                  # the same leaves hang in the tree
+        want = clusters_of_leaves(omc, osd, ow, 0.10)[1]
+        got = m.export_clusters(k, weights=False)[1]
+        step = (got.view(np.uint8).astype(np.int16) - want.view(np.uint8).astype(np.int16))
+        assert np.abs(step).max() <= 1                                   # a byte off by one step at most ...
+        assert (step != 0).mean() < 1e-3                                 # ... and rarely
+        trees_equal += int(np.array_equal(got, want))
+        assert np.abs(sd - osd).max() <= 0.10 / 127 + 1e-5              # cluster.hpp:13-26 truncates: one step
+    if trees_equal == 2:                                                # no byte on a step boundary: then everything matches
+        assert_same_dag(m, o)
+        assert m.dag_roots(1) == o.dag_roots(1)
+
+
+def test_finalize_is_lazy_in_order_and_leaves_the_insert_loop_alone(chad, oracle):
+    m = chad.TSDFMap(0.05, 0.10)
+    o = oracle.OracleMap(0.05, 0.10)
+    frames = corridor(22, 20_000)
+    for pts, pos in frames[:10]:
+        m.insert(pts, pos)
+    assert m.closed_submaps == 1
+    r0 = m.dag_roots(0)                   # folds submap 0 while the second submap is being filled
+    before = [m.dag_level(l) for l in range(21)]
+    with pytest.raises(chad._lib.ChadError):
+        m.dag_roots(1)                    # not closed yet
+    for pts, pos in frames[10:]:
+        m.insert(pts, pos)
+    assert m.closed_submaps == 2
+    m.finalize()
+    assert m.dag_roots(0) == r0
+    for l in range(21):                   # levels only ever grow at the end (addresses stay valid)
+        assert np.array_equal(m.dag_level(l)[:len(before[l])], before[l])
+    for k in range(2):
+        o.close_submap_from_leaves(*m.export_leaves(k))
+    assert_same_dag(m, o)
+    # the active submap went on undisturbed: it holds the frames since the second roll-over (poses 0.6 m apart: frames 9, 18)
+    ref = oracle.OracleMap(0.05, 0.10)
+    for pts, pos in frames[18:]:
+        ref.insert(pts, pos)
+    assert_leaves_match(m.export_leaves(-1), ref.export_leaves(-1), 0.10)
+
+
+def test_reset_forgets_the_dag_and_an_empty_submap_has_a_root(chad, oracle):
+    m = chad.TSDFMap(0.05, 0.10)
+    pts, pos = synth.cfg2_frame(30_000, seed=21)
+    m.insert(pts, pos)
+    m.close_submap()
+    assert len(m.dag_level(20)) > 1
+    m.reset()
+    assert [len(m.dag_level(l)) for l in range(21)] == [1] * 21
+    m.insert(np.zeros((0, 3), np.float32), pos)      # a pose, no points
+    m.close_submap()
+    o = oracle.OracleMap(0.05, 0.10)
+    o.insert(np.zeros((0, 3), np.float32), pos)
+    o.close_submap()
+    assert m.dag_roots(0) == o.dag_roots(0)
+    assert_same_dag(m, o)
+    assert m.dag_leaves(0)[0].size == 0
+
+
+def test_full_size_submap_round_trips_through_the_dag(chad):
+    """cfg2 at full size (1 M points, 335 k leaves): every leaf comes back out of the DAG, in Morton order, one
+    quantisation step from its mean; a second identical submap adds nothing to any level."""
+    m = chad.TSDFMap(0.05, 0.10)
+    pts, pos = synth.cfg2_frame()
+    m.insert(pts, pos)
+    m.close_submap()
+    mc, sd, w = m.export_leaves(0)
+    dmc, dsd = m.dag_leaves(0)
+    assert np.array_equal(dmc, mc)
+    assert np.abs(dsd - sd).max() <= 0.10 / 127 + 1e-6
+    words = [len(m.dag_level(l)) for l in range(21)]
+    m.insert(pts, pos)
+    m.close_submap()
+    assert [len(m.dag_level(l)) for l in range(21)] == words
+    assert m.dag_roots(1) == m.dag_roots(0)
+    st = m.dag_stats()
+    assert st["uniques"][20] + 1 == words[20] and st["ms_device"] > 0

@@ -23,3 +23,19 @@ def by_input_index(order, values, n):
     out = np.zeros((n,) + values.shape[1:], dtype=values.dtype)
     out[order] = values
     return out
+
+
+def clusters_of_leaves(mc, sd, w, trunc, saturate=False):
+    """What k_leaf_clusters delivers: block keys ascending and eight cluster words per block (cluster.hpp:13-31)."""
+    recip = np.float32(1.0) / np.float32(trunc)
+    q = np.clip(sd.astype(np.float32) * recip, np.float32(-1), np.float32(1)) * np.float32(127) + np.float32(127)
+    sd_bits = q.astype(np.uint64)
+    keys, block_of = np.unique(mc & ~np.uint64(63), return_inverse=True)
+    tsdf = np.full((len(keys), 64), 0xFF, dtype=np.uint64)
+    wts = np.full((len(keys), 64), 0xFF, dtype=np.uint64)
+    cell = (mc & np.uint64(63)).astype(np.int64)
+    tsdf[block_of, cell] = sd_bits
+    wts[block_of, cell] = np.minimum(w, 254).astype(np.uint64)
+    shifts = (np.arange(8, dtype=np.uint64) * np.uint64(8))
+    pack = lambda a: np.bitwise_or.reduce(a.reshape(len(keys), 8, 8) << shifts, axis=2)
+    return keys, np.ascontiguousarray(pack(tsdf)), np.ascontiguousarray(pack(wts)) if saturate else None
