@@ -173,6 +173,19 @@ def main():
         },
     }
 
+    if rank == 0 and world == 1:
+        # the row behind the path, outside the timed region: the last step's map closed and folded
+        # into the DAG of NodeLevels (Submap::finalize, submap.hpp:10-106)
+        m.close_submap()
+        m.sync()
+        t1 = time.perf_counter()
+        m.finalize()
+        fin_ms = (time.perf_counter() - t1) * 1e3
+        ds = m.dag_stats()
+        out["finalize"] = {"ms": round(fin_ms, 3), "ms_device": round(ds["ms_device"], 3), "ms_host": round(ds["ms_host"], 3),
+                           "blocks": int(st["blocks"]), "leaves": n_voxels, "unique_clusters": ds["uniques"][20],
+                           "dag_words": int(sum(len(m.dag_level(l)) * (2 if l == 20 else 1) for l in range(21)))}
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import pyoracle  # CPU baseline leg only: the checker, timed -- never on the product path
 
@@ -204,6 +217,10 @@ def main():
             "stage_ms": dict(zip(("mc_calc", "mc_sort", "norm_est", "oct_upd", "total"), (stage / frames).round(2).tolist())),
         }
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        o.reset()
+        o.close_submap_from_leaves(mc, sd, w)  # the oracle's finalize of the same leaves, on one core
+        out["finalize"]["cpu_ms"] = round(o.finalize_ms, 3)
+        out["finalize"]["levels_identical"] = bool(all(np.array_equal(m.dag_level(l), o.dag_level(l)) for l in range(21)))
 
     if rank == 0:
         print(json.dumps(out))

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Generates the small golden vectors under tests/golden/ (SURVEY.md section 8(c) G1-G6).
+"""Generates the small golden vectors under tests/golden/ (SURVEY.md section 8(c) G1-G6, and G8 for the finalize row 8(f1)).
 
 PROVENANCE.  The reference itself cannot be built or run in this image (it needs glm, gtl, libmorton and fmt, none of
 which is installed, and upstream ships no fixtures), so these vectors are produced by the oracle -- the CPU
 restatement in oracle/chad_oracle.cpp -- AFTER that oracle reproduced the scalar summaries of a real reference run
 recorded in SURVEY.md section 8(c) G7 (tests/test_oracle_survey_pins.py).  They freeze the oracle's behaviour so that
 later edits to the oracle or the generators cannot drift unnoticed, and they give the GPU parity tests fixed inputs
-with fixed expected outputs.  Run from the repo root:  python tests/golden/make_golden.py
+with fixed expected outputs.  Run from the repo root:  python tests/golden/make_golden.py [names...]
 """
 import os
 import sys
@@ -84,8 +84,30 @@ def g6_sequence():
                 active_mc=a_mc, active_sd=a_sd, active_w=a_w.astype(np.uint16))
 
 
+def g8_finalize():
+    """Submap::finalize (submap.hpp:10-106): two submaps given as leaf lists, folded one after the other into one DAG.
+    Expected: the 21 level arrays after each submap, the uniques/dupes counters and the roots."""
+    m = po.OracleMap(0.05, 0.10)
+    out = {}
+    for k, seed in enumerate((81, 82)):
+        src = po.OracleMap(0.05, 0.10)
+        pts, pos = synth.cfg2_frame(2500, seed=seed)
+        src.insert(pts, pos)
+        mc, sd, w = src.export_leaves()
+        m.close_submap_from_leaves(mc, sd, w)
+        out.update({f"s{k}_mc": mc, f"s{k}_sd": sd, f"s{k}_w": w.astype(np.uint16), f"s{k}_roots": np.array(m.dag_roots(k), np.uint32)})
+        for l in range(21):
+            out[f"s{k}_level{l}"] = m.dag_level(l)
+        out[f"s{k}_counts"] = np.array([m.dag_level_counts(l) for l in range(21)], np.uint32)
+    return out
+
+
 if __name__ == "__main__":
-    for name, fn in (("g1_morton", g1_morton), ("g3_normals", g3_normals), ("g4_rays", g4_rays), ("g5_leaves", g5_leaves), ("g6_sequence", g6_sequence)):
+    every = (("g1_morton", g1_morton), ("g3_normals", g3_normals), ("g4_rays", g4_rays), ("g5_leaves", g5_leaves), ("g6_sequence", g6_sequence),
+             ("g8_finalize", g8_finalize))
+    for name, fn in every:
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **fn())
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")

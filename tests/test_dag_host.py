@@ -121,3 +121,14 @@ def test_walk_returns_every_leaf_in_morton_order(dagcheck):
     lut = dict(zip(np.unique(bits).tolist(), back.tolist()))
     got = np.array([lut[int(b)] for b in bits], dtype=np.float32)
     assert np.abs(got - sd).max() <= 0.10 / 127 + 1e-6       # one quantisation step (cluster.hpp:13-26: truncation, not rounding)
+
+
+def test_g8_golden_levels(dagcheck):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g8_finalize.npz"))
+    host = HostDag(dagcheck)
+    for k in range(2):
+        roots = host.add(*clusters_of_leaves(g[f"s{k}_mc"], g[f"s{k}_sd"], g[f"s{k}_w"].astype(np.uint32), 0.10))
+        assert roots == tuple(int(x) for x in g[f"s{k}_roots"])
+        for l in range(21):
+            assert np.array_equal(host.level(l), g[f"s{k}_level{l}"]), (k, l)
+            assert host.counts(l) == tuple(int(x) for x in g[f"s{k}_counts"][l])

@@ -67,3 +67,28 @@ def test_g6_sequence_with_rollover(chad, mode):
     assert_leaves_match(m.export_leaves(0), (g["closed_mc"], g["closed_sd"], g["closed_w"].astype(np.uint32)), 0.10)
     assert_leaves_match(m.export_leaves(-1), (g["active_mc"], g["active_sd"], g["active_w"].astype(np.uint32)), 0.10)
     m.close()
+
+
+def test_g8_finalize(chad):
+    """The golden submaps enter as bricks holding one observation per leaf (sum = sd, count = 1, so the mean is sd exactly)
+    through the merge's entry point; the DAG must come out as frozen."""
+    import torch
+
+    g = gold("g8_finalize")
+    m = chad.TSDFMap(0.05, 0.10)
+    dev = torch.device("cuda", 0)
+    for k in range(2):
+        mc, sd = g[f"s{k}_mc"], g[f"s{k}_sd"]
+        keys, block_of = np.unique(mc & ~np.uint64(63), return_inverse=True)
+        shuffle = np.random.default_rng(k).permutation(len(keys))          # archives are unordered: finalize sorts them
+        s = np.zeros((len(keys), 64), np.float32)
+        c = np.zeros((len(keys), 64), np.int32)
+        cell = (mc & np.uint64(63)).astype(np.int64)
+        s[block_of, cell] = sd
+        c[block_of, cell] = 1
+        m.close_submap_with_blocks(torch.from_numpy(keys[shuffle].astype(np.int64)).to(dev), torch.from_numpy(s[shuffle]).to(dev), torch.from_numpy(c[shuffle]).to(dev))
+        assert m.dag_roots(k) == tuple(int(x) for x in g[f"s{k}_roots"])
+        st = m.dag_stats()
+        for l in range(21):
+            assert np.array_equal(m.dag_level(l), g[f"s{k}_level{l}"]), (k, l)
+            assert (st["uniques"][l], st["dupes"][l]) == tuple(int(x) for x in g[f"s{k}_counts"][l])

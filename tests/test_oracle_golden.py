@@ -135,3 +135,19 @@ def test_empty_and_degenerate_frames(oracle):
     m.insert(np.repeat(np.array([[2.0, 1.0, 0.5]], np.float32), 12, axis=0), [0, 0, 0])     # Q4: NaN normal -> NaN sd, like upstream
     mc, sd, w = m.export_leaves()
     assert len(mc) > 0 and np.isnan(sd).all() and (w == 12).all()
+
+
+def test_g8_finalize(oracle):
+    """Submap::finalize + NodeLevels (submap.hpp:10-106, levels.hpp): frozen level arrays, counters and roots."""
+    g = gold("g8_finalize")
+    m = oracle.OracleMap(0.05, 0.10)
+    for k in range(2):
+        m.close_submap_from_leaves(g[f"s{k}_mc"], g[f"s{k}_sd"], g[f"s{k}_w"].astype(np.uint32))
+        assert m.dag_roots(k) == tuple(int(x) for x in g[f"s{k}_roots"])
+        for l in range(21):
+            assert np.array_equal(m.dag_level(l), g[f"s{k}_level{l}"]), (k, l)
+            assert m.dag_level_counts(l) == tuple(int(x) for x in g[f"s{k}_counts"][l])
+    # structure of the arrays (levels.hpp:56-86): word 0 reserved; a node is its child mask followed by one address per set bit
+    top = g["s1_level0"]
+    assert top[0] == 0 and bin(int(top[1])).count("1") + 2 <= len(top)
+    assert g["s1_level20"][0] == 0 and (g["s1_level20"][1:] == np.uint64(0xFFFFFFFFFFFFFFFF)).sum() == 1   # Q6: one all-ones weight cluster
