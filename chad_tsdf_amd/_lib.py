@@ -76,6 +76,7 @@ SYMBOLS = {
     "chad_map_insert_device": (_i32, [_vp, _vp, _sz, _vp]),
     "chad_map_sync": (_i32, [_vp]),
     "chad_map_reset": (_i32, [_vp]),
+    "chad_map_would_roll_over": (_i32, [_vp, _vp, C.POINTER(_i32)]),
     "chad_map_close_submap": (_i32, [_vp]),
     "chad_map_leaf_count": (_i32, [_vp, _i32, C.POINTER(_sz)]),
     "chad_map_export_leaves": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),

@@ -463,13 +463,19 @@ chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
 // Submap bookkeeping of an insert, tsdf.cpp:46-61 (f32 distance in the reference's operation order; this file is built
 // with -ffp-contract=off): the first pose of a submap is remembered, and a frame taken more than 5 m from it closes the
 // submap and opens the next one.
+// tsdf.cpp:50-52: would a frame taken at `position` finalize the active submap?
+inline bool rolls_over(const chad_map* m, const float position[3]) {
+    if (m->positions.empty()) return false;
+    const std::array<float, 3>& first = m->positions.front();
+    const float dx = position[0] - first[0], dy = position[1] - first[1], dz = position[2] - first[2];
+    return std::sqrt(dx * dx + dy * dy + dz * dz) > 5.0f;
+}
+
 chad_status note_pose(chad_map* m, const float position[3]) {
     const std::array<float, 3> pose{position[0], position[1], position[2]};
     if (m->positions.empty()) m->positions.push_back(pose);
     else {
-        const std::array<float, 3>& first = m->positions.front();
-        const float dx = pose[0] - first[0], dy = pose[1] - first[1], dz = pose[2] - first[2];
-        if (std::sqrt(dx * dx + dy * dy + dz * dz) > 5.0f) {
+        if (rolls_over(m, position)) {
             TRY(close_active(m));
             m->positions.clear();
             m->positions.push_back(pose);
@@ -783,6 +789,12 @@ chad_status chad_map_reset(chad_map* m) {
     // frame's preparation does not queue behind it; anything else that looks at the map first carries it out (flush_pending_clear).
     m->pending_clear = true;
     m->pending_clear_overflow = true;
+    return CHAD_OK;
+}
+
+chad_status chad_map_would_roll_over(chad_map* m, const float position[3], int32_t* yes) {
+    if (!m || !position || !yes) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    *yes = rolls_over(m, position) ? 1 : 0;
     return CHAD_OK;
 }
 

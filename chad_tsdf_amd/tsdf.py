@@ -37,6 +37,8 @@ class TSDFMap:
         handle = C.c_void_p()
         _lib.check(self._lib.chad_map_create(sdf_res, sdf_trunc, C.byref(opt), C.byref(handle)), "TSDFMap")
         self._h = handle
+        self._yes = C.c_int32()
+        self._yes_ref = C.byref(self._yes)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -62,6 +64,20 @@ class TSDFMap:
         else:
             pts = _np_f32(points)
             _lib.check(self._lib.chad_map_insert(self._h, pts.ctypes.data, pts.shape[0], pos.ctypes.data), "TSDFMap.insert")
+
+    def note_pose(self, pos: np.ndarray):
+        """An insert without points (pose bookkeeping of tsdf.cpp:46-61 only); pos: float32[3], C-contiguous.  The cheap path
+        the frame-sharded map takes on the ranks that do not own a frame."""
+        s = self._lib.chad_map_insert_device(self._h, None, 0, pos.ctypes.data)
+        if s:
+            _lib.check(s, "TSDFMap.note_pose")
+
+    def would_roll_over(self, pos: np.ndarray) -> bool:
+        """tsdf.cpp:50-52 as a query: is pos (float32[3]) more than 5 m from the active submap's first pose?"""
+        s = self._lib.chad_map_would_roll_over(self._h, pos.ctypes.data, self._yes_ref)
+        if s:
+            _lib.check(s, "TSDFMap.would_roll_over")
+        return self._yes.value != 0
 
     def save(self, filename: str):
         """TSDFMap::save -- tsdf.cpp:76-86: close the active submap, write the FIRST submap (as PLY voxels here)."""

@@ -103,6 +103,11 @@ chad_status chad_map_reset(chad_map* map);
  * archived as a closed submap and a fresh one is started (same effect as the 5 m roll-over of tsdf.cpp:52-57). */
 chad_status chad_map_close_submap(chad_map* map);
 
+/* The roll-over rule on its own (tsdf.cpp:50-52): would an insert at `position` finalize the active submap first, i.e. is it
+ * more than 5 m from the submap's first pose?  A pure query (host arithmetic, nothing enqueued); the frame-sharded multi-GPU
+ * map asks it on every rank before every frame, so that all ranks merge the submap at the same point of the stream. */
+chad_status chad_map_would_roll_over(chad_map* map, const float position[3], int32_t* yes);
+
 /* Read-back extension (the reference's iterator API is commented out, tsdf.hpp:120-161).
  * submap < 0: the active submap; 0..closed-1: a submap closed by the 5 m roll-over rule (tsdf.cpp:52-58).
  * Leaves are the voxels with weight > 0, sorted by Morton code ascending: mc as MortonCode::_value

@@ -261,3 +261,28 @@ def test_sharded_map_with_one_rank_equals_the_plain_map(chad):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
         assert rel_err(got[1], want[1], 0.10) <= SD_TOL   # f32 atomic sums: the order of arrival differs from run to run
     plain.close(); shard.local.close()
+
+
+def test_roll_over_query_is_the_rule_of_the_insert(chad):
+    """chad_map_would_roll_over answers tsdf.cpp:50-52 without side effects; the sharded map's C-call path and its numpy
+    path (the one stand-in maps take) close submaps at the same frames."""
+    from chad_tsdf_amd.sharded import ShardedTSDFMap
+
+    m = chad.TSDFMap(0.05, 0.10)
+    f32 = lambda *v: np.asarray(v, dtype=np.float32)
+    assert not m.would_roll_over(f32(100, 0, 0))                 # no pose yet: the first insert only records it (tsdf.cpp:48)
+    m.insert(np.zeros((0, 3), np.float32), f32(1, 2, 3))
+    assert not m.would_roll_over(f32(6, 2, 3))                   # exactly 5 m: the rule is "> 5.0f"
+    assert m.would_roll_over(f32(6.000001, 2, 3)) and m.would_roll_over(f32(1, 2, -2.01))
+    assert m.closed_submaps == 0                                 # asking changed nothing
+    m.insert(np.zeros((0, 3), np.float32), f32(6.5, 2, 3))
+    assert m.closed_submaps == 1 and not m.would_roll_over(f32(11.4, 2, 3)) and m.would_roll_over(f32(11.6, 2, 3))
+    closed = []
+    for fast in (True, False):
+        s = ShardedTSDFMap(0.05, 0.10)
+        s._fast = fast
+        for k in range(0, 260, 7):
+            pts, pos = synth.cfg3_frame(k, 3000)
+            s.insert(pts, pos)
+        closed.append((s.closed_submaps, s.local.stats()["blocks"], s.local.export_leaves(-1)[2].sum()))
+    assert closed[0] == closed[1] and closed[0][0] == 2
