@@ -69,7 +69,8 @@ enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
 // waits for the updates enqueued so far and makes the later ones wait for it (exclusive_begin / exclusive_end below).
 struct FrameSlot {
     hipStream_t prep = nullptr;
-    hipEvent_t update_done = nullptr;   // recorded on `prep` behind the update: an exclusive operation on the map waits for it
+    hipEvent_t update_done = nullptr;   // recorded on `prep` behind its last update when somebody has to wait for it (updates_done)
+    bool tail_unrecorded = false;       // frames have been enqueued on `prep` since update_done was last recorded
     bool used = false;
     uint64_t seen_epoch = 0;            // the last exclusive operation this stream has been made to wait for
     FrameHeader* d_hdr = nullptr;
@@ -180,12 +181,23 @@ chad_status join_streams(chad_map* m) {
     return CHAD_OK;
 }
 
+// The event behind the last update enqueued on a slot's stream.  Recorded here, when somebody is about to wait for it, and
+// not once per frame: a stream of small frames is bound by the host's launch rate, and most frames are never waited for.
+chad_status updates_done(FrameSlot& f, hipEvent_t* out) {
+    if (f.tail_unrecorded) { HIP_TRY(hipEventRecord(f.update_done, f.prep)); f.tail_unrecorded = false; }
+    *out = f.update_done;
+    return CHAD_OK;
+}
+
 // The map stream is about to do something that needs the map to itself: it waits (on the device) for every update
 // enqueued so far.
 chad_status exclusive_begin(chad_map* m) {
     for (uint32_t k = 0; k < m->n_slots; k++) {
         FrameSlot& f = m->slot[k];
-        if (f.used && f.prep != m->stream) HIP_TRY(hipStreamWaitEvent(m->stream, f.update_done, 0));
+        if (!f.used || f.prep == m->stream) continue;
+        hipEvent_t done;
+        TRY(updates_done(f, &done));
+        HIP_TRY(hipStreamWaitEvent(m->stream, done, 0));
     }
     return CHAD_OK;
 }
@@ -209,7 +221,7 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
         HIP_TRY(hipMalloc(&f.sort.points[i], cap * 16));  // the points travel with their keys; the last pass's output is the frame in processing order
     }
     HIP_TRY(hipMalloc(&f.sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kMaxPasses) * kRadix * 4));
+    HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     f.sort.tiles_capacity = radix_tiles(cap);
     HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
@@ -510,9 +522,9 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     uint4* item_start = reinterpret_cast<uint4*>(f.d_seg + 2 * size_t(list_stride) * kListStripes);
     if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, prep, f.d_hdr);
     if (count) {
-        hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part);
+        hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
         hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
-                           f.sort.hist_part, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
+                           f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
         record(m, T_CALC, prep);
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
         // last of them covering whatever else the frame turns out to need (radix_sort.hpp, k_radix_onesweep to_limit)
@@ -537,7 +549,10 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     if (m->pending_clear) {
         for (uint32_t k = 0; k < m->n_slots; k++) {
             FrameSlot& o = m->slot[k];
-            if (&o != &f && o.used && o.prep != prep) HIP_TRY(hipStreamWaitEvent(prep, o.update_done, 0));
+            if (&o == &f || !o.used || o.prep == prep) continue;
+            hipEvent_t done;
+            TRY(updates_done(o, &done));
+            HIP_TRY(hipStreamWaitEvent(prep, done, 0));
         }
         hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, prep, m->view, m->pending_clear_overflow ? 1u : 0u);
         m->pending_clear = false; m->pending_clear_overflow = false;
@@ -565,7 +580,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         if (!times_stages(m)) record(m, T_NORM, prep);
         record(m, T_UPD, prep);
     }
-    HIP_TRY(hipEventRecord(f.update_done, prep));
+    f.tail_unrecorded = true;   // (update_done is recorded when somebody waits for it: updates_done)
     f.used = true;
     HIP_TRY(hipGetLastError());
     m->frames++;
@@ -1135,7 +1150,7 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     const size_t cap = size_t(tiles) * kSortTile;
     for (int i = 0; i < 2; i++) { HIP_TRY(hipMalloc(&b.keys[i], cap * 8)); HIP_TRY(hipMalloc(&b.idx[i], cap * 4)); }
     HIP_TRY(hipMalloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&b.digit_base, size_t(kMaxPasses) * kRadix * 4));
+    HIP_TRY(hipMalloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&b.tile_status, radix_status_words(tiles) * 4));
     HIP_TRY(hipMemcpy(b.keys[0], keys, n * 8, hipMemcpyHostToDevice));
     const uint32_t passes = std::max(1u, (key_bits + kRadixBits - 1) / kRadixBits);

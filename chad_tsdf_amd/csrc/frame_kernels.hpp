@@ -133,8 +133,10 @@ __device__ __forceinline__ F3 load_point(const float* __restrict__ xyz, size_t i
 
 // Stage 1: voxel bounds and the count of usable points, one partial per workgroup.
 __global__ void __launch_bounds__(256)
-k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FramePartial* __restrict__ part) {
+k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FramePartial* __restrict__ part, uint32_t* __restrict__ digit_total) {
     __shared__ int red[4][7];
+    // the sort's digit totals, which the keys kernel adds into (saves the sort a kernel of its own for them)
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < kBaseStripes * kMaxPasses * kRadix; k += gridDim.x * blockDim.x) digit_total[k] = 0u;
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {int(0x80000000), int(0x80000000), int(0x80000000)};
     uint32_t kept = 0;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -230,7 +232,7 @@ __device__ __forceinline__ LocalFrame combine_bounds(const FramePartial* __restr
 __global__ void __launch_bounds__(256)
 k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
              FramePartial* __restrict__ part, uint64_t* __restrict__ keys,
-             uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words,
+             uint32_t* __restrict__ digit_total, uint32_t* __restrict__ tile_status, uint32_t status_words,
              const uint32_t* __restrict__ live_blocks, uint32_t* __restrict__ live_blocks_host) {
     if (blockIdx.x == 0) frame_header_reset(h);
     if (blockIdx.x == 0) {  // host-mapped: capacity growth hint (the live-brick counter is striped, one stripe per thread)
@@ -274,7 +276,11 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
         for (uint32_t p = 0; p < passes; p++) atomicAdd(&hist[p][uint32_t(key >> (p * kRadixBits)) & (kRadix - 1)], 1u);
     }
     __syncthreads();
-    for (uint32_t p = 0; p < passes; p++) hist_part[(size_t(blockIdx.x) * kMaxPasses + p) * kRadix + threadIdx.x] = hist[p][threadIdx.x];
+    // digit totals of the radix passes (RadixSortBuffers::digit_base): one of kBaseStripes copies per workgroup, zero counts skipped
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t c = hist[p][threadIdx.x];
+        if (c) atomicAdd(&digit_total[((blockIdx.x & (kBaseStripes - 1u)) * kMaxPasses + p) * kRadix + threadIdx.x], c);
+    }
     mc_min = wave_min_u64(mc_min);
     if ((threadIdx.x & 63) == 0) wave_mc[threadIdx.x >> 6] = mc_min;
     __syncthreads();

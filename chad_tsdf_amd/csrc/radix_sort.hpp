@@ -21,6 +21,7 @@ namespace chadhip {
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 constexpr int kMaxPasses = 64 / kRadixBits;
+constexpr uint32_t kBaseStripes = 8;  // the frame's keys kernel adds its digit counts into one of this many copies of the totals (atomics on one address serialise)
 constexpr int kSortThreads = 256;                       // 4 waves
 constexpr int kSortItems = 8;                           // keys per thread
 constexpr int kSortTile = kSortThreads * kSortItems;    // 2048 keys per workgroup (1024-key tiles: twice the look-back chain, 11 % slower)
@@ -69,7 +70,7 @@ struct RadixSortBuffers {
     uint32_t* idx[2];
     uint4* points[2];       // PointPayload ping-pong buffers (null for sorters that only carry indices)
     uint32_t* hist_part;    // [kHistBlocks][kMaxPasses][256] partial digit histograms
-    uint32_t* digit_base;   // [kMaxPasses][256] keys per digit (totals; every pass workgroup scans them)
+    uint32_t* digit_base;   // [kBaseStripes][kMaxPasses][256] keys per digit (totals, the sum over the stripes; every pass workgroup scans them)
     uint32_t* tile_status;  // [kMaxPasses][tiles + groups][256] look-back words, zeroed before every sort
     uint32_t* tile_ticket;  // [kMaxPasses] next tile to hand out, zeroed with tile_status (stored right behind it)
     uint32_t tiles_capacity;
@@ -129,9 +130,17 @@ template <class P>
 __device__ __forceinline__ void
 radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
                     uint64_t* __restrict__ keys_out, typename P::T* __restrict__ pay_out,
-                    uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base,
+                    uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
                     uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const void* __restrict__ first_src) {
     constexpr uint32_t kResidentTiles = P::kResident;
+    // the whole input's count of digit threadIdx.x (asked for first: needed only after the tile has been ranked)
+    // (all stripes loaded back to back: a loop over base_stripes waited for each load in turn, 2.5 us per pass)
+    uint32_t stripe_total[kBaseStripes];
+#pragma unroll
+    for (uint32_t s = 0; s < kBaseStripes; s++) stripe_total[s] = digit_base[((s < base_stripes ? s : 0u) * kMaxPasses + pass) * kRadix + threadIdx.x];
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < kBaseStripes; s++) total += s < base_stripes ? stripe_total[s] : 0u;
     __shared__ uint32_t wave_count[kSortWaves][kRadix];  // per-wave digit counts, then the wave's base inside the tile
     __shared__ int offset[kRadix];                       // global slot of local sorted position s is offset[digit] + s
     __shared__ uint32_t wave_total[kSortWaves], wave_total_all[kSortWaves];
@@ -196,7 +205,6 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 
     // exclusive scans over the digits: of the tile's counts (position of digit d's run in the locally sorted tile) and of
     // the whole input's counts (first output slot of digit d; k_radix_bases left the per-digit totals)
-    const uint32_t total = digit_base[pass * kRadix + d];
     uint32_t incl = count, incl_all = total;
     {
         const uint32_t l = d & 63;
@@ -273,13 +281,13 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 template <class P>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
-                 uint32_t n, uint32_t first_pass, uint32_t to_limit, uint32_t tiles, const uint32_t* __restrict__ digit_base,
+                 uint32_t n, uint32_t first_pass, uint32_t to_limit, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
                  uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src) {
     const uint32_t limit = pass_limit ? min(uint32_t(kMaxPasses), *pass_limit) : uint32_t(kMaxPasses);
     uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
     for (uint32_t pass = first_pass; pass < limit; pass++) {
         const bool odd = pass & 1u;
-        radix_onesweep_tile<P>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base,
+        radix_onesweep_tile<P>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base, base_stripes,
                                tile_status, tile_ticket, first_src);
         if (!to_limit || pass + 1 >= limit) break;
         // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
@@ -306,11 +314,12 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     const uint32_t tiles = radix_tiles(n);
     uint32_t* ticket = b.tile_status + radix_status_words(tiles) - 64;
     if (hist_blocks == 0) {
-        hist_blocks = kHistBlocks;
         hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part, b.tile_status,
                            uint32_t(radix_status_words(tiles)));
     }
-    hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, hist_blocks, passes, pass_limit, b.digit_base);
+    // hist_blocks != 0: the caller's keys kernel has already added its digit counts into the striped totals (k_frame_keys)
+    const uint32_t base_stripes = hist_blocks ? kBaseStripes : 1u;
+    if (!hist_blocks) hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
     const bool hinted = pass_limit && launch_passes && launch_passes < passes && tiles <= P::kResident;
     const uint32_t launches = hinted ? launch_passes : passes;
     for (uint32_t p = 0; p < launches; p++) {
@@ -320,7 +329,7 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         // different streams take turns for this one launch.
         if (to_limit && one_at_a_time && wait_for_it) (void)hipStreamWaitEvent(stream, one_at_a_time, 0);
         hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                           to_limit ? 1u : 0u, tiles, b.digit_base, b.tile_status, ticket, pass_limit, first_src);
+                           to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src);
         if (to_limit && one_at_a_time) (void)hipEventRecord(one_at_a_time, stream);
     }
 }
