@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 0.12 ms: the pipeline's fill and drain, ~0.2 ms, weigh 1-2 % instead of 8 % at 20)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000, help="points per scan (BASELINE config: 1 M)")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic scans cycled through per rank")

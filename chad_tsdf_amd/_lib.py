@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchad_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_CAPACITY, ERR_HIP = range(6)
-FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS = 1, 2, 4, 8, 16
+FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS, FLAG_DAG_ONLY = 1, 2, 4, 8, 16, 32
 DAG_NODE_LEVELS, DAG_CLUSTER_LEVEL = 20, 20
 UPDATE_AUTO, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
 

@@ -55,6 +55,7 @@ struct Submap {  // a closed submap: dense copies of its bricks (stands in for t
     float* sum = nullptr;
     uint32_t* cnt = nullptr;
     uint32_t blocks = 0;
+    bool released = false;  // CHAD_FLAG_DAG_ONLY: folded into the DAG, the dense copy given back
 };
 
 enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
@@ -287,6 +288,8 @@ chad_status read_block_count(chad_map* m, uint32_t* blocks) {
     return CHAD_OK;
 }
 
+chad_status finalize_closed(chad_map* m);  // (further down, with the rest of Submap::finalize)
+
 void free_submap(Submap& s) {
     (void)hipFree(s.keys); (void)hipFree(s.sum); (void)hipFree(s.cnt);
     s = Submap{};
@@ -311,6 +314,20 @@ chad_status compact_active(chad_map* m, Submap& s, uint32_t blocks) {
     return CHAD_OK;
 }
 
+// CHAD_FLAG_DAG_ONLY: what is closed is folded into the DAG right away and its dense copy released, so that device memory
+// holds the active submap only -- what the reference keeps of a closed submap is its DAG too (tsdf.cpp:53-54).
+chad_status release_finalized(chad_map* m) {
+    if (!(m->flags & CHAD_FLAG_DAG_ONLY)) return CHAD_OK;
+    TRY(finalize_closed(m));   // synchronises with the archive copies of everything it folds
+    for (Submap& s : m->closed) {
+        if (s.released) continue;
+        const uint32_t blocks = s.blocks;
+        free_submap(s);
+        s.blocks = blocks; s.released = true;
+    }
+    return CHAD_OK;
+}
+
 // Second half of a roll-over: the closing table's block count is on the host (or is waited for if `block`): size the
 // archive, compact the table into it and clear it -- all on the map's stream, beside the frames that already fill the new
 // active table -- and keep the cleared table as the next spare.
@@ -331,7 +348,7 @@ chad_status finish_closing(chad_map* m, bool block) {
     m->closed.push_back(s);
     m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: whoever swaps it in does so on this stream
     m->closing_view = MapView{}; m->closing = false;
-    return CHAD_OK;
+    return release_finalized(m);
 }
 
 // Submap roll-over (tsdf.cpp:52-57): archive the active submap's bricks and start an empty one -- by swapping tables, so
@@ -350,7 +367,8 @@ chad_status close_active(chad_map* m) {
             Submap s;
             TRY(compact_active(m, s, blocks));
             m->closed.push_back(s);
-            return clear_active(m);
+            TRY(clear_active(m));
+            return release_finalized(m);
         }
         m->has_spare = true;
     }
@@ -376,6 +394,7 @@ chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const u
     if (size_t(submap) >= m->closed.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
     HIP_TRY(hipStreamSynchronize(m->stream));
     const Submap& s = m->closed[size_t(submap)];
+    if (s.released) return fail(CHAD_ERR_INVALID_ARG, "the submap's bricks were released (CHAD_FLAG_DAG_ONLY): read it back with chad_map_dag_leaves");
     *blocks = s.blocks; *keys = s.keys; *sum = s.sum; *cnt = s.cnt;
     return CHAD_OK;
 }
@@ -946,7 +965,7 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
     m->positions.clear();
     TRY(clear_active(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    return CHAD_OK;
+    return release_finalized(m);
 }
 
 // ---- Submap::finalize (submap.hpp:10-106): leaf clusters on the device, the DAG of NodeLevels on the host ----

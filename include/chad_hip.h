@@ -55,8 +55,12 @@ enum {
     CHAD_FLAG_TIME_UPDATE = 4u, /* only the TSDF-update kernel is timed (ms_oct_upd), by the begin / end time stamps of its own dispatch;
                                    frames stay pipelined (up to three in flight) */
     CHAD_FLAG_FIXED_CAPACITY = 8u, /* never grow the block pool beyond max_blocks (default: it doubles between frames when half full) */
-    CHAD_FLAG_DAG_SATURATE_WEIGHTS = 16u /* weight clusters hold min(weight, 254).  Default (off) is what the reference stores:
+    CHAD_FLAG_DAG_SATURATE_WEIGHTS = 16u, /* weight clusters hold min(weight, 254).  Default (off) is what the reference stores:
                                             std::max<uint8_t>(w, 255) at submap.hpp:93 makes every weight byte 0xff */
+    CHAD_FLAG_DAG_ONLY = 32u /* a closed submap is folded into the DAG as soon as its archive is complete and its dense brick copy
+                                is released: device memory then holds the active submap only (long trajectories), as the reference
+                                keeps nothing but the DAG of a closed submap (tsdf.cpp:53-54).  Closed submaps are then read back with
+                                chad_map_dag_leaves; chad_map_export_leaves / export_blocks of a closed submap fail with INVALID_ARG */
 };
 enum {
     CHAD_UPDATE_AUTO = 0,    /* chosen per frame on the device from its points-per-block ratio (default) */

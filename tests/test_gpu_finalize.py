@@ -160,3 +160,34 @@ def test_full_size_submap_round_trips_through_the_dag(chad):
     assert m.dag_roots(1) == m.dag_roots(0)
     st = m.dag_stats()
     assert st["uniques"][20] + 1 == words[20] and st["ms_device"] > 0
+
+
+def test_dag_only_mode_releases_closed_bricks_and_keeps_the_dag(chad):
+    """CHAD_FLAG_DAG_ONLY: closed submaps live in the DAG alone (what the reference keeps of them, tsdf.cpp:53-54)."""
+    import torch
+
+    a = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    b = chad.TSDFMap(0.05, 0.10)
+    for pts, pos in corridor(20, 20_000):
+        a.insert(pts, pos)
+        b.insert(pts, pos)
+    a.close_submap()
+    b.close_submap()
+    assert a.closed_submaps == b.closed_submaps == 3
+    for k in range(3):
+        with pytest.raises(chad._lib.ChadError):
+            a.export_leaves(k)                                     # the bricks are gone ...
+        amc, asd = a.dag_leaves(k)                                  # ... the tree is not
+        bmc, bsd = b.dag_leaves(k)
+        assert np.array_equal(amc, bmc) and np.array_equal(amc, b.export_leaves(k)[0])
+        assert np.abs(asd - bsd).max() <= 0.10 / 127 + 1e-6        # (the two maps' f32 sums may differ by an ulp: one step)
+        assert a.block_count(k) == b.block_count(k)
+    assert a.dag_stats()["submaps"] == 3
+    # the map goes on working, and what it archives later is released as well
+    free_before = torch.cuda.mem_get_info()[0]
+    for pts, pos in corridor(30, 20_000)[20:]:
+        a.insert(pts, pos)
+    a.close_submap()
+    a.sync()
+    assert a.closed_submaps == 5 and a.dag_stats()["submaps"] == 5
+    assert torch.cuda.mem_get_info()[0] >= free_before - (64 << 20)   # no archive copies pile up (they are ~10 MB each here)
