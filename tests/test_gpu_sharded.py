@@ -39,6 +39,9 @@ def _rank(rank, world, port, outdir):
     for s in (0, 1):
         mc, sd, w = sm.export_leaves(s)
         np.savez(os.path.join(outdir, f"rank{rank}_submap{s}.npz"), mc=mc, sd=sd, w=w)
+    # Submap::finalize of the merged submaps: every rank folds the same bricks, so the DAGs must be identical word for word
+    levels = {f"level{l}": sm.local.dag_level(l) for l in range(21)}
+    np.savez(os.path.join(outdir, f"rank{rank}_dag.npz"), roots=np.array([sm.local.dag_roots(0), sm.local.dag_roots(1)], np.uint32), **levels)
     sm.local.close()
     dist.destroy_process_group()
 
@@ -62,4 +65,16 @@ def test_two_ranks_on_one_gpu_build_the_single_process_submaps(tmp_path):
             assert np.array_equal(got["mc"], want[0]) and np.array_equal(got["w"], want[2]), f"rank {rank} submap {s}"
             err = np.abs(got["sd"] - want[1]) / np.maximum(np.abs(want[1]), 0.10)
             assert err.max() <= SD_TOL
+    # ... and the ranks' DAGs: equal to each other, and to the oracle's finalize of the merged leaves
+    from oracle import pyoracle
+
+    dags = [np.load(tmp_path / f"rank{rank}_dag.npz") for rank in range(world)]
+    o = pyoracle.OracleMap(0.05, 0.10)
+    for s in (0, 1):
+        got = np.load(tmp_path / f"rank0_submap{s}.npz")
+        o.close_submap_from_leaves(got["mc"], got["sd"], got["w"])
+    for l in range(21):
+        assert np.array_equal(dags[0][f"level{l}"], dags[1][f"level{l}"]), f"level {l} differs between the ranks"
+        assert np.array_equal(dags[0][f"level{l}"], o.dag_level(l)), f"level {l} differs from the oracle"
+    assert np.array_equal(dags[0]["roots"], dags[1]["roots"]) and tuple(dags[0]["roots"][1]) == o.dag_roots(1)
     single.close()
