@@ -263,14 +263,17 @@ struct Octree {
     std::vector<Node> nodes;
     std::vector<Leaf> leaves;
     std::vector<uint64_t> leaf_mc;  // oracle-only: the code of each leaf, for export without a tree walk
+    std::vector<double> leaf_sum;   // oracle-only: the f64 sum of the leaf's clamped distances (what the f32 running mean of
+                                    // octree.hpp:161-163 approximates), to tell the reference's own rounding drift from a port's error
     BlockLookup lookup;
     Octree() { clear(); }
     void clear() {  // octree.hpp:22-29
         lookup.clear();
-        nodes.clear(); leaves.clear(); leaf_mc.clear();
+        nodes.clear(); leaves.clear(); leaf_mc.clear(); leaf_sum.clear();
         nodes.push_back(Node{});
         leaves.push_back(Leaf{0.0f, 0});
         leaf_mc.push_back(0);
+        leaf_sum.push_back(0.0);
     }
     Leaf& find_or_create(uint64_t mc) {  // octree.hpp:31-78
         constexpr uint32_t lookup_depth = 18;
@@ -297,6 +300,7 @@ struct Octree {
             leaf = uint32_t(leaves.size());
             leaves.push_back(Leaf{0.0f, 0});
             leaf_mc.push_back(mc);
+            leaf_sum.push_back(0.0);
             nodes[node].child[li] = leaf;
         }
         return leaves[leaf];
@@ -457,6 +461,7 @@ void octree_insert(Map& m, V3 pos) {
             leaf.sd = leaf.sd * float(leaf.w) + d;     // :161
             leaf.w++;
             leaf.sd = leaf.sd / float(leaf.w);         // :163
+            m.oct.leaf_sum[size_t(&leaf - m.oct.leaves.data())] += double(d);
         }
         updates += m.walked.size();
     }
@@ -531,6 +536,16 @@ size_t oracle_map_export_leaves(void* h, int submap, uint64_t* mc, float* sd, ui
     const size_t n = std::min(cap, s->mc.size());
     std::memcpy(mc, s->mc.data(), n * 8); std::memcpy(sd, s->sd.data(), n * 4); std::memcpy(w, s->w.data(), n * 4);
     return s->mc.size();
+}
+// The exact means (f64 sum / count) of the ACTIVE octree's leaves, in the order of oracle_map_export_leaves(h, -1, ...).
+size_t oracle_map_export_exact_means(void* h, double* mean, size_t cap) {
+    Map* m = static_cast<Map*>(h);
+    const size_t n = m->oct.leaves.size() - 1;
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = uint32_t(i + 1);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return m->oct.leaf_mc[a] < m->oct.leaf_mc[b]; });
+    for (size_t i = 0; i < std::min(n, cap); i++) mean[i] = m->oct.leaf_sum[order[i]] / double(m->oct.leaves[order[i]].w);
+    return n;
 }
 // out[0..9]: ms calc, sort, normals, update, total; updates U, leaves V, hash entries B, octree nodes, frames
 void oracle_map_stats(void* h, double* out) {

@@ -42,6 +42,8 @@ def lib():
         L.oracle_map_export_leaves.restype = sz
         L.oracle_map_export_leaves.argtypes = [vp, C.c_int, vp, vp, vp, sz]
         L.oracle_map_stats.argtypes = [vp, vp]
+        L.oracle_map_export_exact_means.restype = sz
+        L.oracle_map_export_exact_means.argtypes = [vp, vp, sz]
         L.oracle_morton_codes.argtypes = [vp, sz, f32, vp]
         L.oracle_morton_encode_ivec.argtypes = [vp, sz, vp]
         L.oracle_morton_decode_ivec.argtypes = [vp, sz, vp]
@@ -146,6 +148,14 @@ class OracleMap:
     @property
     def finalize_ms(self) -> float:
         return lib().oracle_map_finalize_ms(self._h)
+
+    def exact_means(self) -> np.ndarray:
+        """f64 mean of the clamped distances of every leaf of the active octree (order of export_leaves(-1)): what the
+        reference's f32 running mean (octree.hpp:161-163) approximates."""
+        n = lib().oracle_map_leaf_count(self._h, -1)
+        out = np.empty(n, dtype=np.float64)
+        assert lib().oracle_map_export_exact_means(self._h, _p(out), n) == n
+        return out
 
     def stats(self) -> dict:
         out = np.zeros(10, dtype=np.float64)

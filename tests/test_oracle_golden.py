@@ -151,3 +151,19 @@ def test_g8_finalize(oracle):
     top = g["s1_level0"]
     assert top[0] == 0 and bin(int(top[1])).count("1") + 2 <= len(top)
     assert g["s1_level20"][0] == 0 and (g["s1_level20"][1:] == np.uint64(0xFFFFFFFFFFFFFFFF)).sum() == 1   # Q6: one all-ones weight cluster
+
+
+def test_running_mean_drift_of_the_reference_arithmetic(oracle):
+    """The reference's leaf update is a running mean in f32 (octree.hpp:161-163).  Its rounding error against the exact
+    mean of the same observations grows with the observation count: negligible at the weights of a single frame, beyond
+    the 1e-4 parity bound for voxels observed tens of thousands of times.  (The device keeps sum and count: DESIGN.md.)"""
+    res, trunc = 0.2, 0.8
+    o = oracle.OracleMap(res, trunc)
+    for k in range(40):
+        o.insert(synth.box_scan(20_000, (-3, -2, -1), (3, 2, 1), (0.1 + 0.01 * k, 0.0, 0.0), 900 + k), (0.1 + 0.01 * k, 0.0, 0.0))
+    mc, sd, w = o.export_leaves()
+    drift = np.abs(sd - o.exact_means()) / np.maximum(np.abs(o.exact_means()), trunc)
+    assert w.max() > 15_000
+    assert drift[w <= 1000].max() < 2e-5
+    assert drift[w <= 8192].max() < 1e-4                 # tests/util.py DRIFT_FREE_WEIGHT
+    assert drift.max() > 1e-4                            # ... and past it the reference itself is off by more than the bound
