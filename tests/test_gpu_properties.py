@@ -307,6 +307,6 @@ def test_heavily_observed_voxels_follow_the_exact_mean(chad, oracle):
     assert np.array_equal(mc, omc) and np.array_equal(w, ow) and w.max() > 15_000
     scale = np.maximum(np.abs(exact), trunc)
     assert (np.abs(sd - exact) / scale).max() <= 1e-5
-    calm = w <= 8192
+    calm = w <= 4096
     assert (np.abs(sd - osd) / scale)[calm].max() <= SD_TOL
     assert_leaves_match((mc, sd, w), (omc, osd, ow), trunc, allow_drift=True)
