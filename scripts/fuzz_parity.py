@@ -1,7 +1,7 @@
 """Randomised parity sweep (not part of the test suite: a longer soak for the GPU box).  Random resolutions, truncation
 ratios, scene boxes, sensor poses, frame sizes and frame counts; every map is compared with the oracle's (leaf sets and
 weights exact, sd within 1e-4 of max(|sd|, trunc)) and its closed submaps' DAG with the oracle's finalize of the same leaves.
-  python scripts/fuzz_parity.py [seconds] [first seed]"""
+  python scripts/fuzz_parity.py [seconds] [first seed] [big]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,7 @@ from tests.util import assert_leaves_match
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"   # frames of 1-4 M points (the oracle needs 0.15-0.6 s for each)
 t_end = time.time() + budget
 cases = 0
 while time.time() < t_end:
@@ -22,6 +23,8 @@ while time.time() < t_end:
     lo, hi = -half, half * rng.uniform(0.3, 1.0, size=3)
     frames = int(rng.choice([1, 1, 2, 5, 12]))
     n = int(rng.choice([1, 7, 64, 1000, 20_000, 150_000, 400_000]))
+    if big:
+        n, frames = int(rng.choice([1_000_000, 2_000_000, 4_000_000])), int(rng.choice([1, 2, 3]))
     step = rng.uniform(0.0, 1.5) * (res / 0.05)
     mode = int(rng.choice([0, 0, 1, 2]))
     m = chad.TSDFMap(res, trunc, update_mode=mode, dag_saturate_weights=bool(seed & 1))
