@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel-trace stats of Submap::finalize (scripts/finalize_bench.py): the cluster kernel, the key sort and the copies
+# kernel-trace stats of Submap::finalize (tests/soak/finalize_bench.py): the cluster kernel, the key sort and the copies
 out=gpurun_out/finalize_prof
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out"; mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 scripts/finalize_bench.py > "$out/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 tests/soak/finalize_bench.py > "$out/bench.log" 2>&1
 cat "$out/bench.log" | grep -v amdgpu.ids
 python3 - "$out" <<'PY'
 import csv, glob, sys

@@ -3,8 +3,8 @@
 frames), device-resident, inserted back to back -- on one GPU (cfg3), or dealt round-robin over N ranks with the block
 partials merged at every submap close (cfg4, strong scaling):
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/stream_bench.py --gpus N
-(add --backend gloo to rehearse a few ranks on one GPU).  Prints steady-state throughput and the hash occupancy; --cpu-frames N also times
-the oracle (CPU restatement) on the first N frames.  Not the bench line (bench.py is): a measurement script for DESIGN.md."""
+(add --backend gloo to rehearse a few ranks on one GPU).  Prints steady-state throughput and the hash occupancy (the CPU path on the same frames:
+tests/soak/stream_cpu_baseline.py).  Not the bench line (bench.py is): a measurement script for DESIGN.md."""
 import argparse, json, os, sys, time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,6 @@ from chad_tsdf_amd import TSDFMap, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=500)
-ap.add_argument("--cpu-frames", type=int, default=0)
 ap.add_argument("--gpus", type=int, default=1, help="cfg4: the same stream dealt round-robin over this many ranks (launch with torch.distributed.run)")
 ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo to rehearse several ranks on one GPU")
 args = ap.parse_args()
@@ -75,16 +74,6 @@ if rank != 0:
     if world > 1:
         dist.destroy_process_group()
     sys.exit(0)
-if args.cpu_frames:
-    from oracle import pyoracle
-    o = pyoracle.OracleMap(0.05, 0.10)
-    cpu_frames = [synth.cfg3_frame(k) for k in range(args.cpu_frames)]
-    t1 = time.perf_counter()
-    for pts, pos in cpu_frames:
-        o.insert(pts, pos)
-    tc = time.perf_counter() - t1
-    out["cpu_ms_per_frame"] = tc / args.cpu_frames * 1e3
-    out["speedup_vs_cpu"] = out["cpu_ms_per_frame"] / out["ms_per_frame"]
 print(json.dumps(out))
 if world > 1:
     dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """Submap::finalize: device + host time here against the oracle's finalize on one core.
 
-  python scripts/finalize_bench.py            # cfg2 frame (9.4 k blocks) and a cfg3 submap (100 frames x 200 k points)
+  python tests/soak/finalize_bench.py            # cfg2 frame (9.4 k blocks) and a cfg3 submap (100 frames x 200 k points)
 """
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import chad_tsdf_amd as chad  # noqa: E402

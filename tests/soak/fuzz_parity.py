@@ -1,9 +1,9 @@
 """Randomised parity sweep (not part of the test suite: a longer soak for the GPU box).  Random resolutions, truncation
 ratios, scene boxes, sensor poses, frame sizes and frame counts; every map is compared with the oracle's (leaf sets and
 weights exact, sd within 1e-4 of max(|sd|, trunc)) and its closed submaps' DAG with the oracle's finalize of the same leaves.
-  python scripts/fuzz_parity.py [seconds] [first seed] [big]"""
+  python tests/soak/fuzz_parity.py [seconds] [first seed] [big]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import chad_tsdf_amd as chad
 from chad_tsdf_amd import synth
