@@ -247,14 +247,14 @@ chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream, u
     v.overflow = overflow;
     HIP_TRY(hipMalloc(&v.hash_keys, hcap * 8));
     HIP_TRY(hipMalloc(&v.live_bits, hcap / 8));
-    HIP_TRY(hipMalloc(&v.brick_sum, hcap * 256));   // a brick lives at its hash slot (map_kernels.hpp)
+    HIP_TRY(hipMalloc(&v.brick_sum, hcap * 512));   // a brick lives at its hash slot; 64-bit sums (map_kernels.hpp)
     HIP_TRY(hipMalloc(&v.brick_cnt, hcap * 256));
     HIP_TRY(hipMalloc(&v.brick_count, kCountStripes * 64));
     v.hash_mask = uint32_t(hcap - 1);
     v.brick_capacity = uint32_t(blocks);
     hipLaunchKernelGGL(k_fill_u64, grid_for(hcap), dim3(256), 0, stream, v.hash_keys, size_t(hcap), kEmptyKey);
     HIP_TRY(hipMemsetAsync(v.live_bits, 0, hcap / 8, stream));
-    HIP_TRY(hipMemsetAsync(v.brick_sum, 0, hcap * 256, stream));
+    HIP_TRY(hipMemsetAsync(v.brick_sum, 0, hcap * 512, stream));
     HIP_TRY(hipMemsetAsync(v.brick_cnt, 0, hcap * 256, stream));
     HIP_TRY(hipMemsetAsync(v.brick_count, 0, kCountStripes * 64, stream));
     HIP_TRY(hipGetLastError());
@@ -309,7 +309,7 @@ chad_status compact_active(chad_map* m, Submap& s, uint32_t blocks) {
     TRY(alloc_submap(s, blocks));
     if (!blocks) return CHAD_OK;
     HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
-    hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, blocks, s.keys, s.sum, s.cnt);
+    hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
 }
@@ -341,7 +341,7 @@ chad_status finish_closing(chad_map* m, bool block) {
     TRY(alloc_submap(s, blocks));
     if (blocks) {
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
-        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, m->d_cursor, blocks, s.keys, s.sum, s.cnt);
+        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
     }
     hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, 0u);
     HIP_TRY(hipGetLastError());
@@ -912,7 +912,7 @@ static chad_status export_blocks(chad_map* m, int32_t submap, uint64_t* keys_dev
         if (!nb) return CHAD_OK;
         if (!keys_device || !sum_device || !cnt_device) return fail(CHAD_ERR_INVALID_ARG, "null output");
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
-        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, nb, keys_device, sum_device, cnt_device);
+        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, nb, keys_device, sum_device, cnt_device, m->trunc);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(m->stream));
         return CHAD_OK;

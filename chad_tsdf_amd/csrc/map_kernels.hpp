@@ -31,9 +31,21 @@ constexpr uint64_t kEmptyKey = ~0ull;
 constexpr uint32_t kNoBrick = 0xfffffffeu;   // table too full: updates to this block are dropped (overflow flag set)
 constexpr uint32_t kMaxProbes = 256;         // at load <= 0.5 probe sequences are a handful of slots long
 
+// A voxel of the ACTIVE map holds (sum of its observations' clamped distances, their count) -- the same information as the
+// reference's running mean and weight (octree.hpp:161-163).  The sum is a 64-bit integer in units of trunc / 2^30 (the
+// fixed point the update kernel's LDS tile accumulates in): integer addition is exact and does not depend on the order of
+// the atomics, so a map is a function of its frames alone -- bit-reproducible -- and a voxel observed a hundred thousand
+// times still holds the exact mean (f32 sums of that many terms, like the reference's f32 running mean, drift by 1e-4 of
+// the truncation distance and more).  Archives, exports and the multi-GPU exchange carry f32 sums: k_compact_bricks
+// converts, with one rounding.  The reference's NaN leaves (a degenerate neighbourhood's NaN normal, Q4) are kept as a
+// flag in the count's top bit: the count goes on counting, the compacted sum comes out NaN.
+constexpr float kSumOne = 1073741824.0f;        // 2^30 units per truncation distance
+constexpr uint32_t kPoisonedCount = 0x80000000u;
+__device__ __forceinline__ long long sum_units(float d, float units_per_metre) { return (long long)rintf(d * units_per_metre); }
+
 struct MapView {
     uint64_t* hash_keys;
-    float* brick_sum;
+    long long* brick_sum;
     uint32_t* brick_cnt;
     uint32_t* live_bits;
     uint32_t* brick_count;   // striped device counter of live bricks
@@ -41,6 +53,13 @@ struct MapView {
     uint32_t hash_mask;      // H - 1 (H a power of two)
     uint32_t brick_capacity; // nominal capacity (H / 2 or less): the pools grow once half of it is in use
 };
+
+// One observation into cell `at` of the active map (the scatter form; the tiled update adds whole partial sums).
+__device__ __forceinline__ void add_observation(const MapView& m, size_t at, float d, float units_per_metre) {
+    if (d == d) atomicAdd(reinterpret_cast<unsigned long long*>(&m.brick_sum[at]), (unsigned long long)sum_units(d, units_per_metre));
+    else atomicOr(&m.brick_cnt[at], kPoisonedCount);   // NaN (Q4): the voxel's mean is NaN from here on, as in the reference
+    atomicAdd(&m.brick_cnt[at], 1u);
+}
 
 __device__ __forceinline__ uint32_t hash_block(uint64_t key, uint32_t mask) {
     return uint32_t(((key >> 6) * 0x9E3779B97F4A7C15ull) >> 32) & mask;
@@ -93,8 +112,7 @@ __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, c
             if (key != cached_key) { brick = find_or_create_brick(m, key); cached_key = key; }
             if (brick != kNoBrick) {
                 const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
-                atomicAdd(&m.brick_sum[at], observe(w.cur, p, nrm, res, trunc));
-                atomicAdd(&m.brick_cnt[at], 1u);
+                add_observation(m, at, observe(w.cur, p, nrm, res, trunc), kSumOne / trunc);
                 applied++;
             }
         } while (w.next());
@@ -233,7 +251,8 @@ __device__ __forceinline__ void for_each_live_brick(const MapView& m, Visit visi
 // ~25 ns each on gfx950: one per brick would cost more than the copy).
 __global__ void __launch_bounds__(256)
 k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, uint64_t* __restrict__ out_key, float* __restrict__ out_sum,
-                 uint32_t* __restrict__ out_cnt) {
+                 uint32_t* __restrict__ out_cnt, float trunc) {
+    const double metres_per_unit = double(trunc) / double(kSumOne);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
@@ -253,8 +272,10 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
             for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u, k++) {
                 if (k >= capacity) continue;
                 const uint32_t slot = (w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u;
-                out_sum[size_t(k) * 64 + lane] = m.brick_sum[size_t(slot) * 64 + lane];
-                out_cnt[size_t(k) * 64 + lane] = m.brick_cnt[size_t(slot) * 64 + lane];
+                const uint32_t count = m.brick_cnt[size_t(slot) * 64 + lane];
+                const float sum = float(double(m.brick_sum[size_t(slot) * 64 + lane]) * metres_per_unit);   // exact integer -> one rounding
+                out_sum[size_t(k) * 64 + lane] = (count & kPoisonedCount) ? __int_as_float(0x7fc00000) : sum;
+                out_cnt[size_t(k) * 64 + lane] = count & ~kPoisonedCount;
                 if (lane == 0) out_key[k] = m.hash_keys[slot];
             }
         }
@@ -268,7 +289,7 @@ k_clear_bricks(MapView m, uint32_t clear_overflow) {
     const uint32_t lane = threadIdx.x & 63;
     for_each_live_brick(m, [&](uint32_t slot) {
         if (lane == 0) m.hash_keys[slot] = kEmptyKey;
-        m.brick_sum[size_t(slot) * 64 + lane] = 0.0f;
+        m.brick_sum[size_t(slot) * 64 + lane] = 0ll;
         m.brick_cnt[size_t(slot) * 64 + lane] = 0u;
     });
     // each wave clears exactly the words it has just read

@@ -43,7 +43,7 @@ namespace chadhip {
 constexpr int kTileWaves = 4;            // waves per workgroup: they share the item's tile and take its chunks in turn
 constexpr int kTileThreads = 64 * kTileWaves;
 constexpr uint32_t kMaxReach = 4;        // D = 16: 32 KiB of LDS per workgroup
-constexpr float kFixedOne = 1073741824.0f;  // 2^30: |d| = trunc in the tile's fixed-point scale
+constexpr float kFixedOne = kSumOne;  // 2^30: |d| = trunc in the tile's fixed-point scale -- the unit of the map's sums (map_kernels.hpp)
 constexpr uint32_t kCountShift = 44;        // tile cell = [count : 20 | sum of biased fixed-point distances : 44]: an item's 512 observations of
                                             // at most 2^31 each stay below 2^40 (with the count at bit 40 a cell that took 512 observations of
                                             // +trunc carried into its own count: found by test_sort_survives_..., whose small frames put
@@ -104,7 +104,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     unsigned long long* tile = reinterpret_cast<unsigned long long*>(tile_raw);
     uint4* next_record = reinterpret_cast<uint4*>(tile + ((cells + 2u) & ~1u));
     const uint32_t tile_base = uint32_t(uintptr_t(tile));  // LDS byte address (low half of the flat address)
-    const float to_fixed = kFixedOne / trunc, from_fixed = trunc / kFixedOne;
+    const float to_fixed = kFixedOne / trunc;
     // (the stripe counts of the work lists are loaded here so that their latency overlaps the zeroing of the tile)
     uint32_t stripe_count = 0;
     if (threadIdx.x < 2 * kListStripes) stripe_count = h->list_count[threadIdx.x / kListStripes ? kListShortItems : kListLongItems][(threadIdx.x % kListStripes) * 16];
@@ -251,8 +251,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
                         if (key != far_key) { far_brick = find_or_create_brick(m, key); far_key = key; }
                         if (far_brick != kNoBrick) {
                             const size_t at = size_t(far_brick) * 64 + (uint32_t(mc) & 63u);
-                            atomicAdd(&m.brick_sum[at], observe(w.cur, p, nrm, res, trunc));
-                            atomicAdd(&m.brick_cnt[at], 1u);
+                            add_observation(m, at, observe(w.cur, p, nrm, res, trunc), to_fixed);
                             applied++;
                         }
                     } while (w.next());
@@ -315,10 +314,10 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
             const unsigned long long cell = ((lane_valid >> b) & 1u) ? tile[at] : 0ull;
             if (cell) {
                 const uint32_t c = uint32_t(cell >> kCountShift);
-                // sum of d = (sum of biased fixed values - c * 2^30) * trunc / 2^30: exact integer, one rounding to f32
+                // sum of d in units of trunc / 2^30 = sum of biased fixed values - c * 2^30: an exact integer, added as such
                 const long long fixed_sum = (long long)(cell & ((1ull << kCountShift) - 1)) - ((long long)c << 30);
                 if (brick != kNoBrick) {
-                    atomicAdd(&m.brick_sum[size_t(brick) * 64 + lane], float(fixed_sum) * from_fixed);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&m.brick_sum[size_t(brick) * 64 + lane]), (unsigned long long)fixed_sum);
                     atomicAdd(&m.brick_cnt[size_t(brick) * 64 + lane], c);
                     applied += c;
                 }

@@ -37,7 +37,7 @@ enum {
 typedef struct chad_options {
     uint32_t struct_size;
     int32_t device;      /* HIP device ordinal; -1 = the calling thread's current device */
-    uint64_t max_blocks; /* initial capacity of the active submap in 4x4x4-voxel blocks (532 B of HBM each); 0 = default (1<<21).
+    uint64_t max_blocks; /* initial capacity of the active submap in 4x4x4-voxel blocks (1 044 B of HBM each: two hash slots of a 64-bit key, 64 64-bit sums and 64 counts); 0 = default (1<<21).
                             Doubles automatically between frames when half full, unless CHAD_FLAG_FIXED_CAPACITY */
     uint64_t max_points; /* initial per-frame point capacity (grows on demand); 0 = default (1<<20) */
     void* stream;        /* hipStream_t of the caller: frames wait for the work enqueued on it before the insert, and operations

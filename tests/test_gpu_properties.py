@@ -310,3 +310,22 @@ def test_heavily_observed_voxels_follow_the_exact_mean(chad, oracle):
     calm = w <= 4096
     assert (np.abs(sd - osd) / scale)[calm].max() <= SD_TOL
     assert_leaves_match((mc, sd, w), (omc, osd, ow), trunc, allow_drift=True)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_maps_are_bit_reproducible(chad, mode):
+    """The map's sums are integers (units of trunc / 2^30), so the order in which the atomics of three frames in flight land
+    does not matter: the same frames give the same map, bit for bit -- sums, counts, and the DAG built from them."""
+    frames = [synth.cfg2_frame(300_000, seed=70 + k, sensor=(0.3 + 0.02 * k, -0.2, 0.1)) for k in range(4)]
+    out = []
+    for _ in range(2):
+        m = chad.TSDFMap(0.05, 0.10, update_mode=mode)
+        for pts, pos in frames:
+            m.insert(pts, pos)
+        mc, sd, w = m.export_leaves()
+        m.close_submap()
+        out.append((mc, sd, w, [m.dag_level(l) for l in range(21)]))
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))        # the means: identical bits
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
