@@ -124,7 +124,9 @@ chad_status chad_map_stats(chad_map* map, chad_stats* out);
  * (key = MortonCode & ~63, the reference's lookup key, octree.hpp:33-36).  sum[b*64+v] is the sum of
  * the clamped signed distances observed by voxel v of block b, cnt[b*64+v] their count, so partials of
  * different GPUs combine by addition (the reference's update is a mean of unit-weight observations,
- * octree.hpp:161-163). */
+ * octree.hpp:161-163).  Inside the active map the sums are 64-bit integers in units of sdf_trunc / 2^30 (exact and
+ * independent of the order of the updates: the same frames give the same map bit for bit); what is exported here is
+ * that integer converted to f32 with one rounding, NaN where the reference's leaf is NaN. */
 chad_status chad_map_block_count(chad_map* map, int32_t submap, size_t* blocks);
 chad_status chad_map_export_blocks_device(chad_map* map, int32_t submap, uint64_t* keys_device, float* sum_device, uint32_t* cnt_device, size_t capacity_blocks);
 /* The same blocks in no particular order (skips the sort: the multi-GPU merge orders the union of all ranks' keys anyway). */

@@ -51,10 +51,9 @@ while time.time() < t_end:
         got = m.export_leaves(-1)
         exact = o.exact_means()   # the device's own accuracy: sum / count against the f64 mean of the same observations
         if got[1].size:
-            # (both the reference's running mean and f32 sums of many observations drift from the f64 mean about linearly in
-            # the weight: the bound is 1e-4 up to 4 096 observations and grows with the weight beyond, tests/util.py)
-            e = np.abs(got[1] - exact) / np.maximum(np.abs(exact), trunc) / np.maximum(1.0, got[2] / 4096.0)
-            assert e.max() <= 1e-4, f"sd vs exact mean: {e.max():.3g} at weight {got[2][e.argmax()]} (reference there: {abs(o.export_leaves(-1)[1][e.argmax()] - exact[e.argmax()]) / max(abs(exact[e.argmax()]), trunc):.3g})"
+            # (the map's sums are exact integers: no allowance for the weight here)
+            e = np.abs(got[1] - exact) / np.maximum(np.abs(exact), trunc)
+            assert e.max() <= 1e-5, f"sd vs exact mean: {e.max():.3g} at weight {got[2][e.argmax()]} (reference there: {abs(o.export_leaves(-1)[1][e.argmax()] - exact[e.argmax()]) / max(abs(exact[e.argmax()]), trunc):.3g})"
         m.close_submap()
         ref = pyoracle.OracleMap(res, trunc)
         ref.set_saturate_weights(bool(seed & 1))

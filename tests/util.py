@@ -12,8 +12,9 @@ def assert_leaves_match(got, want, trunc, tol=SD_TOL, allow_drift=False):
 
     allow_drift: the reference's leaf is a running mean in f32 (octree.hpp:161-163: sd = (sd * w + d) / (w + 1)), whose
     rounding error grows roughly linearly with the observation count -- 5e-6 at 1 000 observations, 5e-5 at 8 000, 2-3e-4 at
-    40-75 000 (tests/test_oracle_golden.py::test_running_mean_drift...).  A sum / count cannot follow it there (and f32 sums of that many terms drift
-    themselves), so soak tests over long accumulations widen the bound for such leaves in proportion to their weight."""
+    40-75 000 (tests/test_oracle_golden.py::test_running_mean_drift...).  The device's exact integer sums cannot follow it there -- they
+    stay at the exact mean --, so soak tests over long accumulations widen the bound against the reference for such leaves
+    in proportion to their weight."""
     gmc, gsd, gw = got
     wmc, wsd, ww = want
     assert gmc.shape == wmc.shape, f"leaf count {gmc.shape[0]} != {wmc.shape[0]}"
