@@ -23,7 +23,7 @@
 //      of the brick, all 16 reads in flight together) to learn which received observations; lanes 0..15 whose brick
 //      was touched and whose speculative look-up (below) did not already show the key claim or find the slot with
 //      one CAS (map_kernels.hpp);
-//   3. every touched brick is flushed with two 256-byte wave-wide atomic adds (sum, count), the full-rate shape for
+//   3. every touched brick is flushed with two wave-wide atomic adds (512 B of 64-bit sums, 256 B of counts), the full-rate shape for
 //      memory-side atomics, and its part of the tile is zeroed for the next item; workgroup barrier.
 // Memory operations of a wave complete in issue order, so a load issued behind the flush's atomics waits ~3000
 // cycles for them.  The loop is therefore software-pipelined: right after the first barrier -- before the flush --
