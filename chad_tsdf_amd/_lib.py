@@ -14,9 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchad_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_CAPACITY, ERR_HIP = range(6)
-FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS, FLAG_DAG_ONLY = 1, 2, 4, 8, 16, 32
+FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS, FLAG_DAG_ONLY, FLAG_TIME_KERNELS = 1, 2, 4, 8, 16, 32, 64
+KERNEL_COUNT = 13
 DAG_NODE_LEVELS, DAG_CLUSTER_LEVEL = 20, 20
 UPDATE_AUTO, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
+MAX_SLOTS = 8  # chad_map::kMaxSlots: the most frames a map ever keeps in flight (three by default)
 
 
 class ChadError(RuntimeError):
@@ -57,6 +59,10 @@ class Stats(C.Structure):
     ]
 
 
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * KERNEL_COUNT), ("launches", C.c_uint64 * KERNEL_COUNT)]
+
+
 class DagStats(C.Structure):
     _fields_ = [
         ("submaps", C.c_uint64),
@@ -74,6 +80,7 @@ SYMBOLS = {
     "chad_map_destroy": (None, [_vp]),
     "chad_map_insert": (_i32, [_vp, _vp, _sz, _vp]),
     "chad_map_insert_device": (_i32, [_vp, _vp, _sz, _vp]),
+    "chad_map_insert_device_stream": (_i32, [_vp, _vp, _sz, _vp, _vp]),
     "chad_map_sync": (_i32, [_vp]),
     "chad_map_reset": (_i32, [_vp]),
     "chad_map_would_roll_over": (_i32, [_vp, _vp, C.POINTER(_i32)]),
@@ -81,6 +88,8 @@ SYMBOLS = {
     "chad_map_leaf_count": (_i32, [_vp, _i32, C.POINTER(_sz)]),
     "chad_map_export_leaves": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "chad_map_kernel_times": (_i32, [_vp, C.POINTER(KernelTimes)]),
+    "chad_kernel_name": (C.c_char_p, [_i32]),
     "chad_map_block_count": (_i32, [_vp, _i32, C.POINTER(_sz)]),
     "chad_map_export_blocks_device": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
     "chad_map_export_blocks_device_unordered": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),

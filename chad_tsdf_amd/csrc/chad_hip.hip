@@ -80,6 +80,8 @@ struct FrameSlot {
     float* d_xyz = nullptr;             // device copy of a host frame
     float* h_stage = nullptr;           // pinned staging buffer for chad_map_insert (host points), cap_points * 12 bytes
     hipEvent_t stage_done = nullptr;    // the H2D copies out of h_stage have completed
+    uint32_t input_seq = 0;             // frames enqueued on this slot so far; the device stores the number into chad_map::h_consumed[slot]
+                                        // once the frame's input (the caller's points) has been read for the last time
     RadixSortBuffers sort{};
     float4* d_normals = nullptr;
     uint32_t* d_seg = nullptr;
@@ -97,6 +99,13 @@ struct chad_map {
     bool pending_clear_overflow = false;
     bool own_stream = false;
     hipEvent_t caller_ready = nullptr;  // caller-supplied stream only: the frame's input is ready once this has passed
+    hipEvent_t producer_ready = nullptr;  // chad_map_insert_device_stream: recorded on the producer's stream, waited for by the frame's stream
+    volatile uint32_t* h_consumed = nullptr;  // host-mapped, one 64-byte line per slot: FrameSlot::input_seq of the last frame whose input the device has consumed
+    uint32_t* d_consumed = nullptr;           // (its device address)
+    RadixSortBuffers aux_sort{};        // block-key sorter of exports and of Submap::finalize (never a frame slot's: those belong to frames in flight)
+    size_t aux_cap = 0;
+    uint32_t sort_resident = 0;         // workgroups of the frame sort's pass kernel the device certainly holds at once (radix_resident_workgroups)
+    uint32_t aux_resident = 0;
     static constexpr uint32_t kMaxSlots = 8;
     uint32_t n_slots = 3;               // frames in flight (CHAD_SLOTS overrides, for experiments)
     FrameSlot slot[kMaxSlots];
@@ -140,6 +149,14 @@ struct chad_map {
     hipEvent_t ev[kTimingRing][T_COUNT] = {};
     uint64_t timed_begin = 0, timed_end = 0;  // inserts [timed_begin, timed_end) have unread event sets
     float ms[T_COUNT] = {};                   // mean stage times over the inserts read at the last stats call
+    // kernel timing (CHAD_FLAG_TIME_KERNELS): every kernel of an insert is launched with a pair of events that take the
+    // dispatch's own begin / end time stamps (hipExtLaunchKernel); frames then run one after the other on one stream
+    static constexpr int kKernelRing = 16;
+    hipEvent_t kev[kKernelRing][2 * CHAD_KERNEL_COUNT] = {};
+    uint32_t kev_launched[kKernelRing] = {};  // bit id: kernel `id` was launched for that insert
+    uint64_t ktimed_begin = 0, ktimed_end = 0;
+    double kernel_ms[CHAD_KERNEL_COUNT] = {};
+    uint64_t kernel_launches[CHAD_KERNEL_COUNT] = {};
 };
 
 namespace {
@@ -163,15 +180,22 @@ inline dim3 grid_for(size_t n, int threads = 256, int max_blocks = 2048) {
     return dim3(unsigned(b));
 }
 
+void free_sort_buffers(RadixSortBuffers& b) {
+    (void)hipFree(b.keys[0]); (void)hipFree(b.keys[1]); (void)hipFree(b.idx[0]); (void)hipFree(b.idx[1]);
+    (void)hipFree(b.points[0]); (void)hipFree(b.points[1]);
+    (void)hipFree(b.hist_part); (void)hipFree(b.digit_base); (void)hipFree(b.tile_status);
+    const uint32_t resident = b.resident;
+    b = RadixSortBuffers{};
+    b.resident = resident;
+}
+
 void free_frame_buffers(FrameSlot& f) {
     if (f.h_stage) (void)hipHostFree(f.h_stage);
     f.h_stage = nullptr;
-    (void)hipFree(f.d_xyz); (void)hipFree(f.sort.keys[0]); (void)hipFree(f.sort.keys[1]);
-    (void)hipFree(f.sort.idx[0]); (void)hipFree(f.sort.idx[1]); (void)hipFree(f.sort.hist_part);
-    (void)hipFree(f.sort.digit_base); (void)hipFree(f.sort.tile_status);
-    (void)hipFree(f.sort.points[0]); (void)hipFree(f.sort.points[1]);
+    (void)hipFree(f.d_xyz);
+    free_sort_buffers(f.sort);
     (void)hipFree(f.d_normals); (void)hipFree(f.d_seg);
-    f.d_xyz = nullptr; f.sort = RadixSortBuffers{}; f.d_normals = nullptr; f.d_seg = nullptr;
+    f.d_xyz = nullptr; f.d_normals = nullptr; f.d_seg = nullptr;
     f.cap_points = 0;
 }
 
@@ -218,7 +242,6 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     HIP_TRY(hipMalloc(&f.d_xyz, cap * 12));
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipMalloc(&f.sort.keys[i], cap * 8));
-        HIP_TRY(hipMalloc(&f.sort.idx[i], cap * 4));
         HIP_TRY(hipMalloc(&f.sort.points[i], cap * 16));  // the points travel with their keys; the last pass's output is the frame in processing order
     }
     HIP_TRY(hipMalloc(&f.sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
@@ -230,6 +253,26 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     // kListStripes stripes of cap / kListStripes + kGatherChunk entries (FrameHeader::list_count)
     HIP_TRY(hipMalloc(&f.d_seg, (cap + size_t(kListStripes) * kGatherChunk) * 24));
     f.cap_points = cap;
+    return CHAD_OK;
+}
+
+// The (key, index) sorter of exports and finalize: buffers of its own, so that no frame slot is ever borrowed (a slot's buffers
+// belong to a frame that may still be in flight, and growing them would free a frame's staged points).  Used on the map's stream only.
+chad_status ensure_aux_sort(chad_map* m, size_t n) {
+    if (n <= m->aux_cap) return CHAD_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    size_t cap = std::max<size_t>(n, m->aux_cap * 2);
+    cap = (cap + kSortTile - 1) / kSortTile * kSortTile;
+    free_sort_buffers(m->aux_sort);
+    m->aux_cap = 0;
+    RadixSortBuffers& b = m->aux_sort;
+    for (int i = 0; i < 2; i++) { HIP_TRY(hipMalloc(&b.keys[i], cap * 8)); HIP_TRY(hipMalloc(&b.idx[i], cap * 4)); }
+    HIP_TRY(hipMalloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(hipMalloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
+    HIP_TRY(hipMalloc(&b.tile_status, radix_status_words(radix_tiles(cap)) * 4));
+    b.tiles_capacity = radix_tiles(cap);
+    b.resident = m->aux_resident;
+    m->aux_cap = cap;
     return CHAD_OK;
 }
 
@@ -420,6 +463,33 @@ chad_status fetch_bricks(chad_map* m, int32_t submap, HostBricks& hb) {
 }
 
 inline bool times_stages(const chad_map* m) { return (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0; }
+inline bool times_kernels(const chad_map* m) { return (m->flags & CHAD_FLAG_TIME_KERNELS) != 0; }
+// kernel `id` of the insert being enqueued: its event pair (null when kernels are not timed)
+inline hipEvent_t* kernel_events(chad_map* m, int id) {
+    if (!times_kernels(m)) return nullptr;
+    const int at = int(m->ktimed_end % chad_map::kKernelRing);
+    m->kev_launched[at] |= 1u << id;
+    return &m->kev[at][2 * id];
+}
+// sums of the kernel durations of the inserts not read yet (the streams must be idle)
+void collect_kernel_times(chad_map* m) {
+    for (uint64_t f = m->ktimed_begin; f < m->ktimed_end; f++) {
+        const int at = int(f % chad_map::kKernelRing);
+        for (int id = 0; id < CHAD_KERNEL_COUNT; id++) {
+            if (!((m->kev_launched[at] >> id) & 1u)) continue;
+            float t = 0;
+            if (hipEventElapsedTime(&t, m->kev[at][2 * id], m->kev[at][2 * id + 1]) == hipSuccess) { m->kernel_ms[id] += t; m->kernel_launches[id]++; }
+            else (void)hipGetLastError();
+        }
+        m->kev_launched[at] = 0;
+    }
+    m->ktimed_begin = m->ktimed_end;
+}
+#define LAUNCH_TIMED(m_, id_, kernel_, grid_, block_, lds_, stream_, ...)                                                   \
+    do {                                                                                                                    \
+        if (hipEvent_t* ke_ = kernel_events(m_, id_)) hipExtLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, ke_[0], ke_[1], 0u, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, __VA_ARGS__);                                        \
+    } while (0)
 inline bool times_anything(const chad_map* m) { return (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE | CHAD_FLAG_TIME_UPDATE)) != 0; }
 
 // Every hipEventRecord costs ~6 us of stream idle time, so CHAD_FLAG_TIME_UPDATE brackets only the update kernel.
@@ -481,6 +551,20 @@ void collect_timing(chad_map* m) {
 chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
     const uint32_t turn = uint32_t(m->frames % m->n_slots);
     FrameSlot& f = m->slot[turn];
+    // The lifetime contract of chad_map_insert_device: the frame that used this slot before (n_slots inserts ago) has read its
+    // input for the last time before this insert returns.  The device says so itself (the launch behind the first sort pass
+    // stores the frame's number into host-mapped memory: no event, nothing added to the stream); this also bounds how far the
+    // host runs ahead of the device -- n_slots frames.  Normally the number is already there; otherwise poll briefly, then wait
+    // for the slot's stream (always sufficient: everything of that frame ran on it).
+    if (f.input_seq && m->h_consumed[turn * 16] != f.input_seq) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (m->h_consumed[turn * 16] != f.input_seq) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { HIP_TRY(hipStreamSynchronize(f.prep)); break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
     TRY(ensure_frame_capacity(m, f, n));
     if (m->caller_ready) {  // caller-supplied stream: the caller's work enqueued so far (it may produce the points) comes first
         HIP_TRY(hipEventRecord(m->caller_ready, m->stream));
@@ -541,22 +625,28 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     uint4* item_start = reinterpret_cast<uint4*>(f.d_seg + 2 * size_t(list_stride) * kListStripes);
     if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, prep, f.d_hdr);
     if (count) {
-        hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
-        hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
-                           f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
+        if (times_kernels(m) && m->ktimed_end - m->ktimed_begin >= uint64_t(chad_map::kKernelRing)) { TRY(join_streams(m)); collect_kernel_times(m); }
+        LAUNCH_TIMED(m, CHAD_KERNEL_BOUNDS, k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
+        LAUNCH_TIMED(m, CHAD_KERNEL_KEYS, k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
+                     f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
         record(m, T_CALC, prep);
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
         // last of them covering whatever else the frame turns out to need (radix_sort.hpp, k_radix_onesweep to_limit)
         const uint32_t hint = m->sort_passes_forced ? m->sort_passes_forced : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1])));
-        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used);
+        RadixSortSignals sig;
+        sig.fault = m->d_overflow; sig.consumed = m->d_consumed + m->last_slot * 16u; sig.seq = ++f.input_seq;
+        uint32_t pass_launches = 0;
+        if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
+        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used, sig);
         m->sort_turn_used = true;   // (recorded by the hinted path only; an unrecorded event makes the wait a no-op)
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
-        hipLaunchKernelGGL(k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                           points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride);
+        if (times_kernels(m)) m->kev_launched[m->ktimed_end % chad_map::kKernelRing] |= ((1u << pass_launches) - 1u) << CHAD_KERNEL_SORT_PASS0;
+        LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
+                     points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq);
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
-        hipLaunchKernelGGL(k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate);
+        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -583,17 +673,19 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
         // CHAD_FLAG_TIME_UPDATE times the update kernel alone, with the dispatch's own begin / end time stamps (hipExtLaunchKernel)
-        const bool time_kernel = !times_stages(m) && (m->flags & CHAD_FLAG_TIME_UPDATE);
+        const bool time_kernel = (!times_stages(m) && (m->flags & CHAD_FLAG_TIME_UPDATE)) || times_kernels(m);
         hipEvent_t* ev = m->ev[m->timed_end % chad_map::kTimingRing];
+        hipEvent_t upd_pair[2] = {ev[T_NORM], ev[T_UPD]};
+        if (hipEvent_t* ke = kernel_events(m, CHAD_KERNEL_UPDATE)) { upd_pair[0] = ke[0]; upd_pair[1] = ke[1]; }
         if (m->update_mode == CHAD_UPDATE_SCATTER) {
             const dim3 grid = grid_for(count);
             if (time_kernel)
-                hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, prep, ev[T_NORM], ev[T_UPD], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
+                hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, prep, upd_pair[0], upd_pair[1], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
             else
                 hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
         } else  // the tiled kernel; in automatic mode it takes the scatter form itself when the frame is sparse (decided on the device)
             tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, list_stride, m->d_stamps,
-                                time_kernel ? ev[T_NORM] : nullptr, time_kernel ? ev[T_UPD] : nullptr);
+                                time_kernel ? upd_pair[0] : nullptr, time_kernel ? upd_pair[1] : nullptr);
         if (times_stages(m)) record(m, T_UPD, prep);
     } else {
         if (!times_stages(m)) record(m, T_NORM, prep);
@@ -604,6 +696,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     HIP_TRY(hipGetLastError());
     m->frames++;
     m->last_points_in = n;
+    if (times_kernels(m)) m->ktimed_end++;
     if (times_anything(m)) {
         m->timed_end++;
         if (m->timed_end - m->timed_begin > chad_map::kTimingRing) m->timed_begin = m->timed_end - chad_map::kTimingRing;
@@ -668,7 +761,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         m->own_stream = true;
     }
     if (const char* e = std::getenv("CHAD_SLOTS")) m->n_slots = std::min<uint32_t>(chad_map::kMaxSlots, std::max(1, std::atoi(e)));
-    m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr;
+    m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE | CHAD_FLAG_TIME_KERNELS)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr;
 
     uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
     if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
@@ -697,9 +790,21 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->h_live_blocks[1] = kMaxPasses;  // sort pass hint: all passes as single launches until the first frame has reported
     if (const char* e = std::getenv("CHAD_DEBUG_SORT_PASSES")) m->sort_passes_forced = uint32_t(std::atoi(e));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
+    CREATE_TRY(hipHostMalloc(&m->h_consumed, chad_map::kMaxSlots * 64, hipHostMallocMapped));
+    std::memset(const_cast<uint32_t*>(m->h_consumed), 0, chad_map::kMaxSlots * 64);
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_consumed), const_cast<uint32_t*>(m->h_consumed), 0));
+    CREATE_TRY(hipEventCreateWithFlags(&m->producer_ready, hipEventDisableTiming));
+    // what the look-back sort may assume about residency: the pass kernel's real occupancy, shared among the frames in flight
+    m->sort_resident = radix_resident_workgroups<PointPayload>();
+    m->aux_resident = radix_resident_workgroups<IndexPayload>() / (m->serial ? 1u : m->n_slots + 1u);
+    m->aux_sort.resident = m->aux_resident;
+    if (std::getenv("CHAD_DEBUG_SORT_TICKETS")) m->sort_resident = 0u;   // experiments: every sort takes tickets
+    for (uint32_t k = 0; k < m->n_slots; k++) m->slot[k].sort.resident = m->sort_resident / (m->serial ? 1u : m->n_slots);
     CREATE_TRY(hipMalloc(&m->d_cursor, 4));
     if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
+    if (times_kernels(m))
+        for (auto& set : m->kev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
     for (uint32_t k = 0; k < m->n_slots; k++)
         if (ensure_frame_capacity(m, m->slot[k], o.max_points ? o.max_points : (1u << 20)) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     CREATE_TRY(hipStreamSynchronize(m->stream));
@@ -739,6 +844,9 @@ void chad_map_destroy(chad_map* m) {
         if (f.prep && f.prep != m->stream) (void)hipStreamDestroy(f.prep);
     }
     if (m->caller_ready) (void)hipEventDestroy(m->caller_ready);
+    if (m->producer_ready) (void)hipEventDestroy(m->producer_ready);
+    if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
+    free_sort_buffers(m->aux_sort);
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
     if (m->sort_turn) (void)hipEventDestroy(m->sort_turn);
     if (m->closing_counted) (void)hipEventDestroy(m->closing_counted);
@@ -752,6 +860,7 @@ void chad_map_destroy(chad_map* m) {
     if (m->h_live_blocks) (void)hipHostFree(const_cast<uint32_t*>(m->h_live_blocks));
     if (m->h_hdr) (void)hipHostFree(m->h_hdr);
     for (auto& set : m->ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
+    for (auto& set : m->kev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -762,6 +871,18 @@ chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t 
     if (!n) return insert_nothing(m, position);
     FrameSlot* f = nullptr;
     TRY(prepare_slot(m, n, &f));
+    return insert_device(m, *f, xyz_device, n, position);
+}
+
+chad_status chad_map_insert_device_stream(chad_map* m, const float* xyz_device, size_t n, const float position[3], void* producer_stream) {
+    if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    if (!n) return insert_nothing(m, position);
+    FrameSlot* f = nullptr;
+    TRY(prepare_slot(m, n, &f));
+    // whatever the producer's stream has been given so far -- the kernels or copies that write the points -- comes first
+    HIP_TRY(hipEventRecord(m->producer_ready, hipStream_t(producer_stream)));
+    HIP_TRY(hipStreamWaitEvent(f->prep, m->producer_ready, 0));
     return insert_device(m, *f, xyz_device, n, position);
 }
 
@@ -803,6 +924,7 @@ chad_status chad_map_sync(chad_map* m) {
     DeviceGuard guard(m->device);
     uint32_t overflow = 0;
     TRY(read_back_header(m, &overflow));
+    if (overflow & kSortFaultStalled) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors (workgroups not dispatched in index order?): at least one frame was sorted incompletely");
     if (overflow) return fail(CHAD_ERR_CAPACITY, "block capacity of the active submap exceeded; raise chad_options.max_blocks");
     return CHAD_OK;
 }
@@ -888,6 +1010,27 @@ chad_status chad_map_stats(chad_map* m, chad_stats* out) {
     return CHAD_OK;
 }
 
+chad_status chad_map_kernel_times(chad_map* m, chad_kernel_times* out) {
+    if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (!times_kernels(m)) return fail(CHAD_ERR_INVALID_ARG, "the map was not created with CHAD_FLAG_TIME_KERNELS");
+    DeviceGuard guard(m->device);
+    TRY(join_streams(m));
+    collect_kernel_times(m);
+    std::memset(out, 0, sizeof(*out));
+    for (int id = 0; id < CHAD_KERNEL_COUNT; id++) {
+        out->launches[id] = m->kernel_launches[id];
+        out->ms[id] = m->kernel_launches[id] ? float(m->kernel_ms[id] / double(m->kernel_launches[id])) : 0.0f;
+        m->kernel_ms[id] = 0; m->kernel_launches[id] = 0;
+    }
+    return CHAD_OK;
+}
+
+const char* chad_kernel_name(int32_t id) {
+    static const char* const names[CHAD_KERNEL_COUNT] = {"k_frame_bounds", "k_frame_keys", "k_radix_onesweep[0]", "k_radix_onesweep[1]", "k_radix_onesweep[2]", "k_radix_onesweep[3]",
+                                                         "k_radix_onesweep[4]", "k_radix_onesweep[5]", "k_radix_onesweep[6]", "k_radix_onesweep[7]", "k_frame_gather", "k_frame_normals", "k_update"};
+    return id >= 0 && id < CHAD_KERNEL_COUNT ? names[id] : "";
+}
+
 chad_status chad_map_block_count(chad_map* m, int32_t submap, size_t* blocks) {
     if (!m || !blocks) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
@@ -929,13 +1072,13 @@ static chad_status export_blocks(chad_map* m, int32_t submap, uint64_t* keys_dev
         HIP_TRY(hipStreamSynchronize(m->stream));
         return CHAD_OK;
     }
-    TRY(join_streams(m));  // slot 0's sort buffers are borrowed below
-    FrameSlot& f = m->slot[0];
-    TRY(ensure_frame_capacity(m, f, nb));
-    // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
-    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, f.sort.keys[0], nb);
-    radix_sort_enqueue(f.sort, nb, kMaxPasses, nullptr, m->stream);
-    hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)f.sort.idx[0], nb, keys, sum, cnt, keys_device, sum_device, cnt_device);
+    TRY(ensure_aux_sort(m, nb));
+    // order the bricks by block key with the radix sorter (all 8 digits: keys are full 63-bit codes)
+    RadixSortSignals sig;
+    sig.fault = m->d_overflow;
+    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
+    radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
+    hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, keys_device, sum_device, cnt_device);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHAD_OK;
@@ -977,9 +1120,7 @@ struct HostClusters { std::vector<uint64_t> keys, tsdf, weight; };
 chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum, const uint32_t* cnt, uint32_t nb, bool want_weights, HostClusters& hc, float* ms) {
     hc.keys.resize(nb); hc.tsdf.resize(size_t(nb) * 8); hc.weight.resize(want_weights ? size_t(nb) * 8 : 0);
     if (!nb) return CHAD_OK;
-    TRY(join_streams(m));  // slot 0's sort buffers are borrowed below
-    FrameSlot& f = m->slot[0];
-    TRY(ensure_frame_capacity(m, f, nb));
+    TRY(ensure_aux_sort(m, nb));
     uint64_t* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_out, size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))));
     uint64_t* d_keys = d_out; uint64_t* d_tsdf = d_out + nb; uint64_t* d_weight = want_weights ? d_tsdf + size_t(nb) * 8 : nullptr;
@@ -987,9 +1128,11 @@ chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum,
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, m->stream));
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
-    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, f.sort.keys[0], nb);
-    radix_sort_enqueue(f.sort, nb, kMaxPasses, nullptr, m->stream);
-    hipLaunchKernelGGL(k_leaf_clusters, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)f.sort.idx[0], nb, keys, sum, cnt, 1.0f / m->trunc /* submap.hpp:23 */,
+    RadixSortSignals sig;
+    sig.fault = m->d_overflow;
+    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
+    radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
+    hipLaunchKernelGGL(k_leaf_clusters, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, 1.0f / m->trunc /* submap.hpp:23 */,
                        d_keys, d_tsdf, d_weight);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hc.keys.data(), d_keys, size_t(nb) * 8, hipMemcpyDeviceToHost, m->stream));
@@ -1171,6 +1314,10 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     HIP_TRY(hipMalloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&b.tile_status, radix_status_words(tiles) * 4));
+    b.resident = std::getenv("CHAD_DEBUG_SORT_TICKETS") ? 0u : radix_resident_workgroups<IndexPayload>();   // nothing else runs beside this sort
+    RadixSortSignals sig;
+    HIP_TRY(hipMalloc(&sig.fault, 4));
+    HIP_TRY(hipMemset(sig.fault, 0, 4));
     HIP_TRY(hipMemcpy(b.keys[0], keys, n * 8, hipMemcpyHostToDevice));
     const uint32_t passes = std::max(1u, (key_bits + kRadixBits - 1) / kRadixBits);
     int reps = 1;
@@ -1180,7 +1327,7 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     for (int r = 0; r < reps; r++) {
         if (r == reps - 1) HIP_TRY(hipEventRecord(e0, nullptr));
         if (r) HIP_TRY(hipMemcpyAsync(b.keys[0], keys, n * 8, hipMemcpyHostToDevice, nullptr));
-        radix_sort_enqueue(b, uint32_t(n), passes, nullptr, nullptr);
+        radix_sort_enqueue(b, uint32_t(n), passes, nullptr, nullptr, 0, 0, sig);
         if (r == reps - 1) HIP_TRY(hipEventRecord(e1, nullptr));
     }
     HIP_TRY(hipGetLastError());
@@ -1192,6 +1339,10 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     if (order_out) HIP_TRY(hipMemcpy(order_out, b.idx[out], n * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < 2; i++) { (void)hipFree(b.keys[i]); (void)hipFree(b.idx[i]); }
     (void)hipFree(b.hist_part); (void)hipFree(b.digit_base); (void)hipFree(b.tile_status);
+    uint32_t fault = 0;
+    HIP_TRY(hipMemcpy(&fault, sig.fault, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(sig.fault);
+    if (fault) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors");
     return CHAD_OK;
 }
 

@@ -308,8 +308,12 @@ __global__ void __launch_bounds__(256)
 k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const float4* __restrict__ points0, const float4* __restrict__ points1,
-               uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t list_stride) {
+               uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t list_stride,
+               uint32_t* __restrict__ consumed, uint32_t consumed_seq) {
     constexpr uint32_t kWords = kGatherChunk / 32;
+    // the sort is over (stream order), so the caller's raw points -- read by its first pass only -- are no longer needed: tell the
+    // host (host-mapped word; chad_hip.hip, prepare_slot).  The sort's later launches store the same number earlier when there are any.
+    if (consumed && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(consumed, consumed_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __shared__ uint32_t mark_bits[kWords], head_bits[kWords];  // bit k: point k of the chunk starts a work item / a point block
     __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
     __shared__ uint32_t base_heads, n_big, n_small, base_big, base_small;

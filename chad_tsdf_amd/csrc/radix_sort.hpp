@@ -14,6 +14,7 @@
 // the maximum and surplus passes return at once, so no host round trip sits between the stages of a frame.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace chadhip {
@@ -33,6 +34,9 @@ constexpr int kMaxHistBlocks = 512;                     // partial tables the bu
 constexpr uint32_t kStatusPublished = 1u << 30;         // flag of a look-back word: the count in its low 30 bits is valid
 constexpr uint32_t kStatusValue = (1u << 30) - 1;
 constexpr uint32_t kGroupTiles = 32;                    // tiles per group of the two-level look-back
+constexpr uint32_t kSpinLimit = 1u << 20;               // polls of one thread for its predecessors before the tile gives up (seconds): a broken
+                                                        // dispatch-order assumption then reports kSortFaultStalled instead of hanging the GPU
+constexpr uint32_t kSortFaultStalled = 2u;              // bit set in RadixSortSignals::fault (bit 0 is the map's capacity overflow)
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -48,15 +52,14 @@ __device__ __forceinline__ size_t tile_index(uint32_t tile, uint32_t wave, uint3
 // memory traffic of the frame); the last pass's output IS the frame's point array in processing order.
 struct IndexPayload {
     using T = uint32_t;
-    static constexpr uint32_t kResident = 1024;   // workgroups of the pass kernel resident at once: 4 per CU (28 KB of LDS each)
     static constexpr bool kStaged = true;         // the payload is reordered through LDS together with its key
     static __device__ __forceinline__ T first(const void*, size_t i) { return uint32_t(i); }
     static __device__ __forceinline__ T none() { return 0u; }
 };
 struct PointPayload {
     using T = uint4;
-    static constexpr uint32_t kResident = 1024;   // 4 per CU: only the keys go through LDS (20 KB).  Staging the 16-byte payload too costs
-                                                  // 32 KB more per workgroup, and three frames' passes then queue for LDS instead of overlapping
+    // only the keys go through LDS (20 KB).  Staging the 16-byte payload too costs 32 KB more per workgroup, and three frames'
+    // passes then queue for LDS instead of overlapping
     static constexpr bool kStaged = false;        // the payload goes from registers straight to its slot (16 bytes per lane, runs of equal digits adjacent)
     static __device__ __forceinline__ T first(const void* xyz, size_t i) {
         const float* p = static_cast<const float*>(xyz) + 3 * i;
@@ -74,6 +77,18 @@ struct RadixSortBuffers {
     uint32_t* tile_status;  // [kMaxPasses][tiles + groups][256] look-back words, zeroed before every sort
     uint32_t* tile_ticket;  // [kMaxPasses] next tile to hand out, zeroed with tile_status (stored right behind it)
     uint32_t tiles_capacity;
+    // Workgroups of the pass kernel that are certainly resident at the same time WHILE EVERYTHING ELSE THAT MAY SHARE THE CHIP
+    // RUNS (the host divides the kernel's real occupancy x CU count by the number of sorts in flight): grids up to this size
+    // may take their tile from blockIdx and may end in grid barriers; larger ones take tickets.  0 = unknown: always tickets.
+    uint32_t resident;
+};
+// Per-sort side channels (all optional).
+struct RadixSortSignals {
+    uint32_t* fault = nullptr;      // device word: kSortFaultStalled is OR-ed in when a tile gave up waiting (the output is then incomplete)
+    uint32_t* consumed = nullptr;   // host-mapped word: every launch after the first stores `seq` here -- pass 0, the only reader of the
+    uint32_t seq = 0;               // caller's raw points (PointPayload::first), has completed by then (stream order)
+    hipEvent_t* pass_events = nullptr;  // kernel timing: launch p takes its dispatch time stamps into pass_events[2p], [2p + 1]
+    uint32_t* launches_out = nullptr;   // (host) ... and the number of pass launches is stored here
 };
 
 inline uint32_t radix_tiles(size_t n) { return uint32_t((n + kSortTile - 1) / kSortTile); }
@@ -131,8 +146,8 @@ __device__ __forceinline__ void
 radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
                     uint64_t* __restrict__ keys_out, typename P::T* __restrict__ pay_out,
                     uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
-                    uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const void* __restrict__ first_src) {
-    constexpr uint32_t kResidentTiles = P::kResident;
+                    uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const void* __restrict__ first_src, bool use_ticket,
+                    uint32_t* __restrict__ fault) {
     // the whole input's count of digit threadIdx.x (asked for first: needed only after the tile has been ranked)
     // (all stripes loaded back to back: a loop over base_stripes waited for each load in turn, 2.5 us per pass)
     uint32_t stripe_total[kBaseStripes];
@@ -144,17 +159,18 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     __shared__ uint32_t wave_count[kSortWaves][kRadix];  // per-wave digit counts, then the wave's base inside the tile
     __shared__ int offset[kRadix];                       // global slot of local sorted position s is offset[digit] + s
     __shared__ uint32_t wave_total[kSortWaves], wave_total_all[kSortWaves];
-    __shared__ uint32_t my_tile;
+    __shared__ uint32_t my_tile, tile_fault;
     __shared__ uint64_t sorted_key[kSortTile];
     __shared__ typename P::T sorted_val[P::kStaged ? kSortTile : 1];
 
     for (uint32_t k = threadIdx.x; k < kSortWaves * kRadix; k += kSortThreads) (&wave_count[0][0])[k] = 0;
-    // A tile waits for the tiles before it.  With at most kResidentTiles tiles every workgroup of the grid is
-    // resident at the same time, so nobody waits for a workgroup that cannot start, whatever the dispatch order;
-    // larger grids hand tiles out in start order through a ticket counter (one serialising atomic per tile).
-    if (tiles > kResidentTiles && threadIdx.x == 0) my_tile = atomicAdd(&tile_ticket[pass], 1u);
+    // A tile waits for the tiles before it.  When the whole grid is certainly resident at the same time (use_ticket false:
+    // the host has checked the grid against the kernel's real occupancy and against the other sorts in flight) nobody waits
+    // for a workgroup that cannot start, whatever the dispatch order; otherwise tiles are handed out in start order through a
+    // ticket counter (one serialising atomic per tile), so that every tile waited for has started.
+    if (threadIdx.x == 0) { tile_fault = 0u; if (use_ticket) my_tile = atomicAdd(&tile_ticket[pass], 1u); }
     __syncthreads();
-    const uint32_t tile = tiles > kResidentTiles ? my_tile : blockIdx.x;
+    const uint32_t tile = use_ticket ? my_tile : blockIdx.x;
     const uint32_t shift = pass * kRadixBits;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -225,6 +241,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     // kGroupTiles sums its group's rows and publishes the group's counts; a tile adds the counts of the lower groups and
     // of the lower tiles of its own group -- three dependent round trips whatever the number of tiles.  Every wait is for
     // a lower tile, as before.
+    uint32_t polls = 0;
     auto sum_rows = [&](const uint32_t* first_row, uint32_t rows) {   // sum of word d of `rows` consecutive rows, waiting for each to be published
         uint32_t sum = 0;
         for (uint32_t r0 = 0; r0 < rows; r0 += kLookback) {
@@ -235,7 +252,10 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 #pragma unroll
             for (uint32_t k = 0; k < kLookback; k++) {
                 uint32_t w = word[k];
-                while ((w & kStatusPublished) == 0) w = __hip_atomic_load(first_row + size_t(r0 + k) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((w & kStatusPublished) == 0) {
+                    if (++polls > kSpinLimit) { tile_fault = 1u; w = kStatusPublished; break; }   // give up: reported, never a hang
+                    w = __hip_atomic_load(first_row + size_t(r0 + k) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 sum += w & kStatusValue;
             }
         }
@@ -251,6 +271,10 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 #pragma unroll
     for (uint32_t w = 0; w < kSortWaves; w++) wave_count[w][d] += local_excl;
     __syncthreads();
+    if (tile_fault) {   // a predecessor never published: the slots are unknown, write nothing (the sort's output is incomplete and says so)
+        if (threadIdx.x == 0 && fault) atomicOr(fault, kSortFaultStalled);
+        return;
+    }
 
 #pragma unroll
     for (uint32_t j = 0; j < kSortItems; j++) {
@@ -277,18 +301,21 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 // host-mapped memory) and sets to_limit on the last of them: normally that launch does its one pass like the others, and
 // when a frame suddenly needs more passes than were enqueued (its extent has grown) the rest still runs, just slower --
 // instead of five surplus launches per frame that return at once.  to_limit requires every workgroup of the grid to be
-// resident at once (tiles <= P::kResident; the caller checks).
+// resident at once beside everything else in flight (tiles <= RadixSortBuffers::resident; radix_sort_enqueue_as checks).
 template <class P>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
                  uint32_t n, uint32_t first_pass, uint32_t to_limit, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
-                 uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src) {
+                 uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src,
+                 uint32_t use_ticket, RadixSortSignals sig) {
     const uint32_t limit = pass_limit ? min(uint32_t(kMaxPasses), *pass_limit) : uint32_t(kMaxPasses);
     uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
+    // this launch runs behind pass 0 (stream order): the caller's raw points have been read for the last time
+    if (sig.consumed && first_pass > 0u && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig.consumed, sig.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (uint32_t pass = first_pass; pass < limit; pass++) {
         const bool odd = pass & 1u;
         radix_onesweep_tile<P>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base, base_stripes,
-                               tile_status, tile_ticket, first_src);
+                               tile_status, tile_ticket, first_src, use_ticket != 0u, sig.fault);
         if (!to_limit || pass + 1 >= limit) break;
         // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
         __syncthreads();
@@ -296,7 +323,11 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
             __threadfence();
             atomicAdd(arrived, 1u);
             const uint32_t target = gridDim.x * (pass - first_pass + 1u);
-            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+            uint32_t polls = 0;
+            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++polls > kSpinLimit) { if (sig.fault) atomicOr(sig.fault, kSortFaultStalled); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
             __threadfence();
         }
         __syncthreads();
@@ -309,9 +340,11 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
 // the first pass reading the raw points `first_src` (float xyz[n][3]) in input order.
 template <class P>
 inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                  uint32_t hist_blocks, uint32_t launch_passes, const void* first_src, hipEvent_t one_at_a_time = nullptr, bool wait_for_it = false) {
+                                  uint32_t hist_blocks, uint32_t launch_passes, const void* first_src, hipEvent_t one_at_a_time = nullptr, bool wait_for_it = false,
+                                  const RadixSortSignals& sig = RadixSortSignals{}) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
+    const bool all_resident = b.resident != 0u && tiles <= b.resident;
     uint32_t* ticket = b.tile_status + radix_status_words(tiles) - 64;
     if (hist_blocks == 0) {
         hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part, b.tile_status,
@@ -320,7 +353,7 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     // hist_blocks != 0: the caller's keys kernel has already added its digit counts into the striped totals (k_frame_keys)
     const uint32_t base_stripes = hist_blocks ? kBaseStripes : 1u;
     if (!hist_blocks) hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
-    const bool hinted = pass_limit && launch_passes && launch_passes < passes && tiles <= P::kResident;
+    const bool hinted = pass_limit && launch_passes && launch_passes < passes && all_resident;
     const uint32_t launches = hinted ? launch_passes : passes;
     for (uint32_t p = 0; p < launches; p++) {
         const bool to_limit = hinted && p + 1 == launches;
@@ -328,18 +361,33 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         // each hold part of the CUs while waiting for the rest of their workgroups would wait forever): sorts running on
         // different streams take turns for this one launch.
         if (to_limit && one_at_a_time && wait_for_it) (void)hipStreamWaitEvent(stream, one_at_a_time, 0);
-        hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                           to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src);
+        if (sig.pass_events)
+            hipExtLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, sig.pass_events[2 * p], sig.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                                  to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
+        else
+            hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                               to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
         if (to_limit && one_at_a_time) (void)hipEventRecord(one_at_a_time, stream);
     }
+    if (sig.launches_out) *sig.launches_out = launches;
 }
 inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
-                               uint32_t launch_passes = 0) {
-    radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr);
+                               uint32_t launch_passes = 0, const RadixSortSignals& sig = RadixSortSignals{}) {
+    radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr, nullptr, false, sig);
 }
 inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                      uint32_t hist_blocks, uint32_t launch_passes, hipEvent_t one_at_a_time, bool wait_for_it) {
-    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, one_at_a_time, wait_for_it);
+                                      uint32_t hist_blocks, uint32_t launch_passes, hipEvent_t one_at_a_time, bool wait_for_it, const RadixSortSignals& sig) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, one_at_a_time, wait_for_it, sig);
+}
+// Workgroups of a pass kernel the device holds at once: the kernel's real occupancy (registers, LDS) x CU count, with a quarter
+// held back (the runtime's answer can exceed what the hardware admits by one per CU -- MI355X_MICROARCH.md, Residency).
+template <class P>
+inline uint32_t radix_resident_workgroups() {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_radix_onesweep<P>, kSortThreads, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0u; }
+    return uint32_t(per_cu > 0 ? per_cu : 0) * uint32_t(prop.multiProcessorCount) * 3u / 4u;
 }
 
 }  // namespace chadhip

@@ -22,7 +22,7 @@ def _np_f32(a, shape_last=3):
 class TSDFMap:
     def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, device: int = -1, max_blocks: int = 0,
                  max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, time_update: bool = False, fixed_capacity: bool = False, update_mode: int = 0,
-                 dag_saturate_weights: bool = False, dag_only: bool = False):
+                 dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False):
         self._lib = _lib.load()
         self._sdf_res = float(sdf_res)
         self._sdf_trunc = float(sdf_trunc)
@@ -32,7 +32,7 @@ class TSDFMap:
         opt.max_blocks = max_blocks
         opt.max_points = max_points
         opt.stream = stream or None
-        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0)
+        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0)
         opt.update_mode = update_mode
         handle = C.c_void_p()
         _lib.check(self._lib.chad_map_create(sdf_res, sdf_trunc, C.byref(opt), C.byref(handle)), "TSDFMap")
@@ -48,8 +48,12 @@ class TSDFMap:
     __del__ = close
 
     # ---- reference API ------------------------------------------------------------------------------
-    def insert(self, points, position):
-        """TSDFMap::insert(points, position) -- tsdf.hpp:48-64."""
+    def insert(self, points, position, ready: bool = False):
+        """TSDFMap::insert(points, position) -- tsdf.hpp:48-64.
+
+        A torch CUDA tensor is taken zero-copy.  The frame is ordered behind torch's current stream (whatever produces the
+        tensor there -- a cast, a kernel, a copy -- comes first) unless ready=True: the caller then vouches that the data is
+        complete (e.g. after torch.cuda.synchronize()), which saves an event record and a stream wait per insert."""
         pos = _np_f32(position).reshape(3)
         if hasattr(points, "is_cuda") and points.is_cuda:  # torch tensor on the GPU: zero-copy
             import torch
@@ -58,9 +62,16 @@ class TSDFMap:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 t = t.to(torch.float32).contiguous()
             n = t.numel() // 3
-            _lib.check(self._lib.chad_map_insert_device(self._h, t.data_ptr(), n, pos.ctypes.data), "TSDFMap.insert")
-            # the device buffer must outlive the kernels that read it: two frames are in flight at a time
-            self._keepalive = (getattr(self, "_keepalive", (None, None, None)) + (t,))[-3:]
+            if ready:
+                _lib.check(self._lib.chad_map_insert_device(self._h, t.data_ptr(), n, pos.ctypes.data), "TSDFMap.insert")
+            else:
+                _lib.check(self._lib.chad_map_insert_device_stream(self._h, t.data_ptr(), n, pos.ctypes.data, torch.cuda.current_stream(t.device).cuda_stream),
+                           "TSDFMap.insert")
+            # The buffer must outlive the kernels that read it: until one further insert per frame slot has returned
+            # (include/chad_hip.h; the library waits for the device there).  Holding the tensors also keeps torch's caching
+            # allocator from handing the block to somebody else's kernel on another stream meanwhile.
+            if n:
+                self._keepalive = (getattr(self, "_keepalive", ()) + (t,))[-_lib.MAX_SLOTS:]
         else:
             pts = _np_f32(points)
             _lib.check(self._lib.chad_map_insert(self._h, pts.ctypes.data, pts.shape[0], pos.ctypes.data), "TSDFMap.insert")
@@ -109,6 +120,12 @@ class TSDFMap:
         st = _lib.Stats()
         _lib.check(self._lib.chad_map_stats(self._h, C.byref(st)), "TSDFMap.stats")
         return {name: getattr(st, name) for name, _ in _lib.Stats._fields_}
+
+    def kernel_times(self) -> dict:
+        """Mean duration (ms) and launch count of every kernel of the insert pipeline since the last call (time_kernels=True)."""
+        kt = _lib.KernelTimes()
+        _lib.check(self._lib.chad_map_kernel_times(self._h, C.byref(kt)), "TSDFMap.kernel_times")
+        return {self._lib.chad_kernel_name(i).decode(): (float(kt.ms[i]), int(kt.launches[i])) for i in range(_lib.KERNEL_COUNT) if kt.launches[i]}
 
     @property
     def closed_submaps(self) -> int:

@@ -57,6 +57,8 @@ enum {
     CHAD_FLAG_FIXED_CAPACITY = 8u, /* never grow the block pool beyond max_blocks (default: it doubles between frames when half full) */
     CHAD_FLAG_DAG_SATURATE_WEIGHTS = 16u, /* weight clusters hold min(weight, 254).  Default (off) is what the reference stores:
                                             std::max<uint8_t>(w, 255) at submap.hpp:93 makes every weight byte 0xff */
+    CHAD_FLAG_TIME_KERNELS = 64u, /* every kernel of an insert is timed on its own (begin / end time stamps of its dispatch, no event
+                                     records in between); frames run one after the other.  Read with chad_map_kernel_times */
     CHAD_FLAG_DAG_ONLY = 32u /* a closed submap is folded into the DAG as soon as its archive is complete and its dense brick copy
                                 is released: device memory then holds the active submap only (long trajectories), as the reference
                                 keeps nothing but the DAG of a closed submap (tsdf.cpp:53-54).  Closed submaps are then read back with
@@ -79,7 +81,7 @@ typedef struct chad_stats {
     uint64_t hash_capacity;
     uint64_t closed_submaps;  /* reference: _submaps.size(), tsdf.cpp:54 */
     uint32_t sort_passes;     /* radix passes of the last insert */
-    uint32_t overflow;        /* non-zero once a capacity limit dropped updates */
+    uint32_t overflow;        /* sticky; bit 0: a capacity limit dropped updates, bit 1: a radix sort tile gave up waiting (chad_map_sync reports CHAD_ERR_HIP) */
     /* mean device milliseconds per insert since the previous stats call, by the reference's stage names;
        zero unless CHAD_FLAG_TIMING / CHAD_FLAG_VERBOSE */
     float ms_mc_calc, ms_mc_sort, ms_norm_est, ms_oct_upd, ms_total;
@@ -94,9 +96,18 @@ void chad_map_destroy(chad_map* map);
  * xyz: points_count packed x,y,z triples in HOST memory, borrowed for the duration of the call. */
 chad_status chad_map_insert(chad_map* map, const float* xyz, size_t points_count, const float position[3]);
 /* Same, with the points already resident in DEVICE memory of the map's device (no PCIe copy).  The call returns when the
- * work is enqueued (on internal streams: up to three frames are in flight): the buffer must stay valid and unchanged until
- * three further inserts or a synchronisation point (chad_map_sync / export / stats) have returned. */
+ * work is enqueued (on internal streams: up to three frames are in flight).
+ * Lifetime: the buffer must stay valid and unchanged until three further inserts WITH POINTS (one per frame slot), or a
+ * synchronisation point (chad_map_sync / export / stats), have returned.  The library enforces its half: before an insert
+ * reuses a frame slot it waits until the device has read the input of the frame that used the slot before (the device
+ * reports that through host-mapped memory; no event, no stall when the device keeps up), which also bounds how far the host
+ * runs ahead -- three frames.
+ * Readiness: the points must be complete when the call is made (the frame runs on streams of the map's own, which do not
+ * wait for any other stream).  If a kernel or copy still in flight on some stream produces them, use the _stream form. */
 chad_status chad_map_insert_device(chad_map* map, const float* xyz_device, size_t points_count, const float position[3]);
+/* Same, ordered behind `producer_stream` (a hipStream_t; NULL = the legacy default stream): the frame waits, on the device,
+ * for everything enqueued on that stream so far -- the work that writes xyz_device.  One event record + one stream wait. */
+chad_status chad_map_insert_device_stream(chad_map* map, const float* xyz_device, size_t points_count, const float position[3], void* producer_stream);
 
 /* Wait for all enqueued work of this map; reports CHAD_ERR_CAPACITY if any update was dropped. */
 chad_status chad_map_sync(chad_map* map);
@@ -119,6 +130,17 @@ chad_status chad_map_would_roll_over(chad_map* map, const float position[3], int
 chad_status chad_map_leaf_count(chad_map* map, int32_t submap, size_t* count);
 chad_status chad_map_export_leaves(chad_map* map, int32_t submap, uint64_t* mc, float* sd, uint32_t* w, size_t capacity, size_t* count);
 chad_status chad_map_stats(chad_map* map, chad_stats* out);
+/* Measurement: mean duration of every kernel of the insert pipeline, one entry per kernel and sort pass,
+ * over the inserts since the previous call.  Needs CHAD_FLAG_TIME_KERNELS.  The reference's counterpart are its five stage timers
+ * (morton.hpp:76-78,98-100; normals.hpp:144-146; octree.hpp:167-169; tsdf.cpp:72-74). */
+enum { CHAD_KERNEL_BOUNDS = 0, CHAD_KERNEL_KEYS = 1, CHAD_KERNEL_SORT_PASS0 = 2 /* .. 9: radix passes 0..7 */, CHAD_KERNEL_GATHER = 10,
+       CHAD_KERNEL_NORMALS = 11, CHAD_KERNEL_UPDATE = 12, CHAD_KERNEL_COUNT = 13 };
+typedef struct chad_kernel_times {
+    float ms[CHAD_KERNEL_COUNT];          /* mean milliseconds per launch */
+    uint64_t launches[CHAD_KERNEL_COUNT]; /* launches averaged over (0: the kernel did not run) */
+} chad_kernel_times;
+chad_status chad_map_kernel_times(chad_map* map, chad_kernel_times* out);
+const char* chad_kernel_name(int32_t id);
 
 /* Multi-GPU merge support: per-block partial sums of a submap, on the DEVICE, sorted by block key
  * (key = MortonCode & ~63, the reference's lookup key, octree.hpp:33-36).  sum[b*64+v] is the sum of

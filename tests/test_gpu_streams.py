@@ -1,0 +1,212 @@
+"""Streams of frames at BASELINE.json's full sizes (cfg3, cfg5) and the contracts of the asynchronous insert: buffer lifetime,
+ordering behind the producer's stream, many large frames in flight."""
+import numpy as np
+import pytest
+
+from chad_tsdf_amd import synth
+from tests.util import SD_TOL, assert_leaves_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def chad():
+    import chad_tsdf_amd
+
+    chad_tsdf_amd._lib.load()
+    return chad_tsdf_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import pyoracle
+
+    pyoracle.lib()
+    return pyoracle
+
+
+def same_bits(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def test_device_buffers_may_be_overwritten_after_three_further_inserts(chad):
+    """include/chad_hip.h, chad_map_insert_device: a buffer must stay unchanged until three further inserts have returned --
+    and not a moment longer.  Twelve frames go through a ring of FOUR device buffers: buffer k % 4 is overwritten (by a copy
+    on torch's stream, which waits for nothing) right after insert k + 3 has returned.  The map must equal the map of the
+    same frames inserted one at a time, bit for bit."""
+    import torch
+
+    frames = [synth.cfg3_frame(k) for k in range(12)]
+    src = [torch.from_numpy(p).cuda() for p, _ in frames]
+    torch.cuda.synchronize()
+    serial = chad.TSDFMap(0.05, 0.10)
+    for (_, pos), d in zip(frames, src):
+        serial.insert(d, pos, ready=True)
+        serial.sync()
+    want = serial.export_leaves()
+    serial.close()
+    for attempt in range(3):
+        ring = [torch.empty_like(src[0]) for _ in range(4)]
+        m = chad.TSDFMap(0.05, 0.10)
+        for k, (_, pos) in enumerate(frames):
+            buf = ring[k % 4]
+            buf.copy_(src[k], non_blocking=True)     # overwrites frame k - 4's points; legal since insert k - 1 returned
+            m.insert(buf, pos)                        # (ordered behind the copy: torch's current stream)
+        m.sync()
+        got = m.export_leaves()
+        m.close()
+        assert same_bits(got, want), f"attempt {attempt}: a frame read a buffer that was already overwritten"
+
+
+def test_insert_is_ordered_behind_the_producers_stream(chad):
+    """the tensor handed to insert() may still be being written on torch's stream (a cast, an arithmetic kernel, a
+    .contiguous() copy).  No synchronisation anywhere: the frame must wait for its producer on the device."""
+    import torch
+
+    pts, pos = synth.cfg2_frame(600_000, seed=41)
+    host = chad.TSDFMap(0.05, 0.10)
+    host.insert(pts, pos)
+    want = host.export_leaves()
+    host.close()
+    base = torch.from_numpy(pts).cuda()
+    wide = torch.zeros((len(pts), 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    producers = {
+        "arithmetic": lambda: base * 1.0 + 0.0,
+        "float64": lambda: base.to(torch.float64),                            # cast inside insert()
+        "non-contiguous": lambda: wide.copy_(torch.nn.functional.pad(base.double(), (0, 1)))[:, :3],   # strided view, f64
+        "side stream": None,
+    }
+    for name, make in producers.items():
+        m = chad.TSDFMap(0.05, 0.10)
+        big = torch.empty((64 << 20,), device="cuda")
+        if make is None:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                big.normal_()                         # keeps the side stream busy for a while
+                t = base * 1.0
+                m.insert(t, pos)                      # current stream = side
+        else:
+            big.normal_()                             # the producer queues behind ~100 us of other work
+            m.insert(make(), pos)
+        m.sync()
+        got = m.export_leaves()
+        m.close()
+        assert same_bits(got, want), name
+
+
+def test_three_large_frames_in_flight(chad):
+    """three 1.5 M-point frames (733 sort tiles each) in flight exceed what the chip holds at once; the sort then
+    hands out its tiles by ticket, so that a tile only ever waits for tiles that have started."""
+    import torch
+
+    frames = [synth.cfg2_frame(1_500_000, seed=51 + k, sensor=(0.3 + 0.05 * k, -0.2, 0.1)) for k in range(3)]
+    dev = [torch.from_numpy(p).cuda() for p, _ in frames]
+    torch.cuda.synchronize()
+    ref = chad.TSDFMap(0.05, 0.10, max_points=1_500_000)
+    for (_, pos), d in zip(frames, dev):
+        ref.insert(d, pos, ready=True)
+        ref.sync()
+    want = ref.export_leaves()
+    ref.close()
+    m = chad.TSDFMap(0.05, 0.10, max_points=1_500_000)
+    for rep in range(4):
+        for (_, pos), d in zip(frames, dev):
+            m.insert(d, pos, ready=True)
+    m.sync()
+    got = m.export_leaves()
+    assert m.stats()["overflow"] == 0
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], 4 * want[2])
+    m.close()
+
+
+def test_dag_only_roll_over_with_small_frame_capacity(chad, oracle):
+    """with CHAD_FLAG_DAG_ONLY a roll-over folds the closed submap into the DAG inside insert(); its block-key sort
+    must not borrow (and regrow, i.e. free) the buffers of a frame slot that already holds the staged points of the frame
+    being inserted.  max_points far below the submap's block count forces the growth."""
+    m = chad.TSDFMap(0.05, 0.10, max_points=2048, dag_only=True)
+    o = oracle.OracleMap(0.05, 0.10)
+    for k in range(0, 230, 10):     # poses 0.5 m apart: roll-overs when frames 110 and 220 arrive
+        pts, pos = synth.cfg3_frame(k, 2000)
+        m.insert(pts, pos)          # host points: staged into the slot before the roll-over bookkeeping runs
+        o.insert(pts, pos)
+    m.sync()
+    assert m.closed_submaps == o.closed_submaps == 2
+    assert m.block_count(-1) > 0
+    assert_leaves_match(m.export_leaves(-1), o.export_leaves(-1), 0.10)
+    for s in range(2):
+        mc, sd = m.dag_leaves(s)
+        omc, osd, ow = o.export_leaves(s)
+        assert np.array_equal(mc, omc)
+        assert np.abs(sd - osd).max() <= 0.10 / 127 * 1.01 + 0.10 * SD_TOL   # 8-bit quantisation of the DAG (cluster.hpp:13-26)
+    m.close()
+
+
+def test_cfg3_full_stream(chad):
+    """BASELINE config 3 at its stated size: 500 frames x 200 k points, sensor advancing 0.05 m per frame.  Device-resident,
+    enqueued back to back (three frames in flight, roll-overs asynchronous).  Checked: roll-overs when frames 101 / 202 / 303 /
+    404 arrive (tsdf.cpp:52); every submap bit-identical to the same stream inserted one frame at a time;
+    per submap, sum of weights == sum of the frames' update counts; hash load <= 0.5; the active submap after frames 0..99 is
+    the reference's (V = 737 935, sum of weights 135 382 309)."""
+    import torch
+
+    n_frames = 500
+    frames = [synth.cfg3_frame(k) for k in range(n_frames)]
+    dev = [torch.from_numpy(p).cuda() for p, _ in frames]
+    torch.cuda.synchronize()
+    # one frame at a time, with the per-frame counters
+    serial = chad.TSDFMap(0.05, 0.10)
+    updates, closed_at, max_load = [], [], 0.0
+    for k, ((_, pos), d) in enumerate(zip(frames, dev)):
+        serial.insert(d, pos, ready=True)
+        st = serial.stats()
+        updates.append(st["updates"])
+        max_load = max(max_load, st["blocks"] / st["hash_capacity"])
+        if st["closed_submaps"] != len(closed_at):
+            closed_at.append(k)
+        if k == 99:
+            mc, sd, w = serial.export_leaves()
+            assert len(mc) == 737_935 and int(w.sum(dtype=np.uint64)) == 135_382_309
+    assert closed_at == [101, 202, 303, 404]
+    assert max_load <= 0.5
+    bounds = [0] + closed_at + [n_frames]
+    per_submap = [serial.export_leaves(s) for s in range(4)] + [serial.export_leaves(-1)]
+    for s, leaves in enumerate(per_submap):
+        assert int(leaves[2].sum(dtype=np.uint64)) == sum(updates[bounds[s]:bounds[s + 1]]), f"submap {s}"
+        assert np.isfinite(leaves[1]).all() and np.abs(leaves[1]).max() <= 0.10 * (1 + 1e-5)
+    serial.close()
+    # the way a stream is inserted: no synchronisation at all
+    m = chad.TSDFMap(0.05, 0.10)
+    for (_, pos), d in zip(frames, dev):
+        m.insert(d, pos, ready=True)
+    m.sync()
+    st = m.stats()
+    assert st["closed_submaps"] == 4 and st["overflow"] == 0
+    for s, want in enumerate(per_submap):
+        assert same_bits(m.export_leaves(s if s < 4 else -1), want), f"submap {s}"
+    m.close()
+
+
+def test_cfg5_stream_with_roll_overs_and_table_growth(chad, oracle):
+    """BASELINE config 5's shape: 0.02 m voxels, 0.06 m truncation, 200 k points per frame, the sensor advancing 0.5 m per
+    frame (a roll-over every 11 frames), 34 frames.  The block table starts at 2^20 blocks and doubles while the first submap
+    fills.  Leaf sets and weights of every submap exact against the oracle, signed distances within 1e-4."""
+    n_frames = 34
+    m = chad.TSDFMap(0.02, 0.06, max_blocks=1 << 20)
+    o = oracle.OracleMap(0.02, 0.06)
+    grown = False
+    for k in range(n_frames):
+        pts, pos = synth.cfg5_frame(k)
+        m.insert(pts, pos)
+        o.insert(pts, pos)
+        if k % 8 == 7:    # a strided look at the state in between (synchronises; the other frames stay in flight)
+            st = m.stats()
+            assert st["overflow"] == 0 and st["blocks"] / st["hash_capacity"] <= 0.5
+            grown = grown or st["block_capacity"] > (1 << 20)
+            assert_leaves_match(m.export_leaves(-1), o.export_leaves(-1), 0.06)
+    m.sync()
+    assert grown, "the table never doubled"
+    assert m.closed_submaps == o.closed_submaps == 3      # frames 11, 22 and 33 arrive more than 5 m from their submap's first pose
+    for s in (0, 1, 2, -1):
+        assert_leaves_match(m.export_leaves(s), o.export_leaves(s), 0.06)
+    m.close()
