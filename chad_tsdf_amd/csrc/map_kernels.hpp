@@ -9,13 +9,14 @@
 // CAS, pool counter, index publish/wait -- 17 us of the update kernel):
 //   hash_keys[H]     u64  open-addressed table of block keys (code & ~63); EMPTY = ~0; linear probing, so a probe
 //                         sequence walks consecutive 8-byte keys of one 128-byte line before touching the next
-//   brick_sum[H*64]  f32  sum of the clamped signed distances observed by each voxel of the brick in slot s
+//   brick_sum[H*64]  i64  sum of the clamped signed distances observed by each voxel of the brick in slot s, in units of
+//                         trunc / 2^30 (exact, order-independent; see kSumOne below)
 //   brick_cnt[H*64]  u32  number of observations (the reference's Leaf::_weight)
 //   live_bits[H/32]  u32  bit s set: slot s holds a brick (set fire-and-forget by the claiming lane); clearing,
 //                         export and growth walk this bitmap -- O(H/32 + bricks), not O(table)
-//   brick_count[32*16] u32  number of bricks, striped over 32 cache lines (no same-address atomics)
-// H = 2 * capacity rounded up to a power of two, i.e. the table -- and with it the brick storage, 512 B per slot --
-// is at most half full at the nominal capacity; 288 GB of HBM make that trade (2 x 520 B per block) a cheap one.
+//   brick_count[kCountStripes*16] u32  number of bricks, striped over kCountStripes = 256 cache lines (no same-address atomics)
+// H = 2 * capacity rounded up to a power of two, i.e. the table -- and with it the brick storage, 768 B per slot --
+// is at most half full at the nominal capacity; 288 GB of HBM make that trade (2 x 776 B per block) a cheap one.
 // Slots that hold no brick keep all-zero rows (zeroed at allocation and again whenever a brick is released).
 // The reference keeps a running mean sd and a count w per leaf, with unit weight per observation
 // (octree.hpp:161-163); (sum, cnt) is the same information with sd = sum / cnt, and it is what makes the update a

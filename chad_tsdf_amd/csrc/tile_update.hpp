@@ -5,13 +5,14 @@
 // every voxel a super block's rays touch lies in the cube of D = 8 + 2R voxels around it: D^3 x 8 bytes of LDS --
 // 21.4 KiB for trunc = 2*res (D = 14), 32 KiB for D = 16 (the largest tile kept in LDS) -- which the 4x4x4 = 64
 // bricks around the super block cover.  One workgroup of four waves per work item (a super block, cut at every
-// 512th point by k_frame_gather); the first version staged one 4x4x4 block per wave: 3.2 times as many items,
+// kItemPoints-th = 1024th point by k_frame_gather); the first version staged one 4x4x4 block per wave: 3.2 times as many items,
 // each paying the per-item latencies below, and 83 % of the lanes busy instead of 97 %.  Per item:
 //   1. the waves take the item's 64-point chunks in turn; each lane walks the ray of its point and accumulates
 //      (d, 1) into the tile with ONE ds_add_u64 per observation.  A tile cell is a 64-bit word
 //      [count : 20 | sum of (d * 2^30/trunc + 2^30) : 44]: the fixed-point step trunc * 2^-30 is finer than the f32
-//      rounding of d itself, an item adds at most 512 observations per cell (no carry into the count), and integer
-//      sums do not depend on the order of arrival.
+//      rounding of d itself; an item holds at most kItemPoints = 1024 points, each of which visits a cell at most once,
+//      so a cell takes at most 1024 observations of at most 2^31 each: 2^41 < 2^44, no carry into the count, and the
+//      count (<= 1024) fits its 20 bits; integer sums do not depend on the order of arrival.
 //      The walk itself is the reference's traversal (same f32 operations on tmax/delta, same comparison tree, so
 //      the voxel lists are bit-identical) with the bookkeeping folded into three registers: the LDS address and the
 //      per-axis remaining step counts share one word that a step updates with a single add, and the signed
@@ -44,10 +45,11 @@ constexpr int kTileWaves = 4;            // waves per workgroup: they share the 
 constexpr int kTileThreads = 64 * kTileWaves;
 constexpr uint32_t kMaxReach = 4;        // D = 16: 32 KiB of LDS per workgroup
 constexpr float kFixedOne = kSumOne;  // 2^30: |d| = trunc in the tile's fixed-point scale -- the unit of the map's sums (map_kernels.hpp)
-constexpr uint32_t kCountShift = 44;        // tile cell = [count : 20 | sum of biased fixed-point distances : 44]: an item's 512 observations of
-                                            // at most 2^31 each stay below 2^40 (with the count at bit 40 a cell that took 512 observations of
-                                            // +trunc carried into its own count: found by test_sort_survives_..., whose small frames put
-                                            // thousands of points into the voxels next to the sensor)
+constexpr uint32_t kCountShift = 44;        // tile cell = [count : 20 | sum of biased fixed-point distances : 44]: an item's kItemPoints = 1024
+                                            // observations of at most 2^31 each stay below 2^41 (with the count at bit 40 a cell that took 512
+                                            // observations of +trunc carried into its own count: found by test_sort_survives_..., whose small
+                                            // frames put thousands of points into the voxels next to the sensor)
+static_assert(uint64_t(kItemPoints) << 31 < (1ull << kCountShift) && kItemPoints < (1u << (64 - kCountShift)), "a tile cell must hold an item's worst case");
 
 // b where the lane's bit of `mask` is set, a elsewhere: v_cndmask_b32 with the lane mask in a scalar register pair
 __device__ __forceinline__ float select_f(float a, float b, uint64_t mask) {

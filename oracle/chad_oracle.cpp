@@ -534,7 +534,7 @@ size_t oracle_map_export_leaves(void* h, int submap, uint64_t* mc, float* sd, ui
     else if (size_t(submap) < m->closed.size()) s = &m->closed[size_t(submap)];
     else return 0;
     const size_t n = std::min(cap, s->mc.size());
-    std::memcpy(mc, s->mc.data(), n * 8); std::memcpy(sd, s->sd.data(), n * 4); std::memcpy(w, s->w.data(), n * 4);
+    if (n) { std::memcpy(mc, s->mc.data(), n * 8); std::memcpy(sd, s->sd.data(), n * 4); std::memcpy(w, s->w.data(), n * 4); }   // (memcpy's pointers must not be null, even for 0 bytes: UBSan)
     return s->mc.size();
 }
 // The exact means (f64 sum / count) of the ACTIVE octree's leaves, in the order of oracle_map_export_leaves(h, -1, ...).

@@ -12,14 +12,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libchad_oracle.so")
+SANITIZE = os.environ.get("CHAD_SANITIZE", "") not in ("", "0")   # `make asan`: the ASan + UBSan build (the interpreter runs with libasan preloaded)
+_SO = os.path.join(_HERE, "_build", "libchad_oracle_asan.so" if SANITIZE else "libchad_oracle.so")
 _lib = None
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "chad_oracle.cpp")
     if force or not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if SANITIZE else []))
     return _SO
 
 

@@ -49,3 +49,19 @@ def test_cpp_class_builds_the_oracles_map(tmp_path):
     omc, osd, ow = o.export_leaves()
     assert np.array_equal(mc, omc) and np.array_equal(w, ow)
     assert (np.abs(sd - osd) / np.maximum(np.abs(osd), 0.10)).max() <= SD_TOL
+
+
+@pytest.mark.skipif(shutil.which("cmake") is None, reason="cmake not installed")
+def test_cmake_consumer_links_chad_tsdf_target(tmp_path):
+    """The reference's consumers write `target_link_libraries(app PRIVATE chad::tsdf)` (reference CMakeLists.txt:18-19,
+    README.md:20-29): a consumer project that adds this repository as a subdirectory must configure, build (hipcc
+    cross-compiles gfx950 without a GPU) and link against that target."""
+    (tmp_path / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.18)\nproject(consumer LANGUAGES CXX)\n"
+        f"add_subdirectory({ROOT} chad_tsdf)\n"
+        f"add_executable(app {SRC})\ntarget_link_libraries(app PRIVATE chad::tsdf)\n")
+    build = tmp_path / "build"
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    subprocess.check_call(["cmake", "-S", str(tmp_path), "-B", str(build), *gen], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", str(build)], stdout=subprocess.DEVNULL)
+    assert (build / "app").exists() and (build / "chad_tsdf" / "libchad_hip.so").exists()

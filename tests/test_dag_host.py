@@ -20,7 +20,8 @@ SRC = os.path.join(ROOT, "tests", "cpp", "dag_check.cpp")
 @pytest.fixture(scope="module")
 def dagcheck(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("dagcheck") / "libdagcheck.so")
-    subprocess.check_call([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-shared", "-fPIC", SRC, "-o", out])
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if pyoracle.SANITIZE else ["-O2"]   # `make asan`
+    subprocess.check_call([shutil.which("g++") or "g++", "-std=c++17", *san, "-shared", "-fPIC", SRC, "-o", out])
     lib = C.CDLL(out)
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     lib.dagcheck_create.restype = vp
