@@ -12,7 +12,7 @@ all: $(LIB) oracle
 
 $(LIB): $(CSRC)/chad_hip.hip $(CSRC)/tsdf_shim.cpp $(HDRS)
 	@mkdir -p chad_tsdf_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared -Iinclude -o $@ $(CSRC)/chad_hip.hip -x hip $(CSRC)/tsdf_shim.cpp
+	$(HIPCC) $(HIPFLAGS) -shared -Iinclude -o $@ $(CSRC)/chad_hip.hip -x hip $(CSRC)/tsdf_shim.cpp -ldl
 
 oracle:
 	$(MAKE) -C oracle -s

@@ -18,6 +18,9 @@ FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATUR
 KERNEL_COUNT = 13
 DAG_NODE_LEVELS, DAG_CLUSTER_LEVEL = 20, 20
 UPDATE_AUTO, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
+COMM_ID_BYTES, REDUCE_U32, REDUCE_I64 = 128, 0, 1
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)   # chad_allgather_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32)    # chad_allreduce_fn
 MAX_SLOTS = 8  # chad_map::kMaxSlots: the most frames a map ever keeps in flight (three by default)
 
 
@@ -94,6 +97,12 @@ SYMBOLS = {
     "chad_map_export_blocks_device": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
     "chad_map_export_blocks_device_unordered": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz]),
     "chad_map_close_submap_with_blocks_device": (_i32, [_vp, _vp, _vp, _vp, _sz]),
+    "chad_comm_unique_id": (_i32, [_vp]),
+    "chad_comm_create_rccl": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "chad_comm_create_callbacks": (_i32, [_i32, _i32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "chad_comm_destroy": (None, [_vp]),
+    "chad_map_attach_comm": (_i32, [_vp, _vp]),
+    "chad_map_merge_and_close": (_i32, [_vp, _vp]),
     "chad_map_finalize": (_i32, [_vp]),
     "chad_map_dag_roots": (_i32, [_vp, _i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "chad_map_dag_level_words": (_i32, [_vp, C.c_uint32, C.POINTER(_sz)]),

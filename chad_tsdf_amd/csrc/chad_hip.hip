@@ -15,9 +15,11 @@
 #include <string>
 #include <vector>
 
+#include "comm.hpp"
 #include "dag.hpp"
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
+#include "merge_kernels.hpp"
 #include "radix_sort.hpp"
 #include "tile_update.hpp"
 
@@ -56,6 +58,13 @@ struct Submap {  // a closed submap: dense copies of its bricks (stands in for t
     uint32_t* cnt = nullptr;
     uint32_t blocks = 0;
     bool released = false;  // CHAD_FLAG_DAG_ONLY: folded into the DAG, the dense copy given back
+};
+
+struct DevBuf {   // device allocation released on every exit path
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
 enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
@@ -143,6 +152,10 @@ struct chad_map {
     uint32_t* d_cursor = nullptr;                 // output cursor of k_compact_bricks
     uint64_t frames = 0, last_points_in = 0;
     uint64_t frames_empty_tail = 0;               // empty inserts since the last one with points (they use no slot)
+    // Frame-sharded multi-GPU map (chad_map_attach_comm): insert k of the stream is integrated by rank k % world only, and a
+    // submap is closed by merging the ranks' partial bricks (merge_and_close) instead of archiving the local ones.
+    chad_comm* comm = nullptr;
+    uint64_t stream_frames = 0;                   // inserts seen since the communicator was attached
     // stage timing (CHAD_FLAG_TIMING): a ring of event sets, one per insert, read back lazily by chad_map_stats so
     // that timing adds no synchronisation to insert()
     static constexpr int kTimingRing = 64;
@@ -586,12 +599,16 @@ inline bool rolls_over(const chad_map* m, const float position[3]) {
     return std::sqrt(dx * dx + dy * dy + dz * dz) > 5.0f;
 }
 
+chad_status merge_and_close(chad_map* m, chad_comm* c);   // (further down)
+inline bool is_sharded(const chad_map* m) { return m->comm && m->comm->exchanges(); }
+
 chad_status note_pose(chad_map* m, const float position[3]) {
     const std::array<float, 3> pose{position[0], position[1], position[2]};
     if (m->positions.empty()) m->positions.push_back(pose);
     else {
         if (rolls_over(m, position)) {
-            TRY(close_active(m));
+            // every rank of a sharded map sees every pose, so all of them get here for the same frame: the merge is collective
+            TRY(is_sharded(m) ? merge_and_close(m, m->comm) : close_active(m));
             m->positions.clear();
             m->positions.push_back(pose);
         } else m->positions.push_back(pose);
@@ -865,9 +882,13 @@ void chad_map_destroy(chad_map* m) {
     delete m;
 }
 
+// frame-sharded map: is insert number stream_frames (counted from the attach) this rank's?  Counts the insert.
+static bool owns_next_frame(chad_map* m) { return int32_t(m->stream_frames++ % uint64_t(m->comm->world)) == m->comm->rank; }
+
 chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t n, const float position[3]) {
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
+    if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
     if (!n) return insert_nothing(m, position);
     FrameSlot* f = nullptr;
     TRY(prepare_slot(m, n, &f));
@@ -877,6 +898,7 @@ chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t 
 chad_status chad_map_insert_device_stream(chad_map* m, const float* xyz_device, size_t n, const float position[3], void* producer_stream) {
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
+    if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
     if (!n) return insert_nothing(m, position);
     FrameSlot* f = nullptr;
     TRY(prepare_slot(m, n, &f));
@@ -889,6 +911,7 @@ chad_status chad_map_insert_device_stream(chad_map* m, const float* xyz_device, 
 chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float position[3]) {
     if (!m || !position || (n && !xyz)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
+    if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
     if (!n) return insert_nothing(m, position);
     FrameSlot* fp = nullptr;
     TRY(prepare_slot(m, n, &fp));
@@ -958,7 +981,7 @@ chad_status chad_map_close_submap(chad_map* m) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
     if (m->positions.empty()) return CHAD_OK;
-    TRY(close_active(m));
+    TRY(is_sharded(m) ? merge_and_close(m, m->comm) : close_active(m));
     m->positions.clear();
     return CHAD_OK;
 }
@@ -1109,6 +1132,161 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
     TRY(clear_active(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return release_finalized(m);
+}
+
+
+// ---- multi-GPU: communicators and the exchange at a submap close -----------------------------------
+namespace {
+
+#define COMM_TRY(expr) do { if (!(expr)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: " + c->error); } while (0)
+
+// The exchange step.  Collective: every rank of `c` calls it at the same point of the frame stream (the roll-over rule depends
+// on the poses only, which every rank sees).  Afterwards every rank holds the same closed submap -- the sum of all ranks'
+// partial bricks, bit for bit what one GPU would have archived from the same frames -- and an empty active submap.
+chad_status merge_and_close(chad_map* m, chad_comm* c) {
+    if (!c || !c->exchanges()) return close_active(m);
+    if (c->device != m->device) return fail(CHAD_ERR_INVALID_ARG, "the communicator was created on another device");
+    TRY(finish_closing(m, true));
+    uint32_t nb = 0;
+    TRY(read_block_count(m, &nb));   // carries out a pending reset, waits for every frame in flight
+    hipStream_t s = m->stream;
+    const uint32_t world = uint32_t(c->world);
+
+    // 1. this rank's live bricks, dense and raw (64-bit sums)
+    DevBuf keys, sum, cnt;
+    HIP_TRY(keys.alloc(size_t(nb) * 8)); HIP_TRY(sum.alloc(size_t(nb) * 512)); HIP_TRY(cnt.alloc(size_t(nb) * 256));
+    if (nb) {
+        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
+        hipLaunchKernelGGL(k_compact_bricks_raw, dim3(512), dim3(256), 0, s, m->view, m->d_cursor, nb, keys.as<uint64_t>(), sum.as<long long>(), cnt.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    // 2. how many blocks every rank holds
+    DevBuf d_n, d_all_n;
+    HIP_TRY(d_n.alloc(8)); HIP_TRY(d_all_n.alloc(8 * size_t(world)));
+    const uint64_t n_local = nb;
+    HIP_TRY(hipMemcpyAsync(d_n.p, &n_local, 8, hipMemcpyHostToDevice, s));
+    COMM_TRY(c->all_gather(d_n.p, d_all_n.p, 8, s));
+    std::vector<uint64_t> counts(world);
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_all_n.p, 8 * size_t(world), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint64_t total = 0, longest = 0;
+    RankCounts rc{};
+    for (uint32_t r = 0; r < world; r++) {
+        if (counts[r] >= (1ull << 31)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible block count from a rank");
+        rc.count[r] = uint32_t(counts[r]); rc.begin[r] = uint32_t(total);
+        total += counts[r]; longest = std::max(longest, counts[r]);
+    }
+    if (total >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks over all ranks");
+    Submap arch;
+    if (total) {
+        // 3. all ranks' keys (lists padded to the longest), then the sorted union -- the same on every rank
+        DevBuf send, recv;
+        HIP_TRY(send.alloc(longest * 8)); HIP_TRY(recv.alloc(longest * 8 * world));
+        hipLaunchKernelGGL(k_fill_u64, grid_for(longest), dim3(256), 0, s, send.as<uint64_t>(), size_t(longest), kEmptyKey);
+        if (nb) HIP_TRY(hipMemcpyAsync(send.p, keys.p, size_t(nb) * 8, hipMemcpyDeviceToDevice, s));
+        COMM_TRY(c->all_gather(send.p, recv.p, longest * 8, s));
+        TRY(ensure_aux_sort(m, total));
+        hipLaunchKernelGGL(k_concat_keys, grid_for(longest), dim3(256), 0, s, recv.as<uint64_t>(), uint32_t(longest), rc, world, m->aux_sort.keys[0]);
+        RadixSortSignals sig;
+        sig.fault = m->d_overflow;
+        radix_sort_enqueue(m->aux_sort, uint32_t(total), kMaxPasses, nullptr, s, 0, 0, sig);   // an even number of passes: sorted keys end up in keys[0]
+        const uint32_t chunks = uint32_t((total + kUniqueChunk - 1) / kUniqueChunk);
+        DevBuf heads, d_union_n;
+        HIP_TRY(heads.alloc(size_t(chunks) * 4)); HIP_TRY(d_union_n.alloc(4));
+        hipLaunchKernelGGL(k_unique_count, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(total), heads.as<uint32_t>());
+        hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, s, heads.as<uint32_t>(), chunks, d_union_n.as<uint32_t>());
+        uint32_t n_union = 0;
+        HIP_TRY(hipMemcpyAsync(&n_union, d_union_n.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        TRY(alloc_submap(arch, n_union));
+        hipLaunchKernelGGL(k_unique_write, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(total), heads.as<uint32_t>(), arch.keys);
+        // 4. this rank's bricks into dense buffers over the union; 5. the all-reduce: 64-bit integer sums and counts, exact in any order
+        const size_t cells = size_t(n_union) * 64;
+        DevBuf dense_sum, dense_cnt;
+        HIP_TRY(dense_sum.alloc(cells * 8)); HIP_TRY(dense_cnt.alloc(cells * 4));
+        HIP_TRY(hipMemsetAsync(dense_sum.p, 0, cells * 8, s));
+        HIP_TRY(hipMemsetAsync(dense_cnt.p, 0, cells * 4, s));
+        if (nb) hipLaunchKernelGGL(k_scatter_bricks_dense, grid_for(size_t(nb) * 64), dim3(256), 0, s, keys.as<uint64_t>(), sum.as<long long>(), cnt.as<uint32_t>(), nb, arch.keys, n_union,
+                                   dense_sum.as<long long>(), dense_cnt.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        COMM_TRY(c->all_reduce(dense_sum.p, cells, CHAD_REDUCE_I64, s));
+        COMM_TRY(c->all_reduce(dense_cnt.p, cells, CHAD_REDUCE_U32, s));
+        // 6. the archive's format, converted exactly as the single-GPU archive converts (k_compact_bricks)
+        hipLaunchKernelGGL(k_dense_to_archive, grid_for(cells), dim3(256), 0, s, dense_sum.as<long long>(), dense_cnt.as<uint32_t>(), cells, m->trunc, arch.sum, arch.cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));   // the temporaries go out of scope
+    } else TRY(alloc_submap(arch, 0));
+    m->closed.push_back(arch);
+    m->positions.clear();
+    TRY(clear_active(m));
+    return release_finalized(m);
+}
+#undef COMM_TRY
+
+}  // namespace
+
+chad_status chad_comm_unique_id(uint8_t id[CHAD_COMM_ID_BYTES]) {
+    if (!id) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    const std::string err = rccl().load();
+    if (!err.empty()) return fail(CHAD_ERR_HIP, err);
+    static_assert(sizeof(RcclApi::UniqueId) == CHAD_COMM_ID_BYTES, "ncclUniqueId is 128 bytes (rccl.h:40)");
+    RcclApi::UniqueId uid;
+    const int r = rccl().get_unique_id(&uid);
+    if (r) return fail(CHAD_ERR_HIP, std::string("ncclGetUniqueId: ") + rccl().get_error_string(r));
+    std::memcpy(id, &uid, CHAD_COMM_ID_BYTES);
+    return CHAD_OK;
+}
+
+chad_status chad_comm_create_rccl(const uint8_t id[CHAD_COMM_ID_BYTES], int32_t rank, int32_t world, chad_comm** out) {
+    if (!out || !id) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world) return fail(CHAD_ERR_INVALID_ARG, "rank / world out of range (at most 15 ranks)");
+    chad_comm* c = new chad_comm();
+    c->rank = rank; c->world = world;
+    c->no_shortcut = std::getenv("CHAD_DEBUG_COMM_NO_SHORTCUT") != nullptr;
+    if (hipGetDevice(&c->device) != hipSuccess) { (void)hipGetLastError(); delete c; return fail(CHAD_ERR_NO_DEVICE, "no HIP device"); }
+    if (c->exchanges()) {
+        const std::string err = rccl().load();
+        if (!err.empty()) { delete c; return fail(CHAD_ERR_HIP, err); }
+        RcclApi::UniqueId uid;
+        std::memcpy(&uid, id, CHAD_COMM_ID_BYTES);
+        const int r = rccl().comm_init_rank(&c->nccl, world, uid, rank);   // collective: returns once every rank has joined
+        if (r) { delete c; return fail(CHAD_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().get_error_string(r)); }
+    }
+    *out = c;
+    return CHAD_OK;
+}
+
+chad_status chad_comm_create_callbacks(int32_t rank, int32_t world, chad_allgather_fn all_gather, chad_allreduce_fn all_reduce, void* user, chad_comm** out) {
+    if (!out || (world > 1 && (!all_gather || !all_reduce))) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world) return fail(CHAD_ERR_INVALID_ARG, "rank / world out of range (at most 15 ranks)");
+    chad_comm* c = new chad_comm();
+    c->rank = rank; c->world = world; c->gather = all_gather; c->reduce = all_reduce; c->user = user;
+    c->no_shortcut = std::getenv("CHAD_DEBUG_COMM_NO_SHORTCUT") != nullptr && all_gather && all_reduce;
+    if (hipGetDevice(&c->device) != hipSuccess) { (void)hipGetLastError(); delete c; return fail(CHAD_ERR_NO_DEVICE, "no HIP device"); }
+    *out = c;
+    return CHAD_OK;
+}
+
+void chad_comm_destroy(chad_comm* c) {
+    if (!c) return;
+    if (c->nccl) (void)rccl().comm_destroy(c->nccl);
+    delete c;
+}
+
+chad_status chad_map_attach_comm(chad_map* m, chad_comm* c) {
+    if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    if (c && c->device != m->device) return fail(CHAD_ERR_INVALID_ARG, "the communicator was created on another device than the map's");
+    m->comm = c;
+    m->stream_frames = 0;
+    return CHAD_OK;
+}
+
+chad_status chad_map_merge_and_close(chad_map* m, chad_comm* c) {
+    if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    DeviceGuard guard(m->device);
+    return merge_and_close(m, c ? c : m->comm);
 }
 
 // ---- Submap::finalize (submap.hpp:10-106): leaf clusters on the device, the DAG of NodeLevels on the host ----

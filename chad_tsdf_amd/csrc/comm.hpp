@@ -1,0 +1,105 @@
+// comm.hpp -- the transport of the multi-GPU exchange (the reference is single-process, there is nothing
+// to cite): two collectives over the ranks of a job, all-gather and all-reduce(sum), on DEVICE buffers of the map's stream.
+//   * RCCL (the product path): ncclAllGather / ncclAllReduce over xGMI.  librccl.so.1 is opened at run time (dlopen; a process
+//     that already holds one -- PyTorch ships its own -- gets that same instance), so the library itself loads without RCCL
+//     and single-GPU users never touch it.
+//   * caller-supplied collectives on HOST buffers (tests and rehearsals: gloo / MPI / anything): the buffers are staged
+//     through host memory around each call.  RCCL refuses several ranks on one GPU; this transport is how the exchange's
+//     device-side logic is exercised on a one-GPU box.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/chad_hip.h"
+
+namespace chadhip {
+
+// the few RCCL entry points the exchange needs, by their documented C signatures (rccl.h: ncclGetUniqueId :187,
+// ncclCommInitRank :220, ncclCommDestroy :260, ncclGetErrorString :339, ncclAllReduce :611, ncclAllGather :678)
+struct RcclApi {
+    struct UniqueId { char internal[128]; };
+    typedef int (*GetUniqueId)(UniqueId*);
+    typedef int (*CommInitRank)(void** comm, int nranks, UniqueId id, int rank);
+    typedef int (*CommDestroy)(void* comm);
+    typedef const char* (*GetErrorString)(int);
+    typedef int (*AllReduce)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream);
+    typedef int (*AllGather)(const void* send, void* recv, size_t sendcount, int datatype, void* comm, hipStream_t stream);
+    enum { kUint32 = 3, kInt64 = 4, kUint64 = 5, kSum = 0 };   // ncclDataType_t / ncclRedOp_t values (rccl.h:448-472)
+    void* handle = nullptr;
+    GetUniqueId get_unique_id = nullptr;
+    CommInitRank comm_init_rank = nullptr;
+    CommDestroy comm_destroy = nullptr;
+    GetErrorString get_error_string = nullptr;
+    AllReduce all_reduce = nullptr;
+    AllGather all_gather = nullptr;
+
+    // empty string on success
+    std::string load() {
+        if (handle) return "";
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) return std::string("cannot load librccl.so.1: ") + dlerror();
+        get_unique_id = reinterpret_cast<GetUniqueId>(dlsym(handle, "ncclGetUniqueId"));
+        comm_init_rank = reinterpret_cast<CommInitRank>(dlsym(handle, "ncclCommInitRank"));
+        comm_destroy = reinterpret_cast<CommDestroy>(dlsym(handle, "ncclCommDestroy"));
+        get_error_string = reinterpret_cast<GetErrorString>(dlsym(handle, "ncclGetErrorString"));
+        all_reduce = reinterpret_cast<AllReduce>(dlsym(handle, "ncclAllReduce"));
+        all_gather = reinterpret_cast<AllGather>(dlsym(handle, "ncclAllGather"));
+        if (!get_unique_id || !comm_init_rank || !comm_destroy || !get_error_string || !all_reduce || !all_gather) { handle = nullptr; return "librccl.so.1 lacks an expected symbol"; }
+        return "";
+    }
+};
+inline RcclApi& rccl() { static RcclApi api; return api; }
+
+}  // namespace chadhip
+
+struct chad_comm {
+    int32_t rank = 0, world = 1;
+    int device = 0;
+    void* nccl = nullptr;                         // ncclComm_t (RCCL transport)
+    chad_allgather_fn gather = nullptr;           // callback transport
+    chad_allreduce_fn reduce = nullptr;
+    void* user = nullptr;
+    std::vector<unsigned char> host;              // callback transport: staging
+    std::string error;
+    bool no_shortcut = false;                     // CHAD_DEBUG_COMM_NO_SHORTCUT: a one-rank communicator goes through its transport as well
+                                                  // (tests: the RCCL calls themselves on a one-GPU box)
+    bool exchanges() const { return world > 1 || no_shortcut; }
+
+    // recv[world * bytes] <- every rank's send[bytes], in rank order.  Device buffers; ordered on `stream`.
+    bool all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) {
+        if (!exchanges()) return hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, stream) == hipSuccess;
+        if (nccl) {
+            if (bytes % 8) { error = "all_gather: size not a multiple of 8"; return false; }
+            const int r = chadhip::rccl().all_gather(send, recv, bytes / 8, chadhip::RcclApi::kUint64, nccl, stream);
+            if (r) { error = std::string("ncclAllGather: ") + chadhip::rccl().get_error_string(r); return false; }
+            return true;
+        }
+        host.resize(bytes * size_t(world + 1));
+        if (hipMemcpyAsync(host.data(), send, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { error = "all_gather: staging copy failed"; return false; }
+        if (gather(user, host.data(), host.data() + bytes, bytes) != 0) { error = "all_gather callback failed"; return false; }
+        if (hipMemcpyAsync(recv, host.data() + bytes, bytes * size_t(world), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { error = "all_gather: staging copy failed"; return false; }
+        return true;
+    }
+    // buf[count] <- sum over the ranks, in place.  dtype: CHAD_REDUCE_U32 / CHAD_REDUCE_I64.
+    bool all_reduce(void* buf, size_t count, int32_t dtype, hipStream_t stream) {
+        if (!exchanges() || count == 0) return true;
+        const size_t bytes = count * (dtype == CHAD_REDUCE_I64 ? 8 : 4);
+        if (nccl) {
+            const int r = chadhip::rccl().all_reduce(buf, buf, count, dtype == CHAD_REDUCE_I64 ? chadhip::RcclApi::kInt64 : chadhip::RcclApi::kUint32, chadhip::RcclApi::kSum, nccl, stream);
+            if (r) { error = std::string("ncclAllReduce: ") + chadhip::rccl().get_error_string(r); return false; }
+            return true;
+        }
+        host.resize(bytes);
+        if (hipMemcpyAsync(host.data(), buf, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { error = "all_reduce: staging copy failed"; return false; }
+        if (reduce(user, host.data(), count, dtype) != 0) { error = "all_reduce callback failed"; return false; }
+        if (hipMemcpyAsync(buf, host.data(), bytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { error = "all_reduce: staging copy failed"; return false; }
+        return true;
+    }
+};

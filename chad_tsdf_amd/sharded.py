@@ -12,8 +12,12 @@ happens when a submap closes:
   3. all_reduce(SUM) of the f32 sums and of the i32 counts (backend "nccl" = RCCL over xGMI on ROCm);
   4. every rank archives the merged bricks as the closed submap (sd = sum / count at read-back).
 
-Everything here is torch.distributed plumbing over tensors; it runs unchanged on CPU tensors with the gloo
-backend, which is how the N > 1 path is tested without GPUs (tests/test_distributed_gloo.py).
+With the HIP map all of this lives behind the C ABI (include/chad_hip.h, "Multi-GPU"): chad_map_attach_comm makes insert()
+frame-sharded and the exchange runs in the library -- RCCL all-gather / all-reduce of 64-bit integer sums and counts, so N ranks
+archive bit for bit what one GPU archives.  This module only builds the communicator (`Comm`: the RCCL id travels over
+torch.distributed; with the gloo backend the library's collectives are served by torch.distributed callbacks on host buffers,
+which is how several ranks are rehearsed on one GPU) and keeps the SPMD wrapper.  `merge_blocks` and the Python protocol below
+remain for duck-typed stand-in maps (the CPU tests of the sharding logic, tests/test_distributed_gloo.py).
 """
 from __future__ import annotations
 
@@ -22,6 +26,70 @@ import torch
 import torch.distributed as dist
 
 SUBMAP_DISTANCE = np.float32(5.0)  # tsdf.cpp:52
+
+
+class Comm:
+    """A chad_comm over the ranks of a torch.distributed process group.
+
+    backend nccl: the library's own RCCL communicator (rank 0's ncclUniqueId is broadcast through the process group);
+    backend gloo (or anything else): the library calls back into torch.distributed with host buffers."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+
+        from . import _lib
+
+        self._lib = _lib.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.group = group
+        self.handle = C.c_void_p()
+        backend = dist.get_backend(group)
+        if backend == "nccl":
+            uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+            if self.rank == 0:
+                _lib.check(self._lib.chad_comm_unique_id(uid.numpy().ctypes.data), "Comm")
+            uid = uid.cuda()
+            dist.broadcast(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = uid.cpu().numpy()
+            torch.cuda.synchronize()
+            _lib.check(self._lib.chad_comm_create_rccl(uid.ctypes.data, self.rank, self.world, C.byref(self.handle)), "Comm")
+            self.transport = "rccl"
+        else:
+            def view(ptr, nbytes, dtype):
+                return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)).view(dtype))
+
+            def all_gather(_user, send, recv, nbytes):
+                try:
+                    dist.all_gather_into_tensor(view(recv, nbytes * self.world, np.uint8), view(send, nbytes, np.uint8), group=group)
+                    return 0
+                except Exception:  # noqa: BLE001  (reported by the library as a failed exchange)
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            def all_reduce(_user, buf, count, dtype):
+                try:   # wrapping integer sums: the signed view adds the same bits
+                    t = view(buf, count * 8, np.int64) if dtype == _lib.REDUCE_I64 else view(buf, count * 4, np.int32)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            self._callbacks = (_lib.ALLGATHER_FN(all_gather), _lib.ALLREDUCE_FN(all_reduce))   # kept alive with the communicator
+            _lib.check(self._lib.chad_comm_create_callbacks(self.rank, self.world, C.cast(self._callbacks[0], C.c_void_p), C.cast(self._callbacks[1], C.c_void_p),
+                                                            None, C.byref(self.handle)), "Comm")
+            self.transport = "callbacks/" + backend
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.chad_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
 
 
 def merge_blocks(keys: torch.Tensor, sums: torch.Tensor, cnts: torch.Tensor, group=None):
@@ -79,6 +147,12 @@ class ShardedTSDFMap:
         self._frame = 0          # frames seen in the stream
         self._empty = np.zeros((0, 3), dtype=np.float32)
         self._fast = hasattr(local, "would_roll_over") and hasattr(local, "note_pose")  # the HIP map; stand-ins take the numpy path
+        # the HIP map shards inside the library: attach a communicator and every insert / roll-over / close does the right thing there
+        self._native = hasattr(local, "attach_comm")
+        self.comm = None
+        if self._native:
+            self.comm = Comm(group) if self.world > 1 else None
+            local.attach_comm(self.comm)
 
     def owner(self, frame: int) -> int:
         return frame % self.world
@@ -90,6 +164,14 @@ class ShardedTSDFMap:
 
     def insert(self, points, position):
         pos = np.ascontiguousarray(position, dtype=np.float32).reshape(3)
+        if self._native:   # ownership (frame k -> rank k % world), pose bookkeeping and the exchange at a roll-over all happen in the library
+            if points is None:
+                self.local.note_pose(pos)
+            else:
+                self.local.insert(points, pos)
+            self._first_pose = pos
+            self._frame += 1
+            return
         # The roll-over rule, evaluated identically on every rank before the frame.  A rank that does not own the frame
         # spends about 3 us here (one query + one pose-only insert, both plain C calls): at 8 ranks that is what bounds the
         # strong scaling of a stream of small frames, so the path avoids numpy arithmetic where the local map offers the calls.
@@ -116,6 +198,10 @@ class ShardedTSDFMap:
 
     def merge_and_close(self):
         """The exchange step: merge the active submap across ranks and archive it on every rank."""
+        if self._native:
+            self.local.merge_and_close()
+            self._first_pose = None
+            return
         try:
             keys, sums, cnts = self.local.export_blocks(-1, ordered=False)   # the merge orders the union of all ranks' keys
         except TypeError:  # a stand-in map without the option

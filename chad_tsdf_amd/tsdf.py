@@ -76,6 +76,15 @@ class TSDFMap:
             pts = _np_f32(points)
             _lib.check(self._lib.chad_map_insert(self._h, pts.ctypes.data, pts.shape[0], pos.ctypes.data), "TSDFMap.insert")
 
+    def attach_comm(self, comm):
+        """Make this map one rank's share of a frame-sharded map (chad_map_attach_comm); comm: chad_tsdf_amd.sharded.Comm or None."""
+        _lib.check(self._lib.chad_map_attach_comm(self._h, comm.handle if comm is not None else None), "TSDFMap.attach_comm")
+        self._comm = comm   # must outlive the attachment
+
+    def merge_and_close(self):
+        """The exchange step (collective over the attached communicator): merge the ranks' active submaps, archive the result."""
+        _lib.check(self._lib.chad_map_merge_and_close(self._h, None), "TSDFMap.merge_and_close")
+
     def note_pose(self, pos: np.ndarray):
         """An insert without points (pose bookkeeping of tsdf.cpp:46-61 only); pos: float32[3], C-contiguous.  The cheap path
         the frame-sharded map takes on the ranks that do not own a frame."""

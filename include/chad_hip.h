@@ -156,6 +156,41 @@ chad_status chad_map_export_blocks_device_unordered(chad_map* map, int32_t subma
 /* Close the active submap as if a roll-over happened, replacing its content by the given (merged) blocks. */
 chad_status chad_map_close_submap_with_blocks_device(chad_map* map, const uint64_t* keys_device, const float* sum_device, const uint32_t* cnt_device, size_t blocks);
 
+/* ---- Multi-GPU: one process per GPU, whole frames dealt round-robin, ONE exchange per submap ------------
+ * The reference is a single process; what makes the path shard is its arithmetic: a leaf is the mean of unit-weight
+ * observations (octree.hpp:161-163) and a frame's stages depend on that frame alone (tsdf.cpp:64-70), so per-GPU partial
+ * (sum, count) bricks combine by addition -- exactly, because the map holds 64-bit integer sums: N ranks archive bit for bit
+ * the submaps one GPU archives from the same stream.
+ * Use: every rank creates a communicator and attaches it to its map; then EVERY rank calls the same insert / close_submap /
+ * save sequence with the same positions (points are only read on the rank that owns the frame: insert k of the stream
+ * belongs to rank k % world; the others may pass n = 0).  The 5 m roll-over rule (tsdf.cpp:46-61) sees every pose on every
+ * rank, so all ranks reach the exchange at the same frame: all-gather of block keys, sorted union, all-reduce(sum) of the i64
+ * sums and u32 counts over the union (RCCL over xGMI), every rank archives the merged submap. */
+typedef struct chad_comm chad_comm;
+enum { CHAD_COMM_ID_BYTES = 128 };
+/* RCCL transport.  Rank 0 makes an id (ncclGetUniqueId) and hands the bytes to the other ranks over any channel the
+ * application has (MPI, a file, torch.distributed ...); then every rank calls chad_comm_create_rccl (collective, with the rank's
+ * GPU current).  librccl.so.1 is loaded at this point, not before.  At most 15 ranks. */
+chad_status chad_comm_unique_id(uint8_t id[CHAD_COMM_ID_BYTES]);
+chad_status chad_comm_create_rccl(const uint8_t id[CHAD_COMM_ID_BYTES], int32_t rank, int32_t world, chad_comm** out);
+/* Transport through the caller's own collectives on HOST buffers (the library stages device data through host memory around
+ * each call): for tests and rehearsals where RCCL cannot be used, e.g. several ranks sharing one GPU over gloo or MPI.
+ * all_gather: recv[world * bytes] <- every rank's send[bytes] in rank order; all_reduce: buf[count] <- element-wise sum over
+ * the ranks (wrapping integer addition), dtype CHAD_REDUCE_U32 or CHAD_REDUCE_I64.  Return 0 on success. */
+enum { CHAD_REDUCE_U32 = 0, CHAD_REDUCE_I64 = 1 };
+typedef int32_t (*chad_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
+typedef int32_t (*chad_allreduce_fn)(void* user, void* buf, size_t count, int32_t dtype);
+chad_status chad_comm_create_callbacks(int32_t rank, int32_t world, chad_allgather_fn all_gather, chad_allreduce_fn all_reduce, void* user, chad_comm** out);
+void chad_comm_destroy(chad_comm* comm);
+/* Make `map` one rank's share of a frame-sharded map (NULL detaches).  From here on chad_map_insert* integrate only the
+ * frames this rank owns and record the pose of the others, and a submap is closed -- by the roll-over rule inside insert, by
+ * chad_map_close_submap, by save() -- through the exchange above instead of a local archive.  The communicator must outlive
+ * the attachment. */
+chad_status chad_map_attach_comm(chad_map* map, chad_comm* comm);
+/* The exchange on its own (collective): merge the active submaps of all ranks and archive the result on every rank.
+ * comm NULL = the attached one; a one-rank communicator makes it chad_map_close_submap. */
+chad_status chad_map_merge_and_close(chad_map* map, chad_comm* comm);
+
 /* Submap::finalize (submap.hpp:10-106) and NodeLevels (levels.hpp:141-199): every closed submap is folded, in closing
  * order, into one map-wide DAG -- twenty node levels plus the leaf clusters (cluster.hpp:9-108), each storing a node once
  * and handing out addresses in order of first occurrence, the signed-distance tree before the weight tree.  The device

@@ -280,7 +280,7 @@ def test_roll_over_query_is_the_rule_of_the_insert(chad):
     closed = []
     for fast in (True, False):
         s = ShardedTSDFMap(0.05, 0.10)
-        s._fast = fast
+        s._fast = s._native = fast   # True: the library's own sharding (chad_map_attach_comm); False: the Python protocol stand-in maps take
         for k in range(0, 260, 7):
             pts, pos = synth.cfg3_frame(k, 3000)
             s.insert(pts, pos)

@@ -1,6 +1,8 @@
-"""The N > 1 path with the real single-device map: two processes share the one GPU of the test box, exchange over gloo
-(sharded.py then runs its collectives on host copies), frames dealt round-robin, one merge at the roll-over.  Every rank
-must end up with the submaps a single process builds from the whole stream."""
+"""The N > 1 path with the real single-device map: two processes share the one GPU of the test box (RCCL refuses that, so the
+library's exchange runs over its callback transport, served by gloo), frames dealt round-robin by the library
+(chad_map_attach_comm), one merge at the roll-over.  Every rank must end up with the submaps a single process builds from the
+whole stream -- bit for bit: the exchange adds 64-bit integer sums.  The RCCL transport itself is exercised with a one-rank
+communicator forced through ncclAllGather / ncclAllReduce."""
 import os
 import sys
 
@@ -50,7 +52,6 @@ def test_two_ranks_on_one_gpu_build_the_single_process_submaps(tmp_path):
     import torch.multiprocessing as mp
 
     import chad_tsdf_amd
-    from tests.util import SD_TOL
 
     world, port = 2, 29533
     mp.spawn(_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
@@ -63,8 +64,7 @@ def test_two_ranks_on_one_gpu_build_the_single_process_submaps(tmp_path):
         for rank in range(world):
             got = np.load(tmp_path / f"rank{rank}_submap{s}.npz")
             assert np.array_equal(got["mc"], want[0]) and np.array_equal(got["w"], want[2]), f"rank {rank} submap {s}"
-            err = np.abs(got["sd"] - want[1]) / np.maximum(np.abs(want[1]), 0.10)
-            assert err.max() <= SD_TOL
+            assert np.array_equal(got["sd"].view(np.uint32), want[1].view(np.uint32)), f"rank {rank} submap {s}: N ranks == 1 GPU, bit for bit"
     # ... and the ranks' DAGs: equal to each other, and to the oracle's finalize of the merged leaves
     from oracle import pyoracle
 
@@ -78,3 +78,41 @@ def test_two_ranks_on_one_gpu_build_the_single_process_submaps(tmp_path):
         assert np.array_equal(dags[0][f"level{l}"], o.dag_level(l)), f"level {l} differs from the oracle"
     assert np.array_equal(dags[0]["roots"], dags[1]["roots"]) and tuple(dags[0]["roots"][1]) == o.dag_roots(1)
     single.close()
+
+
+def test_one_rank_rccl_communicator_goes_through_rccl(monkeypatch):
+    """The RCCL transport on the one GPU there is: a one-rank communicator that is NOT short-cut (CHAD_DEBUG_COMM_NO_SHORTCUT), so
+    that the roll-over's exchange really calls ncclCommInitRank / ncclAllGather (u64) / ncclAllReduce (i64 and u32 sums) through
+    the dlopen-ed librccl.so.1 -- signatures, enum values, stream ordering.  Result: the plain map's submaps, bit for bit."""
+    import ctypes as C
+
+    import chad_tsdf_amd
+    from chad_tsdf_amd import _lib
+
+    lib = _lib.load()
+    monkeypatch.setenv("CHAD_DEBUG_COMM_NO_SHORTCUT", "1")
+    uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    _lib.check(lib.chad_comm_unique_id(uid), "unique_id")
+    comm = C.c_void_p()
+    _lib.check(lib.chad_comm_create_rccl(uid, 0, 1, C.byref(comm)), "create_rccl")
+    monkeypatch.delenv("CHAD_DEBUG_COMM_NO_SHORTCUT")
+
+    class Handle:
+        handle = comm
+
+    plain = chad_tsdf_amd.TSDFMap(0.05, 0.10)
+    shard = chad_tsdf_amd.TSDFMap(0.05, 0.10)
+    shard.attach_comm(Handle)
+    for pts, pos in _stream():
+        plain.insert(pts, pos)
+        shard.insert(pts, pos)
+    plain.close_submap()
+    shard.close_submap()          # with a communicator attached: the exchange
+    assert plain.closed_submaps == shard.closed_submaps == 2
+    for s in (0, 1):
+        got, want = shard.export_leaves(s), plain.export_leaves(s)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+        assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    shard.attach_comm(None)
+    shard.close(); plain.close()
+    lib.chad_comm_destroy(comm)
