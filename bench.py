@@ -136,7 +136,9 @@ def main():
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from chad_tsdf_amd import TSDFMap
-    from chad_tsdf_amd.sharded import ShardedTSDFMap
+    from chad_tsdf_amd.sharded import Comm, ShardedTSDFMap
+
+    comm = Comm() if world > 1 else None   # the library's communicator: RCCL (backend nccl) or torch.distributed callbacks (gloo rehearsal)
 
     scans = [(torch.from_numpy(pts).cuda(), pos, pts) for pts, pos in host_scans]
     torch.cuda.synchronize()
@@ -155,7 +157,7 @@ def main():
     # ---- the contract's line: cfg2, reset + insert per step ---------------------------------------------------------------
     # the timed map brackets only the update kernel with HIP events (the dispatch's own time stamps, on the stream it runs on)
     m = TSDFMap(res, trunc, time_update=True, update_mode=args.update_mode, max_points=args.points)
-    job = ShardedTSDFMap(res, trunc, local=m) if world > 1 else None
+    job = ShardedTSDFMap(res, trunc, local=m, comm=comm) if world > 1 else None
 
     def step(i):
         d_pts, pos, _ = scans[i % len(scans)]
@@ -219,7 +221,7 @@ def main():
             "workload": "cfg2: single 1M-point synthetic room scan (10x8x3 m box), voxel 0.05 m, trunc 0.10 m, inserted into an empty map each step",
             "points_per_frame": args.points,
             "frames_per_step_per_gpu": 1,
-            "parallelism": f"frames round-robin over {world} GPU(s); one block-partial merge ({backend}) per timed region" if world > 1 else "1 GPU",
+            "parallelism": f"frames round-robin over {world} GPU(s); one block-partial merge ({comm.transport}) per timed region" if world > 1 else "1 GPU",
             "update_kernel": {0: "auto (tiled for this dense frame)", 1: "scatter", 2: "tiled"}[args.update_mode],
         },
         "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
@@ -311,14 +313,14 @@ def main():
         dev = {k: torch.from_numpy(p).cuda() for k, (p, _) in stream_frames.items()}
         torch.cuda.synchronize()
         local = TSDFMap(c3["res"], c3["trunc"], max_points=c3["n"])
-        sm = ShardedTSDFMap(c3["res"], c3["trunc"], local=local) if world > 1 else local
+        sm = ShardedTSDFMap(c3["res"], c3["trunc"], local=local, comm=comm) if world > 1 else local
         for k in range(min(3 * world, args.stream_frames)):   # warm-up: kernels and (N > 1) the exchange
             sm.insert(dev.get(k), poses[k]) if world > 1 else sm.insert(dev[k], poses[k], ready=True)
         if world > 1:
             sm.merge_and_close()
         local.reset(); local.sync()
         if world > 1:
-            sm = ShardedTSDFMap(c3["res"], c3["trunc"], local=local)
+            sm = ShardedTSDFMap(c3["res"], c3["trunc"], local=local, comm=comm)   # (re-attaching restarts the frame count: frame 0 is rank 0's again)
         barrier()
         torch.cuda.synchronize()
         max_load = 0.0
@@ -339,7 +341,7 @@ def main():
         t_stream, t_host = max_over_ranks(t_stream, t_host)
         s3 = local.stats()
         leg = {"workload": f"{args.stream_frames} frames x {c3['n']} points, corridor 30x8x3 m, voxel 0.05 m, trunc 0.10 m, sensor moving 0.05 m/frame"
-                           + (f"; frames round-robin over {world} ranks, block partials merged ({backend}) at every submap close" if world > 1 else ""),
+                           + (f"; frames round-robin over {world} ranks, block partials merged ({comm.transport}) at every submap close" if world > 1 else ""),
                "scaling": "strong", "n_gpus": world, "ms_per_frame": round(t_stream / args.stream_frames * 1e3, 4),
                "points_per_s": round(args.stream_frames * c3["n"] / t_stream), "host_enqueue_ms_per_frame": round(t_host / args.stream_frames * 1e3, 4),
                "closed_submaps": int(s3["closed_submaps"]), "live_blocks": int(s3["blocks"]), "hash_load": round(s3["blocks"] / s3["hash_capacity"], 5),

@@ -134,7 +134,7 @@ class ShardedTSDFMap:
     Points are only needed on the rank that owns the frame (frame index % world size); other ranks may pass None.
     """
 
-    def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, local=None, group=None, **map_kwargs):
+    def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, local=None, group=None, comm=None, **map_kwargs):
         if local is None:
             from .tsdf import TSDFMap
 
@@ -151,7 +151,7 @@ class ShardedTSDFMap:
         self._native = hasattr(local, "attach_comm")
         self.comm = None
         if self._native:
-            self.comm = Comm(group) if self.world > 1 else None
+            self.comm = comm if comm is not None else (Comm(group) if self.world > 1 else None)   # (a Comm may serve several maps, one after the other)
             local.attach_comm(self.comm)
 
     def owner(self, frame: int) -> int:
