@@ -157,7 +157,8 @@ def main():
     # ---- the contract's line: cfg2, reset + insert per step ---------------------------------------------------------------
     # the timed map brackets only the update kernel with HIP events (the dispatch's own time stamps, on the stream it runs on)
     m = TSDFMap(res, trunc, time_update=True, update_mode=args.update_mode, max_points=args.points)
-    job = ShardedTSDFMap(res, trunc, local=m, comm=comm) if world > 1 else None
+    # (weak scaling: every rank integrates ALL of its own steps, so the map is not attached to the communicator -- an attached map
+    # integrates only every world-th insert; the exchange is called explicitly)
 
     def step(i):
         d_pts, pos, _ = scans[i % len(scans)]
@@ -168,7 +169,7 @@ def main():
         step(i)
     m.sync()
     if world > 1:  # warm the collective path once as well
-        job.merge_and_close()
+        m.merge_and_close(comm)
         m.reset()
         m.sync()
     m.stats()  # drop the warm-up's timings
@@ -179,7 +180,7 @@ def main():
         step(args.warmup + i)
     t_enqueued = time.perf_counter() - t0  # host side only: all steps are enqueued, the device is still working
     if world > 1:
-        job.merge_and_close()              # the exchange: every rank ends up with the merged submap
+        m.merge_and_close(comm)            # the exchange: every rank ends up with the merged submap
     m.sync()
     torch.cuda.synchronize()
     barrier()

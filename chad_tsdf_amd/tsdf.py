@@ -81,9 +81,10 @@ class TSDFMap:
         _lib.check(self._lib.chad_map_attach_comm(self._h, comm.handle if comm is not None else None), "TSDFMap.attach_comm")
         self._comm = comm   # must outlive the attachment
 
-    def merge_and_close(self):
-        """The exchange step (collective over the attached communicator): merge the ranks' active submaps, archive the result."""
-        _lib.check(self._lib.chad_map_merge_and_close(self._h, None), "TSDFMap.merge_and_close")
+    def merge_and_close(self, comm=None):
+        """The exchange step (collective over `comm`, default: the attached communicator): merge the ranks' active submaps,
+        archive the result on every rank."""
+        _lib.check(self._lib.chad_map_merge_and_close(self._h, comm.handle if comm is not None else None), "TSDFMap.merge_and_close")
 
     def note_pose(self, pos: np.ndarray):
         """An insert without points (pose bookkeeping of tsdf.cpp:46-61 only); pos: float32[3], C-contiguous.  The cheap path
