@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchad_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_CAPACITY, ERR_HIP = range(6)
-FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS, FLAG_DAG_ONLY, FLAG_TIME_KERNELS = 1, 2, 4, 8, 16, 32, 64
+FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS, FLAG_DAG_ONLY, FLAG_TIME_KERNELS, FLAG_MESH_FROM_DAG = 1, 2, 4, 8, 16, 32, 64, 128
+QUERY_LEAF, QUERY_TRILINEAR = 0, 1
 KERNEL_COUNT = 13
 DAG_NODE_LEVELS, DAG_CLUSTER_LEVEL = 20, 20
 UPDATE_AUTO, UPDATE_SCATTER, UPDATE_TILED = 0, 1, 2
@@ -60,6 +61,10 @@ class Stats(C.Structure):
         ("ms_oct_upd", C.c_float),
         ("ms_total", C.c_float),
     ]
+
+
+class Leaf(C.Structure):   # chad_leaf
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("signed_distance", C.c_float), ("weight", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class KernelTimes(C.Structure):
@@ -110,6 +115,18 @@ SYMBOLS = {
     "chad_map_dag_stats": (_i32, [_vp, C.POINTER(DagStats)]),
     "chad_map_dag_leaves": (_i32, [_vp, _i32, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_export_clusters": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "chad_map_iter_begin": (_i32, [_vp, _i32, C.POINTER(_vp)]),
+    "chad_iter_destroy": (None, [_vp]),
+    "chad_iter_valid": (_i32, [_vp]),
+    "chad_iter_seek": (_i32, [_vp, _i32]),
+    "chad_iter_advance": (_i32, [_vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "chad_iter_get": (_i32, [_vp, C.POINTER(Leaf)]),
+    "chad_iter_read": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "chad_map_query_sd": (_i32, [_vp, _vp, _sz, _i32, _vp, _vp]),
+    "chad_map_query_sd_device": (_i32, [_vp, _vp, _sz, _i32, _vp, _vp]),
+    "chad_map_raycast": (_i32, [_vp, _vp, _vp, _sz, _f32, _vp]),
+    "chad_map_mesh": (_i32, [_vp, _i32, _vp, _sz, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "chad_map_save_mesh": (_i32, [_vp, _i32, C.c_char_p]),
     "chad_map_last_frame": (_i32, [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_walk_rays": (_i32, [_vp, _sz, _vp, _f32, _f32, _vp, _vp, _sz]),
     "chad_morton_codes": (_i32, [_vp, _sz, _f32, _vp]),

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "comm.hpp"
@@ -20,6 +21,8 @@
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
 #include "merge_kernels.hpp"
+#include "mesh_kernels.hpp"
+#include "query_kernels.hpp"
 #include "radix_sort.hpp"
 #include "tile_update.hpp"
 
@@ -140,6 +143,11 @@ struct chad_map {
     Dag dag;                                      // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps, built lazily (chad_map_finalize)
     std::vector<std::array<uint32_t, 2>> dag_roots;  // submap.hpp:108-109 of the closed submaps folded so far (a prefix of `closed`)
     float dag_ms_device = 0, dag_ms_host = 0;
+    uint64_t dag_generation = 0;                  // bumped when the DAG is thrown away (chad_map_reset): iterators of an older generation are dead
+    // the last mesh extracted (chad_map_mesh is called twice: sizes, then data)
+    int32_t mesh_submap = INT32_MIN;
+    std::vector<float> mesh_vertices;
+    std::vector<uint32_t> mesh_triangles;
     // Roll-over without a pipeline stall: the active table is swapped for an empty spare one of the same size and is
     // archived (counted, compacted into a dense closed submap, cleared) on the map's stream behind the frames, the host
     // part of it -- sizing the archive -- whenever the count has arrived.  At most one submap is closing at a time.
@@ -963,6 +971,8 @@ chad_status chad_map_reset(chad_map* m) {
     }
     m->dag = Dag();
     m->dag_roots.clear();
+    m->dag_generation++;
+    m->mesh_submap = INT32_MIN;
     m->positions.clear();
     // The clear itself is deferred to the stream of the next insert (right in front of its update), so that the next
     // frame's preparation does not queue behind it; anything else that looks at the map first carries it out (flush_pending_clear).
@@ -1429,6 +1439,255 @@ chad_status chad_map_export_clusters(chad_map* m, int32_t submap, uint64_t* keys
     if (tsdf_out) std::memcpy(tsdf_out, hc.tsdf.data(), size_t(nb) * 64);
     if (weights_out) std::memcpy(weights_out, hc.weight.data(), size_t(nb) * 64);
     return CHAD_OK;
+}
+
+
+// ---- read-back: leaf iterator over a closed submap's DAG (tsdf.hpp:120-161, tsdf.cpp:88-159) -----------------------------------
+struct chad_iter {
+    chad_map* map;
+    uint64_t generation;
+    DagCursor cursor;
+};
+
+chad_status chad_map_iter_begin(chad_map* m, int32_t submap, chad_iter** out) {
+    if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    DeviceGuard guard(m->device);
+    TRY(finalize_closed(m));
+    // tsdf.cpp:106-110: "chad::TSDFMap::begin() given faulty root address"
+    if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
+    chad_iter* it = new chad_iter{m, m->dag_generation, DagCursor{}};
+    it->cursor.open(m->dag, m->dag_roots[size_t(submap)][0], m->dag_roots[size_t(submap)][1]);
+    it->cursor.first();
+    *out = it;
+    return CHAD_OK;
+}
+
+void chad_iter_destroy(chad_iter* it) { delete it; }
+
+static bool iter_alive(const chad_iter* it) { return it && it->map && it->generation == it->map->dag_generation; }
+
+int32_t chad_iter_valid(const chad_iter* it) { return iter_alive(it) && it->cursor.valid ? 1 : 0; }
+
+chad_status chad_iter_seek(chad_iter* it, int32_t to_last) {
+    if (!iter_alive(it)) return fail(CHAD_ERR_INVALID_ARG, "dead iterator (the map was reset)");
+    if (to_last) it->cursor.last(); else it->cursor.first();
+    return CHAD_OK;
+}
+
+chad_status chad_iter_advance(chad_iter* it, int64_t n, int64_t* moved) {
+    if (!iter_alive(it)) return fail(CHAD_ERR_INVALID_ARG, "dead iterator (the map was reset)");
+    int64_t done = 0;
+    for (; done < (n < 0 ? -n : n) && it->cursor.valid; done++)
+        if (!(n < 0 ? it->cursor.prev() : it->cursor.next())) break;
+    if (moved) *moved = n < 0 ? -done : done;
+    return CHAD_OK;
+}
+
+static void leaf_of(const chad_iter* it, chad_leaf* out) {
+    const chad_map* m = it->map;
+    const uint64_t code = it->cursor.code();
+    // the leaf's position: its voxel's corner, vec3(decode(mc)) * res (octree.hpp:157, lvr2.cpp:78-79)
+    out->x = float(int(dag_compact21(code) - (1u << 20))) * m->res;
+    out->y = float(int(dag_compact21(code >> 1) - (1u << 20))) * m->res;
+    out->z = float(int(dag_compact21(code >> 2) - (1u << 20))) * m->res;
+    out->signed_distance = cluster_sd_of_bits(it->cursor.sd_bits(), m->trunc);
+    out->weight = it->cursor.weight_bits();
+    out->reserved = 0;
+}
+
+chad_status chad_iter_get(const chad_iter* it, chad_leaf* out) {
+    if (!iter_alive(it) || !out) return fail(CHAD_ERR_INVALID_ARG, "dead iterator or null output");
+    if (!it->cursor.valid) return fail(CHAD_ERR_INVALID_ARG, "iterator is past the end");
+    leaf_of(it, out);
+    return CHAD_OK;
+}
+
+chad_status chad_iter_read(chad_iter* it, chad_leaf* out, size_t capacity, size_t* count) {
+    if (!iter_alive(it) || !count || (capacity && !out)) return fail(CHAD_ERR_INVALID_ARG, "dead iterator or null argument");
+    size_t k = 0;
+    while (k < capacity && it->cursor.valid) {
+        leaf_of(it, &out[k++]);
+        it->cursor.next();
+    }
+    *count = k;
+    return CHAD_OK;
+}
+
+// ---- read-back: batched queries of the ACTIVE submap on the device (query_kernels.hpp) ---------------------------------------
+static chad_status query_ready(chad_map* m) {
+    TRY(flush_pending_clear(m));
+    return join_streams(m);   // the frames enqueued so far are part of what is asked about
+}
+
+chad_status chad_map_query_sd_device(chad_map* m, const float* xyz_device, size_t n, int32_t mode, float* sd_device, uint32_t* weight_device) {
+    if (!m || (n && (!xyz_device || !sd_device))) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (mode != CHAD_QUERY_LEAF && mode != CHAD_QUERY_TRILINEAR) return fail(CHAD_ERR_INVALID_ARG, "unknown query mode");
+    if (n >= (1ull << 32)) return fail(CHAD_ERR_INVALID_ARG, "too many query points");
+    DeviceGuard guard(m->device);
+    if (!n) return CHAD_OK;
+    TRY(query_ready(m));
+    hipLaunchKernelGGL(k_query_points, grid_for(n, 256, 4096), dim3(256), 0, m->stream, m->view, xyz_device, uint32_t(n), uint32_t(mode), m->res, m->recip, m->trunc, sd_device, weight_device);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHAD_OK;
+}
+
+chad_status chad_map_query_sd(chad_map* m, const float* xyz, size_t n, int32_t mode, float* sd, uint32_t* weight) {
+    if (!m || (n && (!xyz || !sd))) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    if (!n) return CHAD_OK;
+    DevBuf d_xyz, d_sd, d_w;
+    HIP_TRY(d_xyz.alloc(n * 12)); HIP_TRY(d_sd.alloc(n * 4)); HIP_TRY(d_w.alloc(n * 4));
+    HIP_TRY(hipMemcpy(d_xyz.p, xyz, n * 12, hipMemcpyHostToDevice));
+    TRY(chad_map_query_sd_device(m, d_xyz.as<float>(), n, mode, d_sd.as<float>(), d_w.as<uint32_t>()));
+    HIP_TRY(hipMemcpy(sd, d_sd.p, n * 4, hipMemcpyDeviceToHost));
+    if (weight) HIP_TRY(hipMemcpy(weight, d_w.p, n * 4, hipMemcpyDeviceToHost));
+    return CHAD_OK;
+}
+
+chad_status chad_map_raycast(chad_map* m, const float* origins, const float* directions, size_t n, float t_max, float* t_hit) {
+    if (!m || (n && (!origins || !directions || !t_hit))) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (n >= (1ull << 32) || !(t_max >= 0.0f)) return fail(CHAD_ERR_INVALID_ARG, "too many rays or negative range");
+    DeviceGuard guard(m->device);
+    if (!n) return CHAD_OK;
+    DevBuf d_o, d_d, d_t;
+    HIP_TRY(d_o.alloc(n * 12)); HIP_TRY(d_d.alloc(n * 12)); HIP_TRY(d_t.alloc(n * 4));
+    HIP_TRY(hipMemcpy(d_o.p, origins, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d.p, directions, n * 12, hipMemcpyHostToDevice));
+    TRY(query_ready(m));
+    hipLaunchKernelGGL(k_raycast, grid_for(n, 256, 4096), dim3(256), 0, m->stream, m->view, d_o.as<float>(), d_d.as<float>(), uint32_t(n), t_max, m->res, m->recip, m->trunc, d_t.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(t_hit, d_t.p, n * 4, hipMemcpyDeviceToHost));
+    return CHAD_OK;
+}
+
+// ---- mesh extraction (reference: TSDFMap::save -> lvr2.cpp:275-321) -----------------------------------
+namespace {
+
+// triangle soup -> indexed mesh: vertices welded by their bits (mesh_kernels.hpp: a grid edge's vertex comes out bit-identical in
+// every cell around it), triangles that lost a corner to the welding (a surface passing exactly through a grid point) dropped
+void weld_mesh(const std::vector<float>& soup, std::vector<float>& vertices, std::vector<uint32_t>& triangles) {
+    struct Key { uint32_t x, y, z; bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; } };
+    struct Hash { size_t operator()(const Key& k) const { return size_t(dag_mix((uint64_t(k.x) << 32 | k.y) ^ dag_mix(k.z))); } };
+    std::unordered_map<Key, uint32_t, Hash> index;
+    index.reserve(soup.size() / 9 + 16);
+    vertices.clear(); triangles.clear();
+    for (size_t t = 0; t + 9 <= soup.size(); t += 9) {
+        uint32_t v[3];
+        for (int c = 0; c < 3; c++) {
+            Key k;
+            float p[3] = {soup[t + 3 * c], soup[t + 3 * c + 1], soup[t + 3 * c + 2]};
+            for (float& f : p) if (f == 0.0f) f = 0.0f;   // -0 and +0 are the same place
+            std::memcpy(&k.x, &p[0], 4); std::memcpy(&k.y, &p[1], 4); std::memcpy(&k.z, &p[2], 4);
+            auto found = index.find(k);
+            if (found == index.end()) {
+                found = index.emplace(k, uint32_t(vertices.size() / 3)).first;
+                vertices.insert(vertices.end(), p, p + 3);
+            }
+            v[c] = found->second;
+        }
+        if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) continue;
+        triangles.insert(triangles.end(), v, v + 3);
+    }
+}
+
+// sorted block keys and per-voxel means (NaN = no leaf) of a submap on the device
+chad_status mesh_source(chad_map* m, int32_t submap, DevBuf& keys_sorted, DevBuf& means, uint32_t* blocks_out) {
+    const bool from_dag = submap >= 0 && ((m->flags & CHAD_FLAG_MESH_FROM_DAG) || (size_t(submap) < m->closed.size() && m->closed[size_t(submap)].released));
+    if (from_dag) {
+        // what the reference meshes (lvr2.cpp:30-90): the leaves read back through the DAG, signed distances de-quantised from 8 bits
+        TRY(finalize_closed(m));
+        if (size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
+        std::vector<uint64_t> keys;
+        std::vector<float> sd;
+        DagCursor c;
+        c.open(m->dag, m->dag_roots[size_t(submap)][0], m->dag_roots[size_t(submap)][1]);
+        for (bool ok = c.first(); ok; ok = c.next()) {
+            const uint64_t code = c.code();
+            if (keys.empty() || keys.back() != (code & kBlockMask)) { keys.push_back(code & kBlockMask); sd.resize(sd.size() + 64, std::nanf("")); }
+            sd[sd.size() - 64 + (code & 63u)] = cluster_sd_of_bits(c.sd_bits(), m->trunc);
+        }
+        *blocks_out = uint32_t(keys.size());
+        HIP_TRY(keys_sorted.alloc(keys.size() * 8)); HIP_TRY(means.alloc(sd.size() * 4));
+        if (!keys.empty()) {
+            HIP_TRY(hipMemcpy(keys_sorted.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(means.p, sd.data(), sd.size() * 4, hipMemcpyHostToDevice));
+        }
+        return CHAD_OK;
+    }
+    uint32_t nb = 0;
+    const uint64_t* keys; const float* sum; const uint32_t* cnt;
+    TRY(select_submap(m, submap, &nb, &keys, &sum, &cnt));
+    *blocks_out = nb;
+    HIP_TRY(keys_sorted.alloc(size_t(nb) * 8)); HIP_TRY(means.alloc(size_t(nb) * 256));
+    if (!nb) return CHAD_OK;
+    TRY(ensure_aux_sort(m, nb));
+    RadixSortSignals sig;
+    sig.fault = m->d_overflow;
+    hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
+    radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
+    hipLaunchKernelGGL(k_brick_means, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, keys_sorted.as<uint64_t>(), means.as<float>());
+    HIP_TRY(hipGetLastError());
+    return CHAD_OK;
+}
+
+chad_status extract_mesh(chad_map* m, int32_t submap) {
+    if (m->mesh_submap == submap && submap >= 0) return CHAD_OK;   // (a closed submap does not change; the active one does)
+    DevBuf keys, means;
+    uint32_t nb = 0;
+    TRY(mesh_source(m, submap, keys, means, &nb));
+    m->mesh_vertices.clear(); m->mesh_triangles.clear();
+    m->mesh_submap = submap;
+    if (!nb) return CHAD_OK;
+    DevBuf counts, d_total;
+    HIP_TRY(counts.alloc(size_t(nb) * 4)); HIP_TRY(d_total.alloc(4));
+    hipLaunchKernelGGL((k_mesh_bricks<false>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, m->res, counts.as<uint32_t>(), (float*)nullptr);
+    hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, m->stream, counts.as<uint32_t>(), nb, d_total.as<uint32_t>());
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_total.p, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (!total) return CHAD_OK;
+    DevBuf soup;
+    HIP_TRY(soup.alloc(size_t(total) * 36));
+    hipLaunchKernelGGL((k_mesh_bricks<true>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, m->res, counts.as<uint32_t>(), soup.as<float>());
+    HIP_TRY(hipGetLastError());
+    std::vector<float> host(size_t(total) * 9);
+    HIP_TRY(hipMemcpyAsync(host.data(), soup.p, host.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    weld_mesh(host, m->mesh_vertices, m->mesh_triangles);
+    return CHAD_OK;
+}
+
+}  // namespace
+
+chad_status chad_map_mesh(chad_map* m, int32_t submap, float* vertices, size_t vertex_capacity, uint32_t* triangles, size_t triangle_capacity, size_t* vertex_count, size_t* triangle_count) {
+    if (!m || !vertex_count || !triangle_count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(extract_mesh(m, submap));
+    *vertex_count = m->mesh_vertices.size() / 3; *triangle_count = m->mesh_triangles.size() / 3;
+    if (vertices && vertex_capacity >= *vertex_count) std::memcpy(vertices, m->mesh_vertices.data(), m->mesh_vertices.size() * 4);
+    if (triangles && triangle_capacity >= *triangle_count) std::memcpy(triangles, m->mesh_triangles.data(), m->mesh_triangles.size() * 4);
+    if ((vertices && vertex_capacity < *vertex_count) || (triangles && triangle_capacity < *triangle_count)) return fail(CHAD_ERR_INVALID_ARG, "mesh buffers too small");
+    return CHAD_OK;
+}
+
+chad_status chad_map_save_mesh(chad_map* m, int32_t submap, const char* filename) {
+    if (!m || !filename) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(extract_mesh(m, submap));
+    std::FILE* f = std::fopen(filename, "wb");
+    if (!f) return fail(CHAD_ERR_INVALID_ARG, std::string("cannot open ") + filename);
+    const size_t nv = m->mesh_vertices.size() / 3, nt = m->mesh_triangles.size() / 3;
+    std::fprintf(f, "ply\nformat binary_little_endian 1.0\ncomment chad_tsdf mesh: sd = 0 surface of submap %d, res %g trunc %g\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\n"
+                    "element face %zu\nproperty list uchar uint vertex_indices\nend_header\n", submap, double(m->res), double(m->trunc), nv, nt);
+    bool ok = nv == 0 || std::fwrite(m->mesh_vertices.data(), 12, nv, f) == nv;
+    std::vector<unsigned char> faces(nt * 13);
+    for (size_t t = 0; t < nt; t++) { faces[13 * t] = 3; std::memcpy(&faces[13 * t + 1], &m->mesh_triangles[3 * t], 12); }
+    ok = ok && (nt == 0 || std::fwrite(faces.data(), 13, nt, f) == nt);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? CHAD_OK : fail(CHAD_ERR_INVALID_ARG, std::string("short write to ") + filename);
 }
 
 chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, float* normals, size_t capacity, size_t* count) {

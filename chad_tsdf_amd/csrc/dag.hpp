@@ -195,6 +195,100 @@ inline void dag_walk(const Dag& dag, uint32_t root, Leaf&& leaf) {
     }
 }
 
+// A position in one submap's DAG: the reference's (commented-out) TSDFMap::iterator -- tsdf.hpp:125-151: _node_paths, _node_addrs,
+// _leaf_cluster_p, _mc_raw; begin() at tsdf.cpp:104-146 walks to the first leaf exactly like first() below -- completed with the
+// operations the reference leaves as TODO (operator++ / -- / + / -, end()).  Leaves are visited in ascending Morton order.  The
+// signed-distance tree and the weight tree of a submap have the same shape (submap.hpp:70-99 adds them side by side), so one path
+// serves both.
+struct DagCursor {
+    const Dag* dag = nullptr;
+    uint32_t addr_t[kDagDepth] = {}, addr_w[kDagDepth] = {};   // node addresses on the path, per tree
+    int8_t child[kDagDepth] = {};                              // child taken at each depth
+    uint32_t cluster_t = 0, cluster_w = 0;                     // addresses of the current leaf clusters
+    int32_t leaf = 0;                                          // leaf inside the cluster, 0..7
+    bool valid = false;
+
+    void open(const Dag& d, uint32_t root_tsdf, uint32_t root_weight) {
+        dag = &d; addr_t[0] = root_tsdf; addr_w[0] = root_weight; valid = false;
+    }
+    uint64_t code() const {   // tsdf.cpp:138-143 / lvr2.cpp:62-67: three bits per level, root first; the leaf's bits last
+        uint64_t c = uint64_t(leaf);
+        for (uint32_t k = 0; k < kDagDepth; k++) c |= uint64_t(child[k]) << (60u - 3u * k);
+        return c;
+    }
+    uint8_t sd_bits() const { return uint8_t(dag->clusters.raw[cluster_t] >> (8 * leaf)); }
+    uint8_t weight_bits() const { return uint8_t(dag->clusters.raw[cluster_w] >> (8 * leaf)); }
+
+    bool first() { return valid = descend(0, +1) && settle(+1); }
+    bool last() { return valid = descend(0, -1) && settle(-1); }
+    bool next() { return step(+1); }
+    bool prev() { return step(-1); }
+
+private:
+    uint32_t mask_at(uint32_t depth) const { return dag->nodes[depth].raw[addr_t[depth]] & 0xffu; }
+    uint32_t child_addr(const uint32_t* addr, uint32_t depth, uint32_t c) const {   // levels.hpp:142-156
+        const std::vector<uint32_t>& raw = dag->nodes[depth].raw;
+        const uint32_t mask = raw[addr[depth]];
+        return raw[addr[depth] + 1 + uint32_t(__builtin_popcount(mask & ((1u << c) - 1u)))];
+    }
+    // lowest (dir > 0) / highest (dir < 0) set bit of `mask` strictly beyond position `from` (-1 .. 8) in direction dir; -1 if none
+    static int pick(uint32_t mask, int from, int dir) {
+        mask &= 0xffu;
+        if (dir > 0) { const uint32_t m = from < 0 ? mask : (from >= 7 ? 0u : mask & (0xffu << (from + 1))); return m ? __builtin_ctz(m) : -1; }
+        const uint32_t m = from > 7 ? mask : (from <= 0 ? 0u : mask & ((1u << from) - 1u));
+        return m ? 31 - __builtin_clz(m) : -1;
+    }
+    // from the node at `depth` (its address set) down to a leaf cluster, always taking the first child in direction dir
+    bool descend(uint32_t depth, int dir) {
+        for (uint32_t d = depth; d < kDagDepth; d++) {
+            const int c = pick(mask_at(d), dir > 0 ? -1 : 8, dir);
+            if (c < 0) return false;   // only an empty submap's childless root (submap.hpp:29-44)
+            child[d] = int8_t(c);
+            const uint32_t at = child_addr(addr_t, d, uint32_t(c)), aw = child_addr(addr_w, d, uint32_t(c));
+            if (d + 1 < kDagDepth) { addr_t[d + 1] = at; addr_w[d + 1] = aw; }
+            else { cluster_t = at; cluster_w = aw; }
+        }
+        leaf = dir > 0 ? -1 : 8;
+        return true;
+    }
+    // move `leaf` to the next stored leaf of the current cluster in direction dir (0xff = no leaf, cluster.hpp:28-31)
+    bool settle(int dir) {
+        const uint64_t word = dag->clusters.raw[cluster_t];
+        for (int i = leaf + dir; i >= 0 && i < 8; i += dir)
+            if ((uint32_t(word >> (8 * i)) & 0xffu) != 0xffu) { leaf = i; return true; }
+        return false;
+    }
+    bool step(int dir) {
+        if (!valid) return false;
+        if (settle(dir)) return true;
+        // leave the cluster: climb to the deepest node with a further child in that direction, descend again from there
+        for (;;) {
+            int d = int(kDagDepth) - 1, c = -1;
+            for (; d >= 0; d--) { c = pick(mask_at(uint32_t(d)), child[d], dir); if (c >= 0) break; }
+            if (d < 0) return valid = false;   // past the last (first) leaf
+            child[d] = int8_t(c);
+            const uint32_t at = child_addr(addr_t, uint32_t(d), uint32_t(c)), aw = child_addr(addr_w, uint32_t(d), uint32_t(c));
+            if (uint32_t(d) + 1 < kDagDepth) {
+                addr_t[d + 1] = at; addr_w[d + 1] = aw;
+                if (!descend(uint32_t(d) + 1, dir)) return valid = false;   // (a stored node always has a child)
+            } else { cluster_t = at; cluster_w = aw; leaf = dir > 0 ? -1 : 8; }
+            if (settle(dir)) return true;
+            // (a stored cluster always holds a leaf -- dag_add_submap skips empty octets; if not, simply go on from here)
+        }
+    }
+};
+
+// one axis of MortonCode::decode (morton.hpp:29-37; libmorton's morton3D_64_decode): every third bit, compacted
+inline uint32_t dag_compact21(uint64_t v) {
+    v &= 0x1249249249249249ull;
+    v = (v | (v >> 2)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v >> 4)) & 0x100f00f00f00f00full;
+    v = (v | (v >> 8)) & 0x001f0000ff0000ffull;
+    v = (v | (v >> 16)) & 0x001f00000000ffffull;
+    v = (v | (v >> 32)) & 0x1fffffull;
+    return uint32_t(v);
+}
+
 // cluster.hpp:33-52
 inline float cluster_sd_of_bits(uint8_t bits, float trunc) {
     float sd = float(bits) - 127.0f;

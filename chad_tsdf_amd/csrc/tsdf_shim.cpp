@@ -50,33 +50,55 @@ TSDFMap::Leaves TSDFMap::leaves(int submap) const {
 }
 
 void TSDFMap::save(const std::string& filename) {
-    // tsdf.cpp:78-85: the active submap is closed if it holds a pose, then the FIRST submap is written.
+    // tsdf.cpp:78-85: the active submap is closed if it holds a pose, then the FIRST submap is reconstructed and written.
     check(chad_map_close_submap(_impl), "chad::TSDFMap::save");
     check(chad_map_finalize(_impl), "chad::TSDFMap::save");  // Submap::finalize of every submap closed so far (tsdf.cpp:53,79)
     if (closed_submaps() == 0) throw std::runtime_error("chad::TSDFMap::save: nothing was inserted");
-    const Leaves first = leaves(0);
-    std::FILE* f = std::fopen(filename.c_str(), "wb");
-    if (!f) throw std::runtime_error("chad::TSDFMap::save: cannot open " + filename);
-    // binary PLY: one vertex per voxel at its lower corner (the point the reference measures from, octree.hpp:157)
-    std::fprintf(f, "ply\nformat binary_little_endian 1.0\ncomment chad_tsdf voxels res %g trunc %g\nelement vertex %zu\n"
-                    "property float x\nproperty float y\nproperty float z\nproperty float signed_distance\nproperty uint weight\nend_header\n",
-                 double(_sdf_res), double(_sdf_trunc), first.code.size());
-    auto compact = [](uint64_t v) {  // inverse of the 21-bit interleave (morton.hpp:29-37)
-        v &= 0x1249249249249249ull;
-        v = (v | (v >> 2)) & 0x10c30c30c30c30c3ull;
-        v = (v | (v >> 4)) & 0x100f00f00f00f00full;
-        v = (v | (v >> 8)) & 0x001f0000ff0000ffull;
-        v = (v | (v >> 16)) & 0x001f00000000ffffull;
-        v = (v | (v >> 32)) & 0x1fffffull;
-        return int32_t(uint32_t(v) - (1u << 20));
-    };
-    for (size_t i = 0; i < first.code.size(); i++) {
-        const uint64_t mc = first.code[i];
-        const float rec[4] = { float(compact(mc)) * _sdf_res, float(compact(mc >> 1)) * _sdf_res, float(compact(mc >> 2)) * _sdf_res, first.signed_distance[i] };
-        std::fwrite(rec, 4, 4, f);
-        std::fwrite(&first.weight[i], 4, 1, f);
-    }
-    std::fclose(f);
+    check(chad_map_save_mesh(_impl, 0, filename.c_str()), "chad::TSDFMap::save");   // detail::reconstruct(*_submaps.front(), ...), tsdf.cpp:85
 }
+
+// ---- the iterator the reference sketches (tsdf.hpp:120-161, tsdf.cpp:88-159) ----
+TSDFMap::iterator::iterator(chad_iter* it) : _it(it) {}
+TSDFMap::iterator::iterator(iterator&& other) noexcept : _it(other._it) { other._it = nullptr; }
+TSDFMap::iterator& TSDFMap::iterator::operator=(iterator&& other) noexcept {
+    if (this != &other) { chad_iter_destroy(_it); _it = other._it; other._it = nullptr; }
+    return *this;
+}
+TSDFMap::iterator::~iterator() { chad_iter_destroy(_it); }
+bool TSDFMap::iterator::valid() const { return _it && chad_iter_valid(_it) != 0; }
+TSDFMap::iterator& TSDFMap::iterator::operator++() { check(chad_iter_advance(_it, 1, nullptr), "chad::TSDFMap::iterator++"); return *this; }
+TSDFMap::iterator& TSDFMap::iterator::operator--() { check(chad_iter_advance(_it, -1, nullptr), "chad::TSDFMap::iterator--"); return *this; }
+TSDFMap::iterator& TSDFMap::iterator::operator+=(int64_t n) { check(chad_iter_advance(_it, n, nullptr), "chad::TSDFMap::iterator+="); return *this; }
+TSDFMap::iterator& TSDFMap::iterator::operator-=(int64_t n) { check(chad_iter_advance(_it, -n, nullptr), "chad::TSDFMap::iterator-="); return *this; }
+TSDFMap::Leaf TSDFMap::iterator::operator*() const {
+    chad_leaf l{};
+    check(chad_iter_get(_it, &l), "chad::TSDFMap::iterator*");
+    return Leaf{{l.x, l.y, l.z}, l.signed_distance, l.weight};
+}
+TSDFMap::iterator TSDFMap::begin(uint32_t submap) const {
+    chad_iter* it = nullptr;
+    check(chad_map_iter_begin(_impl, int32_t(submap), &it), "chad::TSDFMap::begin");   // throws on a faulty submap, as tsdf.cpp:106-110 does on a faulty root
+    return iterator(it);
+}
+TSDFMap::iterator TSDFMap::last(uint32_t submap) const {
+    iterator it = begin(submap);
+    check(chad_iter_seek(it._it, 1), "chad::TSDFMap::last");
+    return it;
+}
+
+std::vector<float> TSDFMap::signed_distance_at(const std::vector<std::array<float, 3>>& points, bool trilinear) const {
+    std::vector<float> sd(points.size());
+    check(chad_map_query_sd(_impl, points.empty() ? nullptr : points.front().data(), points.size(), trilinear ? CHAD_QUERY_TRILINEAR : CHAD_QUERY_LEAF, sd.data(), nullptr),
+          "chad::TSDFMap::signed_distance_at");
+    return sd;
+}
+std::vector<float> TSDFMap::raycast(const std::vector<std::array<float, 3>>& origins, const std::vector<std::array<float, 3>>& directions, float max_range) const {
+    if (origins.size() != directions.size()) throw std::runtime_error("chad::TSDFMap::raycast: origins and directions differ in size");
+    std::vector<float> t(origins.size());
+    check(chad_map_raycast(_impl, origins.empty() ? nullptr : origins.front().data(), directions.empty() ? nullptr : directions.front().data(), origins.size(), max_range, t.data()),
+          "chad::TSDFMap::raycast");
+    return t;
+}
+void TSDFMap::attach(chad_comm* comm) { check(chad_map_attach_comm(_impl, comm), "chad::TSDFMap::attach"); }
 
 }  // namespace chad

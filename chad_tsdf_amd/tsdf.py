@@ -22,7 +22,7 @@ def _np_f32(a, shape_last=3):
 class TSDFMap:
     def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, device: int = -1, max_blocks: int = 0,
                  max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, time_update: bool = False, fixed_capacity: bool = False, update_mode: int = 0,
-                 dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False):
+                 dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False, mesh_from_dag: bool = False):
         self._lib = _lib.load()
         self._sdf_res = float(sdf_res)
         self._sdf_trunc = float(sdf_trunc)
@@ -32,7 +32,7 @@ class TSDFMap:
         opt.max_blocks = max_blocks
         opt.max_points = max_points
         opt.stream = stream or None
-        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0)
+        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.FLAG_MESH_FROM_DAG if mesh_from_dag else 0)
         opt.update_mode = update_mode
         handle = C.c_void_p()
         _lib.check(self._lib.chad_map_create(sdf_res, sdf_trunc, C.byref(opt), C.byref(handle)), "TSDFMap")
@@ -101,20 +101,50 @@ class TSDFMap:
         return self._yes.value != 0
 
     def save(self, filename: str):
-        """TSDFMap::save -- tsdf.cpp:76-86: close the active submap, write the FIRST submap (as PLY voxels here)."""
+        """TSDFMap::save -- tsdf.cpp:76-86: close the active submap, reconstruct the FIRST submap and write the mesh (binary PLY)."""
         self.close_submap()
         self.finalize()  # Submap::finalize of every submap closed so far (tsdf.cpp:53,79)
         if self.closed_submaps == 0:
             raise RuntimeError("TSDFMap.save: nothing was inserted")
-        mc, sd, w = self.export_leaves(0)
-        xyz = decode_morton(mc).astype(np.float32) * np.float32(self._sdf_res)
-        with open(filename, "wb") as f:
-            f.write((f"ply\nformat binary_little_endian 1.0\ncomment chad_tsdf voxels res {self._sdf_res:g} trunc {self._sdf_trunc:g}\n"
-                     f"element vertex {len(mc)}\nproperty float x\nproperty float y\nproperty float z\n"
-                     "property float signed_distance\nproperty uint weight\nend_header\n").encode())
-            rec = np.empty(len(mc), dtype=[("p", "<f4", 3), ("sd", "<f4"), ("w", "<u4")])
-            rec["p"], rec["sd"], rec["w"] = xyz, sd, w
-            f.write(rec.tobytes())
+        _lib.check(self._lib.chad_map_save_mesh(self._h, 0, filename.encode()), "TSDFMap.save")
+
+    # ---- the read-back API the reference sketches (tsdf.hpp:120-161) ---------------------------------------
+    def iter_leaves(self, submap: int, chunk: int = 1 << 16):
+        """Leaves of a closed submap in ascending Morton order, read through the DAG: yields structured arrays with fields
+        x, y, z, signed_distance, weight (chad_leaf), `chunk` leaves at a time."""
+        it = LeafIterator(self, submap)
+        try:
+            while it.valid:
+                yield it.read(chunk)
+        finally:
+            it.close()
+
+    def query_sd(self, points, trilinear: bool = True):
+        """(sd f32 [n], weight u32 [n]) of the ACTIVE submap at the given points (numpy, host): the containing voxel's leaf or the
+        trilinear interpolation of the eight leaves around the point; NaN / 0 where a leaf is missing."""
+        pts = _np_f32(points)
+        sd = np.empty(pts.shape[0], dtype=np.float32)
+        w = np.empty(pts.shape[0], dtype=np.uint32)
+        _lib.check(self._lib.chad_map_query_sd(self._h, pts.ctypes.data, pts.shape[0], _lib.QUERY_TRILINEAR if trilinear else _lib.QUERY_LEAF, sd.ctypes.data, w.ctypes.data),
+                   "TSDFMap.query_sd")
+        return sd, w
+
+    def raycast(self, origins, directions, max_range: float):
+        """Distance along each ray (unit directions) to the first sd = 0 crossing of the active submap, NaN if none within max_range."""
+        o, d = _np_f32(origins), _np_f32(directions)
+        assert o.shape == d.shape
+        t = np.empty(o.shape[0], dtype=np.float32)
+        _lib.check(self._lib.chad_map_raycast(self._h, o.ctypes.data, d.ctypes.data, o.shape[0], max_range, t.ctypes.data), "TSDFMap.raycast")
+        return t
+
+    def mesh(self, submap: int = 0):
+        """(vertices f32 [V,3], triangles u32 [T,3]) of the sd = 0 surface of a submap (closed: >= 0; active: -1)."""
+        nv, nt = C.c_size_t(), C.c_size_t()
+        _lib.check(self._lib.chad_map_mesh(self._h, submap, None, 0, None, 0, C.byref(nv), C.byref(nt)), "TSDFMap.mesh")
+        v = np.empty((nv.value, 3), dtype=np.float32)
+        t = np.empty((nt.value, 3), dtype=np.uint32)
+        _lib.check(self._lib.chad_map_mesh(self._h, submap, v.ctypes.data, nv.value, t.ctypes.data, nt.value, C.byref(nv), C.byref(nt)), "TSDFMap.mesh")
+        return v, t
 
     # ---- extensions ---------------------------------------------------------------------------------
     def sync(self):
@@ -234,6 +264,48 @@ class TSDFMap:
         _lib.check(self._lib.chad_map_export_clusters(self._h, submap, keys.ctypes.data, tsdf.ctypes.data, wts.ctypes.data if weights else None, b.value, C.byref(b)),
                    "TSDFMap.export_clusters")
         return keys, tsdf, wts
+
+
+LEAF_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("signed_distance", "<f4"), ("weight", "<u4"), ("reserved", "<u4")])
+
+
+class LeafIterator:
+    """chad::TSDFMap::iterator (tsdf.hpp:126-151): a position among the leaves of one closed submap."""
+
+    def __init__(self, tsdf_map: TSDFMap, submap: int):
+        self._lib = tsdf_map._lib
+        self._h = C.c_void_p()
+        _lib.check(self._lib.chad_map_iter_begin(tsdf_map._h, submap, C.byref(self._h)), "LeafIterator")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.chad_iter_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def valid(self) -> bool:
+        return bool(self._lib.chad_iter_valid(self._h))
+
+    def seek(self, last: bool = False):
+        _lib.check(self._lib.chad_iter_seek(self._h, int(last)), "LeafIterator.seek")
+
+    def advance(self, n: int = 1) -> int:
+        moved = C.c_int64()
+        _lib.check(self._lib.chad_iter_advance(self._h, n, C.byref(moved)), "LeafIterator.advance")
+        return moved.value
+
+    def get(self):
+        leaf = _lib.Leaf()
+        _lib.check(self._lib.chad_iter_get(self._h, C.byref(leaf)), "LeafIterator.get")
+        return (leaf.x, leaf.y, leaf.z), leaf.signed_distance, leaf.weight
+
+    def read(self, capacity: int) -> np.ndarray:
+        out = np.empty(capacity, dtype=LEAF_DTYPE)
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_iter_read(self._h, out.ctypes.data, capacity, C.byref(n)), "LeafIterator.read")
+        return out[: n.value]
 
 
 # ---- stage entry points (parity tests call the device through these) ---------------------------------

@@ -8,9 +8,12 @@
 //     insert() on unallocated members, tsdf.hpp:31-44 vs tsdf.cpp:27-31);
 //   * failures (no GPU, out of memory, capacity) throw std::runtime_error, as the reference does for mmap
 //     failures (virtual_array.cpp:16-20); nothing is printed unless CHAD_VERBOSE=1 is set in the environment;
-//   * save() writes the first submap's voxels as a PLY point list (mesh extraction via LVR2 is out of scope);
-//   * extension: leaves() reads back (code, signed distance, weight) triples -- the reference's iterator API is
-//     commented out (tsdf.hpp:120-161).
+//   * save() reconstructs the first submap on the GPU (the reference's cell grid, lvr2.cpp:15-133, triangulated by marching
+//     tetrahedra) and writes a triangle mesh as binary PLY; LVR2 itself is not used;
+//   * the read-back API the reference sketches and leaves commented out (tsdf.hpp:120-161) exists: TSDFMap::iterator over a
+//     closed submap's leaves (position, signed distance, weight -- no Morton codes), batched signed-distance queries and a
+//     raycast on the active submap;
+//   * extensions: leaves() bulk read-back, attach() for the frame-sharded multi-GPU map (chad_hip.h, "Multi-GPU").
 #pragma once
 #include <array>
 #include <cstddef>
@@ -27,7 +30,9 @@
 #   define CHAD_HAS_EIGEN 1
 #endif
 
-struct chad_map;  // C ABI handle (chad_hip.h)
+struct chad_map;   // C ABI handles (chad_hip.h)
+struct chad_iter;
+struct chad_comm;
 
 namespace chad {
 
@@ -90,7 +95,40 @@ namespace chad {
         // tsdf.hpp:118 -- closes the active submap like the reference and writes the FIRST submap to disk
         void save(const std::string& filename);
 
+        // ---- the read-back API of tsdf.hpp:120-161 (commented out / TODO in the reference) ----
+        // what an iterator gives the user (tsdf.hpp:121-124): the leaf's real position, the data written there, no Morton codes
+        struct Leaf { std::array<float, 3> position; float signed_distance; uint32_t weight; };
+        // leaves of one CLOSED submap in ascending Morton order, read through the DAG (tsdf.hpp:126-151; begin() = tsdf.cpp:104-146)
+        class iterator {
+        public:
+            iterator(const iterator&) = delete;
+            iterator& operator=(const iterator&) = delete;
+            iterator(iterator&& other) noexcept;
+            iterator& operator=(iterator&& other) noexcept;
+            ~iterator();
+            bool valid() const;                 // false once moved past either end (what comparing with end() would tell)
+            explicit operator bool() const { return valid(); }
+            iterator& operator++();             // tsdf.hpp:137-140 (TODO in the reference)
+            iterator& operator--();
+            iterator& operator+=(int64_t n);
+            iterator& operator-=(int64_t n);
+            Leaf operator*() const;
+        private:
+            friend class TSDFMap;
+            explicit iterator(chad_iter* it);
+            chad_iter* _it = nullptr;
+        };
+        iterator begin(uint32_t submap) const;  // on the submap's first leaf (the reference passes the submap's root address)
+        iterator last(uint32_t submap) const;   // on its last leaf (tsdf.cpp:148-153)
+        // signed distance of the ACTIVE submap at arbitrary points: the containing voxel's leaf, or trilinear between the eight
+        // leaves around the point; NaN where nothing was observed
+        std::vector<float> signed_distance_at(const std::vector<std::array<float, 3>>& points, bool trilinear = true) const;
+        // "raycast ... + physics hit" (tsdf.hpp:157): distance along each ray to the surface (sd = 0 crossing), NaN if none within max_range
+        std::vector<float> raycast(const std::vector<std::array<float, 3>>& origins, const std::vector<std::array<float, 3>>& unit_directions, float max_range) const;
+
         // ---- extensions (not in the reference) ----
+        // frame-sharded multi-GPU map: every rank calls the same inserts; see chad_hip.h, chad_map_attach_comm
+        void attach(chad_comm* comm);
         struct Leaves { std::vector<uint64_t> code; std::vector<float> signed_distance; std::vector<uint32_t> weight; };
         // voxels of the active submap (submap < 0) or of a closed one, sorted by Morton code
         Leaves leaves(int submap = -1) const;

@@ -59,6 +59,8 @@ enum {
                                             std::max<uint8_t>(w, 255) at submap.hpp:93 makes every weight byte 0xff */
     CHAD_FLAG_TIME_KERNELS = 64u, /* every kernel of an insert is timed on its own (begin / end time stamps of its dispatch, no event
                                      records in between); frames run one after the other.  Read with chad_map_kernel_times */
+    CHAD_FLAG_MESH_FROM_DAG = 128u, /* chad_map_mesh / save read a closed submap's leaves back through the DAG (8-bit signed distances), as the
+                                       reference's mesh extraction does (lvr2.cpp:30-90); default: from the exact means of the dense archive */
     CHAD_FLAG_DAG_ONLY = 32u /* a closed submap is folded into the DAG as soon as its archive is complete and its dense brick copy
                                 is released: device memory then holds the active submap only (long trajectories), as the reference
                                 keeps nothing but the DAG of a closed submap (tsdf.cpp:53-54).  Closed submaps are then read back with
@@ -220,6 +222,52 @@ chad_status chad_map_dag_leaves(chad_map* map, int32_t submap, uint64_t* mc, flo
  * cluster words of octet o (bits 3..5 of the code) of block b, all ones where the octet holds no leaf.  Host pointers,
  * weights may be NULL; submap < 0: the active submap. */
 chad_status chad_map_export_clusters(chad_map* map, int32_t submap, uint64_t* keys, uint64_t* tsdf, uint64_t* weights, size_t capacity_blocks, size_t* blocks);
+
+/* ---- Read-back API.  The reference sketches it and leaves it commented out / TODO: a leaf iterator per
+ * submap that exposes "real floating point position per leaf" and "the data written there (signed distance, weight)", never
+ * Morton codes (tsdf.hpp:120-161), begin() walking the DAG to its first leaf (tsdf.cpp:104-146), operator++ / -- / + / - and
+ * end() as TODO; plus "raycast to retrieve leaves along it + physics hit" (tsdf.hpp:156-158). */
+typedef struct chad_leaf {
+    float x, y, z;         /* position of the leaf: its voxel's corner, vec3(MortonCode::decode()) * sdf_res (octree.hpp:157, lvr2.cpp:78-79) */
+    float signed_distance; /* from the DAG: de-quantised from its byte (cluster.hpp:33-52) */
+    uint32_t weight;       /* the DAG's weight byte: 255 as the reference stores it (Q6, submap.hpp:93), min(w, 254) with CHAD_FLAG_DAG_SATURATE_WEIGHTS */
+    uint32_t reserved;
+} chad_leaf;
+typedef struct chad_iter chad_iter;
+/* TSDFMap::begin(root_addr) (tsdf.cpp:104-146) for closed submap `submap`: an iterator on its first leaf; leaves come in ascending
+ * Morton order, the order of the reference's own DAG traversals.  Folds pending submaps into the DAG first (chad_map_finalize).
+ * An iterator stays usable while further submaps are closed; chad_map_reset / destroy kill it (calls then fail / report invalid). */
+chad_status chad_map_iter_begin(chad_map* map, int32_t submap, chad_iter** out);
+void chad_iter_destroy(chad_iter* it);
+int32_t chad_iter_valid(const chad_iter* it);                             /* 0 once moved past either end (the reference's end()) */
+chad_status chad_iter_seek(chad_iter* it, int32_t to_last);               /* first leaf (0) or last leaf (1: tsdf.cpp:148-153 "walk to the last leaf node") */
+chad_status chad_iter_advance(chad_iter* it, int64_t n, int64_t* moved);  /* operator++ (1), -- (-1), + / - (n); *moved = leaves actually moved (may be NULL) */
+chad_status chad_iter_get(const chad_iter* it, chad_leaf* out);
+chad_status chad_iter_read(chad_iter* it, chad_leaf* out, size_t capacity, size_t* count);   /* bulk: up to `capacity` leaves from the current one on, advancing */
+
+/* Batched queries of the ACTIVE submap, on the device (the frames enqueued so far are included).  mode CHAD_QUERY_LEAF: the leaf
+ * of the voxel containing each point -- Leaf::_signed_distance / _weight (octree.hpp:15), the exact mean as chad_map_export_leaves
+ * reports it; CHAD_QUERY_TRILINEAR: the trilinear interpolation of the eight leaves at the corners of the cell the point lies in
+ * (the cell of lvr2.cpp:93-113), weight = the smallest of the eight.  Where a leaf is missing: sd NaN, weight 0.
+ * weight may be NULL.  _device: all three pointers are device memory of the map's device. */
+enum { CHAD_QUERY_LEAF = 0, CHAD_QUERY_TRILINEAR = 1 };
+chad_status chad_map_query_sd(chad_map* map, const float* xyz, size_t n, int32_t mode, float* sd, uint32_t* weight);
+chad_status chad_map_query_sd_device(chad_map* map, const float* xyz_device, size_t n, int32_t mode, float* sd_device, uint32_t* weight_device);
+/* Raycast (tsdf.hpp:157): ray i = origins[i] + t * directions[i] (unit directions), marched in steps of sdf_res / 2 through the
+ * trilinear field of the active submap; t_hit[i] = distance of the first crossing from positive to non-positive signed distance in
+ * [0, t_max] (linear interpolation between the two samples), NaN if there is none.  Host pointers. */
+chad_status chad_map_raycast(chad_map* map, const float* origins, const float* directions, size_t n, float t_max, float* t_hit);
+
+/* ---- Mesh: what TSDFMap::save produces through LVR2 in the reference (tsdf.cpp:85 -> lvr2.cpp:275-321).
+ * The grid is the reference's (lvr2.cpp:15-133: a query point per leaf at its voxel corner, cells = cubes of eight query points,
+ * cells with a missing corner culled); the sd = 0 surface inside each cell is triangulated on the device by marching tetrahedra
+ * (six per cell) -- LVR2 is not available, so there is nothing to be bit-compatible with: this row is parity-unpinned.
+ * submap >= 0: a closed submap (the reference meshes _submaps.front()); < 0: the active one.  Vertices: 3 floats each, welded
+ * (every vertex once); triangles: 3 vertex indices each, oriented towards increasing signed distance (the sensor's side).
+ * Call with NULL buffers for the sizes. */
+chad_status chad_map_mesh(chad_map* map, int32_t submap, float* vertices, size_t vertex_capacity, uint32_t* triangles, size_t triangle_capacity,
+                          size_t* vertex_count, size_t* triangle_count);
+chad_status chad_map_save_mesh(chad_map* map, int32_t submap, const char* filename);   /* binary little-endian PLY */
 
 /* Stage read-back for parity tests: intermediates of the LAST insert, copied to host.
  * order[i]: input index of the i-th point in processing order; mc[i]: its Morton code; normals: 3 floats per point.

@@ -1,5 +1,6 @@
 // Test harness for the host half of finalize (chad_tsdf_amd/csrc/dag.hpp): a C face over chadhip::Dag so that the CPU
 // suite can drive it with cluster streams made from the oracle's leaves and compare the levels with the oracle's.
+#include <climits>
 #include "../../chad_tsdf_amd/csrc/dag.hpp"
 
 using namespace chadhip;
@@ -33,4 +34,19 @@ size_t dagcheck_walk(void* h, uint32_t root, uint64_t* mc, uint8_t* bits, size_t
     return k;
 }
 float dagcheck_sd_of_bits(uint8_t bits, float trunc) { return cluster_sd_of_bits(bits, trunc); }
+// DagCursor (the iterator of tsdf.hpp:126-151): script[i] > 0: that many next(), < 0: that many prev(), 0: first(), INT32_MIN: last().
+// After every script entry the current leaf (code, sd byte, weight byte; code ~0 when invalid) is appended to the outputs.
+size_t dagcheck_cursor_script(void* h, uint32_t root_tsdf, uint32_t root_weight, const int32_t* script, size_t steps, uint64_t* mc, uint8_t* sd_bits, uint8_t* w_bits) {
+    DagCursor c;
+    c.open(*static_cast<Dag*>(h), root_tsdf, root_weight);
+    for (size_t i = 0; i < steps; i++) {
+        if (script[i] == 0) c.first();
+        else if (script[i] == INT32_MIN) c.last();
+        else for (int32_t k = 0; k < (script[i] < 0 ? -script[i] : script[i]) && c.valid; k++) { if (script[i] > 0) c.next(); else c.prev(); }
+        mc[i] = c.valid ? c.code() : ~0ull;
+        sd_bits[i] = c.valid ? c.sd_bits() : 0;
+        w_bits[i] = c.valid ? c.weight_bits() : 0;
+    }
+    return steps;
+}
 }

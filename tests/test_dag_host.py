@@ -33,6 +33,8 @@ def dagcheck(tmp_path_factory):
     lib.dagcheck_level_counts.argtypes = [vp, u32, vp]
     lib.dagcheck_walk.restype = sz
     lib.dagcheck_walk.argtypes = [vp, u32, vp, vp, sz]
+    lib.dagcheck_cursor_script.restype = sz
+    lib.dagcheck_cursor_script.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp]
     lib.dagcheck_sd_of_bits.restype = C.c_float
     lib.dagcheck_sd_of_bits.argtypes = [C.c_uint8, C.c_float]
     return lib
@@ -65,6 +67,15 @@ class HostDag:
         bits = np.empty(n, dtype=np.uint8)
         k = self.lib.dagcheck_walk(self.h, root, mc.ctypes.data, bits.ctypes.data, n)
         return k, mc, bits
+
+
+def run_cursor(lib, host, roots, script):
+    script = np.asarray(script, dtype=np.int32)
+    mc = np.empty(len(script), dtype=np.uint64)
+    sd = np.empty(len(script), dtype=np.uint8)
+    w = np.empty(len(script), dtype=np.uint8)
+    lib.dagcheck_cursor_script(host.h, roots[0], roots[1], script.ctypes.data, len(script), mc.ctypes.data, sd.ctypes.data, w.ctypes.data)
+    return mc, sd, w
 
 
 def assert_same_dag(host, oracle):
@@ -133,3 +144,43 @@ def test_g8_golden_levels(dagcheck):
         for l in range(21):
             assert np.array_equal(host.level(l), g[f"s{k}_level{l}"]), (k, l)
             assert host.counts(l) == tuple(int(x) for x in g[f"s{k}_counts"][l])
+
+
+@pytest.mark.parametrize("saturate", [False, True])
+def test_cursor_is_the_iterator_the_reference_sketches(dagcheck, saturate):
+    """DagCursor (dag.hpp) = TSDFMap::iterator of tsdf.hpp:126-151: begin() lands on the first leaf like tsdf.cpp:104-146, ++ walks
+    every leaf in ascending Morton order (the order of dag_walk / lvr2.cpp:30-90), -- walks back, + / - jump, past either end it
+    turns invalid.  Two submaps share the DAG; each is walked from its own roots."""
+    NEG = -(2 ** 31)
+    host = HostDag(dagcheck)
+    subs = []
+    for n, seed in ((30_000, 5), (20_000, 6)):
+        o = pyoracle.OracleMap(0.05, 0.10)
+        pts, pos = synth.cfg2_frame(n, seed=seed)
+        o.insert(pts, pos)
+        mc, sd, w = o.export_leaves()
+        subs.append((mc, sd, w, host.add(*clusters_of_leaves(mc, sd, w, 0.10, saturate))))
+    for mc, sd, w, roots in subs:
+        n = len(mc)
+        k, wmc, wbits = host.walk(roots[0], n)
+        assert k == n
+        fwd = run_cursor(dagcheck, host, roots, [0] + [1] * n)                  # first, then n times ++: the last one runs off the end
+        assert np.array_equal(fwd[0][:n], mc) and np.array_equal(fwd[1][:n], wbits) and fwd[0][n] == np.uint64(2**64 - 1)
+        want_w = np.minimum(w, 254).astype(np.uint8) if saturate else np.full(n, 255, np.uint8)   # Q6: the reference stores 0xff (submap.hpp:93)
+        assert np.array_equal(fwd[2][:n], want_w)
+        back = run_cursor(dagcheck, host, roots, [NEG] + [-1] * n)              # last, then n times --
+        assert np.array_equal(back[0][:n], mc[::-1]) and back[0][n] == np.uint64(2**64 - 1)
+        rng = np.random.default_rng(3)
+        at, script, want = 0, [0], [0]
+        for _ in range(400):                                                     # random jumps that stay inside
+            step = int(rng.integers(-at, n - at))
+            if step == 0:
+                continue
+            at += step
+            script.append(step); want.append(at)
+        got = run_cursor(dagcheck, host, roots, script)
+        assert np.array_equal(got[0], mc[np.asarray(want)])
+    # an empty submap: begin() is invalid at once
+    e = np.zeros(0, dtype=np.uint64)
+    roots = host.add(e, e.reshape(0, 8), None)
+    assert run_cursor(dagcheck, host, roots, [0, NEG])[0].tolist() == [2**64 - 1] * 2
