@@ -663,15 +663,17 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         uint32_t pass_launches = 0;
         if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
         radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used, sig);
+        static const uint32_t big_block = std::getenv("CHAD_DEBUG_BIG_BLOCK") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_BLOCK"))) : kBigBlock;
+        static const uint32_t big_groups = std::getenv("CHAD_DEBUG_BIG_GROUPS") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_GROUPS"))) : kNormalBigGroups;
         m->sort_turn_used = true;   // (recorded by the hinted path only; an unrecorded event makes the wait a no-op)
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         if (times_kernels(m)) m->kev_launched[m->ktimed_end % chad_map::kKernelRing] |= ((1u << pass_launches) - 1u) << CHAD_KERNEL_SORT_PASS0;
         LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                     points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq);
+                     points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
-        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(256 * normal_waves_per_cu), dim3(64 * kNormalWavesPerBlock), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate);
+        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(256 * normal_waves_per_cu / kNormalWaves), dim3(64 * kNormalWaves), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, big_groups);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);

@@ -26,6 +26,9 @@ constexpr uint32_t kBigItem = 384;     // items longer than this are handed out 
 constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of this many counters (blockIdx % kWorkGroups)
 constexpr uint32_t kListStripes = 16; // stripes of the frame's block / work-item lists (FrameHeader::list_count)
 constexpr uint32_t kSparsePointsPerBlock = 6;  // frames with fewer points per block than this take the scatter form of the update
+constexpr uint32_t kBigBlock = 256;   // point blocks with more points than this get a workgroup of four waves in k_frame_normals (a wave works a
+                                      // block off in a chain proportional to its size: with one wave each, the few blocks next to the sensor -- a
+                                      // thousand points and more -- set the kernel's duration: 45 us, 25 us without them)
 
 // Per-frame scalars living in device memory (one per map; rewritten every insert).
 struct FrameHeader {
@@ -45,9 +48,11 @@ struct FrameHeader {
     // with one returning atomic per list: on ONE counter per list the 489 workgroups of a 1 M-point frame queued for
     // ~25 ns each, half of that kernel's 26 us.  Stripe s of a list owns entries [s * stride, (s + 1) * stride) of its array,
     // stride = capacity / kListStripes + kGatherChunk; long items fill a stripe's range from the front, short ones from the back.
-    uint32_t list_count[3][kListStripes * 16];
+    uint32_t list_count[4][kListStripes * 16];
 };
-enum { kListBlocks = 0, kListLongItems = 1, kListShortItems = 2 };
+// (the large point blocks -- more than kBigBlock points -- are listed a second time, from the back of the block list's stripes:
+// k_frame_normals gives each of them a whole workgroup)
+enum { kListBlocks = 0, kListLongItems = 1, kListShortItems = 2, kListBigBlocks = 3 };
 
 __device__ __forceinline__ uint32_t list_total(const FrameHeader* h, int list) {
     uint32_t n = 0;
@@ -95,7 +100,7 @@ struct FramePartial {
 __device__ __forceinline__ void frame_header_reset(FrameHeader* h) {
     for (uint32_t k = threadIdx.x; k < kUpdateStripes * 16; k += blockDim.x) h->n_updates[k] = 0;
     for (uint32_t k = threadIdx.x; k < kWorkGroups * 16; k += blockDim.x) h->work_cursor[k] = 0;
-    for (uint32_t k = threadIdx.x; k < 3 * kListStripes * 16; k += blockDim.x) (&h->list_count[0][0])[k] = 0;
+    for (uint32_t k = threadIdx.x; k < 4 * kListStripes * 16; k += blockDim.x) (&h->list_count[0][0])[k] = 0;
     if (threadIdx.x == 0) {
         h->vmin[0] = h->vmin[1] = h->vmin[2] = 0x7fffffff;
         h->vmax[0] = h->vmax[1] = h->vmax[2] = int(0x80000000);
@@ -298,6 +303,23 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
     }
 }
 
+// Length of the run of points of `block` (sort key >> 6) starting at `first`, capped at `limit`.
+// Two dependent loads instead of one per 64 points: lanes first probe the starts of the next 64 chunks of 64
+// points, then the points of the chunk where the run ends.  Wave-uniform result.
+__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ keys, uint32_t first, uint32_t limit, uint64_t block, uint32_t lane) {
+    uint32_t len = 0;
+    for (;;) {
+        const uint32_t probe = first + len + 64u * (lane + 1u);                 // first point of chunk lane+1
+        const uint64_t more = __ballot(probe < limit && (keys[probe] >> 6) == block);
+        const uint32_t full = more == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~more)) - 1u;  // chunks 1..full start inside the run
+        len += 64u * full;
+        if (full == 64u) continue;                                               // the run is longer than 4160 points: go on
+        const uint32_t i = first + len + lane;                                   // the chunk where the run ends
+        const uint64_t same = __ballot(i < limit && (keys[i] >> 6) == block);
+        return len + (same == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~same)) - 1u);
+    }
+}
+
 // Stage 3 (after the sort, which has carried the points along as float4 (x, y, z, input index)): list (a) the start of every point block (run of equal code >> 6) in seg_start[] for the
 // normal estimation and (b) the update work items (start, length, super-block code) in items[]: the super blocks (runs
 // of equal code >> 9) cut again at every kItemPoints-th point, so that no item is longer than kItemPoints.  A workgroup collects its entries in
@@ -309,14 +331,14 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                const float4* __restrict__ points0, const float4* __restrict__ points1,
                uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t list_stride,
-               uint32_t* __restrict__ consumed, uint32_t consumed_seq) {
+               uint32_t* __restrict__ consumed, uint32_t consumed_seq, uint32_t big_block) {
     constexpr uint32_t kWords = kGatherChunk / 32;
     // the sort is over (stream order), so the caller's raw points -- read by its first pass only -- are no longer needed: tell the
     // host (host-mapped word; chad_hip.hip, prepare_slot).  The sort's later launches store the same number earlier when there are any.
     if (consumed && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(consumed, consumed_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __shared__ uint32_t mark_bits[kWords], head_bits[kWords];  // bit k: point k of the chunk starts a work item / a point block
     __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
-    __shared__ uint32_t base_heads, n_big, n_small, base_big, base_small;
+    __shared__ uint32_t base_heads, n_big, n_small, base_big, base_small, trail_extra;
     __shared__ unsigned long long wave_mc[4], block_mc_min;
     // frame-wide smallest code from the keys kernel's partials
     {
@@ -381,6 +403,15 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             const uint32_t after = __shfl_down(first_mark, 1);   // first mark in a later word
             word_next[which][lane] = lane == 63u ? chunk_len : after;
             if (which && lane == 63u) base_heads = stripe * list_stride + (incl ? atomicAdd(&h->list_count[kListBlocks][stripe * 16u], incl) : 0u);
+        } else if (threadIdx.x < 192) {
+            // wave 2 meanwhile: the chunk's last point block may go on in the next chunks -- how far?  (two dependent loads; the
+            // normals kernel used to find out itself, one wave per such block, and could not tell the large blocks apart beforehand)
+            const uint32_t lane = threadIdx.x & 63u, word = head_bits[lane];
+            const int last_in_word = word ? int(lane * 32u) + 31 - __clz(int(word)) : -1;
+            const int last_head = wave_max(last_in_word);
+            uint32_t extra = 0;
+            if (last_head >= 0 && c + 1 < chunks) extra = run_length(keys, (c + 1u) * kGatherChunk, n, keys[c * kGatherChunk + uint32_t(last_head)] >> 6, lane);
+            if (lane == 0) trail_extra = extra;
         }
         __syncthreads();
         // the items of this chunk, long and short ones counted apart (order inside a class does not matter) ...
@@ -418,13 +449,16 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
                 items[at] = make_uint4(c * kGatherChunk + k, item_len[j], uint32_t(corner), uint32_t(corner >> 32));
             }
             if ((hword >> bit) & 1u) {
-                // a point block: (start, length | "holds the frame's last point" << 31).  A block that runs to the end of the
-                // chunk may go on in the next one: length 0 = "find out" (k_frame_normals probes), unless the frame ends here
+                // a point block: (start, length | "holds the frame's last point" << 31).  The chunk's last block may go on in the
+                // next chunks: wave 2 has measured how far
                 const uint32_t rank = word_rank[1][k >> 5] + __popc(hword & ((1u << bit) - 1u));
                 const uint32_t higher = bit == 31u ? 0u : hword >> (bit + 1u);
                 const uint32_t next = higher ? k + uint32_t(__ffs(int(higher))) : word_next[1][k >> 5];
-                const uint32_t len = next < chunk_len ? next - k : (c == chunks - 1 ? chunk_len - k : 0u);
-                segments[base_heads + rank] = make_uint2(c * kGatherChunk + k, len | ((code >> 6) == (mc_min >> 6) ? 0x80000000u : 0u));
+                const uint32_t len = next < chunk_len ? next - k : chunk_len - k + trail_extra;
+                const uint2 record = make_uint2(c * kGatherChunk + k, len | ((code >> 6) == (mc_min >> 6) ? 0x80000000u : 0u));
+                segments[base_heads + rank] = record;
+                if (len > big_block)   // listed again among the large blocks, from the back of the stripe (a hundred or so per frame)
+                    segments[(stripe + 1u) * list_stride - 1u - atomicAdd(&h->list_count[kListBigBlocks][stripe * 16u], 1u)] = record;
             }
         }
         __syncthreads();
@@ -539,103 +573,85 @@ __device__ __forceinline__ double team_sum_f64(double v) {
     return v;
 }
 
-// Length of the run of points of `block` (sort key >> 6) starting at `first`, capped at `limit`.
-// Two dependent loads instead of one per 64 points: lanes first probe the starts of the next 64 chunks of 64
-// points, then the points of the chunk where the run ends.  Wave-uniform result.
-__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ keys, uint32_t first, uint32_t limit, uint64_t block, uint32_t lane) {
-    uint32_t len = 0;
-    for (;;) {
-        const uint32_t probe = first + len + 64u * (lane + 1u);                 // first point of chunk lane+1
-        const uint64_t more = __ballot(probe < limit && (keys[probe] >> 6) == block);
-        const uint32_t full = more == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~more)) - 1u;  // chunks 1..full start inside the run
-        len += 64u * full;
-        if (full == 64u) continue;                                               // the run is longer than 4160 points: go on
-        const uint32_t i = first + len + lane;                                   // the chunk where the run ends
-        const uint64_t same = __ballot(i < limit && (keys[i] >> 6) == block);
-        return len + (same == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~same)) - 1u);
-    }
-}
-
-constexpr int kNormalWavesPerBlock = 1;  // one wave per workgroup: __syncthreads() is then a wave-local LDS fence
+constexpr int kNormalWaves = 4;            // waves per workgroup of k_frame_normals
+constexpr uint32_t kNormalBigGroups = 512;  // its first workgroups (at most): one large point block each at a time, all four waves on it (scripts/sweep_big_blocks.sh)
 
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 
-__global__ void __launch_bounds__(64 * kNormalWavesPerBlock, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
-k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ points1, const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
-                const uint2* __restrict__ segments, uint32_t list_stride,
-                FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate) {
-    __shared__ NormalScratch s;
-    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
-    // ... and their keys: key >> 6 is the point's block, 63 - (key & 63) its voxel in the block (the low 6 code bits)
-    const uint64_t* __restrict__ keys = (h->sort_passes & 1u) ? keys1 : keys0;
-    const uint32_t lane = threadIdx.x & 63;
-    ListIndex blocks;
-    blocks.load(h, kListBlocks);
-    const uint32_t n = h->n_usable, nseg = blocks.total();
-    auto segment = [&](uint32_t i) {   // point block i, counted through the stripes of the list
-        uint32_t index;
-        const uint32_t stripe = blocks.locate(i, &index);
-        return segments[stripe * list_stride + index];
-    };
+// LDS operations of a wave complete in issue order: between a wave's own writes and reads a compiler barrier and a drained
+// LDS counter are enough (what __syncthreads() amounts to in a one-wave workgroup)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-    auto estimate_block = [&](const uint2 record) {
-        // (start, length, flag) from k_frame_gather; only a block that runs across the end of a gather chunk (one in
-        // fourteen) still has to find its length by probing -- two dependent loads that every block used to pay
-        const uint32_t first = record.x;
-        uint32_t len = record.y & 0x7fffffffu;
-        if (len == 0u) len = run_length(keys, first, n, keys[first] >> 6, lane);
-        // normals.hpp:100 -- the frame's last point never joins a neighbourhood; it is the last point of this segment
-        const bool holds_last = (record.y >> 31) != 0u;
-        const uint32_t grouped = holds_last ? len - 1 : len;
+// Normals of one point block (normals.hpp:81-148 restricted to the block: its walk never leaves it).  kTeam false: one wave does
+// everything (the other waves of the workgroup work on other blocks, nothing is shared).  kTeam true: the whole workgroup of four
+// waves -- the two passes over the points, the team fits and the whole-wave fits are dealt over the waves; the greedy walk is
+// repeated by every wave (it runs in registers on the 64 voxel counters) and only wave 0 publishes it.
+template <bool kTeam>
+__device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 record, const float4* __restrict__ pts, const uint64_t* __restrict__ keys, uint32_t n, F3 pos,
+                                               float4* __restrict__ normals, uint32_t ablate) {
+    const uint32_t lane = threadIdx.x & 63u, wave = kTeam ? threadIdx.x >> 6 : 0u;
+    const uint32_t tid = kTeam ? threadIdx.x : lane, stride = kTeam ? 64u * kNormalWaves : 64u, waves = kTeam ? uint32_t(kNormalWaves) : 1u;
+    auto sync = [&]() { if (kTeam) __syncthreads(); else wave_lds_fence(); };
+    const uint32_t first = record.x;
+    uint32_t len = record.y & 0x7fffffffu;
+    if (len == 0u) len = run_length(keys, first, n, keys[first] >> 6, lane);   // (k_frame_gather measures every block now; kept for safety)
+    if ((ablate >> 16) && len > (ablate >> 16)) return;   // timing experiment: blocks above a size are skipped (results are wrong)
+    // normals.hpp:100 -- the frame's last point never joins a neighbourhood; it is the last point of this segment
+    const bool holds_last = (record.y >> 31) != 0u;
+    const uint32_t grouped = holds_last ? len - 1 : len;
 
-        // pass 1 over the block: voxel histogram in LDS, first kStagePoints points staged in LDS
-        s.count[lane] = 0;
-        __syncthreads();
-        for (uint32_t k = lane; k < len; k += 64) {
-            const uint32_t v = 63u - (uint32_t(keys[first + k]) & 63u);
-            if (k < kStagePoints) s.stage[k] = pts[first + k];
-            if (k < grouped) atomicAdd(&s.count[v], 1u);
-        }
-        __syncthreads();
+    // pass 1 over the block: voxel histogram in LDS, first kStagePoints points staged in LDS
+    if (tid < 64u) s.count[tid] = 0;
+    sync();
+    for (uint32_t k = tid; k < len; k += stride) {
+        const uint32_t v = 63u - (uint32_t(keys[first + k]) & 63u);
+        if (k < kStagePoints) s.stage[k] = pts[first + k];
+        if (k < grouped) atomicAdd(&s.count[v], 1u);
+    }
+    sync();
 
-        // greedy neighbourhood walk (normals.hpp:86-138) over the voxel runs, in registers: lane l holds voxel 63 - l,
-        // the order the points are in.  before = points in higher voxels, upto = before + own.
-        const uint32_t own = s.count[63 - lane];
-        uint32_t upto = own;
+    // greedy neighbourhood walk (normals.hpp:86-138) over the voxel runs, in registers: lane l holds voxel 63 - l,
+    // the order the points are in.  before = points in higher voxels, upto = before + own.
+    const uint32_t own = s.count[63 - lane];
+    uint32_t upto = own;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(upto, o); if (int(lane) >= o) upto += t; }
-        const uint32_t before = upto - own;
-        uint64_t rest = (ablate & 64u) ? 0ull : __ballot(own != 0);  // voxel runs not yet in a neighbourhood
-        uint32_t ngroups = 0, my_group = 0, nteams = 0;
-        while (rest) {
-            const uint32_t l = uint32_t(__ffsll((unsigned long long)rest)) - 1u;  // highest remaining voxel
-            const uint32_t start = read_lane(before, l);
-            uint32_t size = read_lane(own, l);
-            uint32_t l_end = l;                            // lane of the lowest voxel taken into the neighbourhood
-            if (size < kMinPoints) {                       // depth 1: the rest of the 2x2x2 octant (voxel & ~7)
-                l_end = l | 7u;
-                size = read_lane(upto, l_end) - start;
-                if (size < kMinPoints) {                   // depth 2: the rest of the block
-                    l_end = 63u;
-                    size = read_lane(upto, 63u) - start;
-                }
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(upto, o); if (int(lane) >= o) upto += t; }
+    const uint32_t before = upto - own;
+    uint64_t rest = (ablate & 64u) ? 0ull : __ballot(own != 0);  // voxel runs not yet in a neighbourhood
+    uint32_t ngroups = 0, my_group = 0, nteams = 0, ncoop = 0;
+    while (rest) {
+        const uint32_t l = uint32_t(__ffsll((unsigned long long)rest)) - 1u;  // highest remaining voxel
+        const uint32_t start = read_lane(before, l);
+        uint32_t size = read_lane(own, l);
+        uint32_t l_end = l;                            // lane of the lowest voxel taken into the neighbourhood
+        if (size < kMinPoints) {                       // depth 1: the rest of the 2x2x2 octant (voxel & ~7)
+            l_end = l | 7u;
+            size = read_lane(upto, l_end) - start;
+            if (size < kMinPoints) {                   // depth 2: the rest of the block
+                l_end = 63u;
+                size = read_lane(upto, 63u) - start;
             }
-            if (lane == 0) {
-                s.g_first[ngroups] = start; s.g_size[ngroups] = size;
-                if (size >= kTeamPoints && size < kCoopPoints) s.team_list[nteams] = ngroups;
-            }
-            if (size >= kTeamPoints && size < kCoopPoints) nteams++;
-            if (lane >= l && lane <= l_end) my_group = ngroups;
-            ngroups++;
-            rest = l_end == 63u ? 0ull : rest & ~((2ull << l_end) - 1ull);
         }
-        s.group_of[63 - lane] = my_group;
-        __syncthreads();
+        if (lane == 0 && wave == 0) {
+            s.g_first[ngroups] = start; s.g_size[ngroups] = size;
+            if (size >= kTeamPoints && size < kCoopPoints) s.team_list[nteams] = ngroups;
+        }
+        if (size >= kTeamPoints && size < kCoopPoints) nteams++;
+        if (size >= kCoopPoints) ncoop++;
+        if (lane >= l && lane <= l_end) my_group = ngroups;
+        ngroups++;
+        rest = l_end == 63u ? 0ull : rest & ~((2ull << l_end) - 1ull);
+    }
+    if (wave == 0) s.group_of[63 - lane] = my_group;
+    sync();
 
-        // large neighbourhoods: the whole wave, one after the other (wave-uniform loop)
-        for (uint32_t g = 0; g < ((ablate & 8u) ? 0u : ngroups); g++) {
+    // large neighbourhoods: a whole wave each, one after the other (dealt over the waves of a team)
+    if (ncoop && !(ablate & 8u)) {
+        uint32_t turn = 0;
+        for (uint32_t g = 0; g < ngroups; g++) {
             const uint32_t g0 = s.g_first[g], gn = s.g_size[g];
             if (gn < kCoopPoints) continue;
+            if ((turn++ % waves) != wave) continue;
             F3 nrm = g0 + gn <= kStagePoints ? fit_plane_wave(&s.stage[g0], gn, lane) : fit_plane_wave(pts + first + g0, gn, lane);
             if (lane == 0) {
                 const float4 q = pts[first + g0];
@@ -644,73 +660,132 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
                 s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
             }
         }
-        // medium neighbourhoods: four 16-lane teams at a time; a team strides over its points (first from the
-        // staged LDS copy, the rest from HBM) and combines the moments with DPP row reductions
-        {
-            const uint32_t team = lane >> 4, tl = lane & 15u;
-            for (uint32_t r = 0; r * 4u < ((ablate & 8u) ? 0u : nteams); r++) {
-                const uint32_t tg = r * 4u + team;
-                const bool on = tg < nteams;
-                const uint32_t g = on ? s.team_list[tg] : 0u;
-                const uint32_t g0 = s.g_first[g], gn = on ? s.g_size[g] : 0u;
-                auto point = [&](uint32_t k) { const uint32_t at = g0 + k; return at < kStagePoints ? s.stage[at] : pts[first + at]; };
-                double cx = 0, cy = 0, cz = 0;
-                for (uint32_t k = tl; k < gn; k += 16) { const float4 q = point(k); cx += double(q.x); cy += double(q.y); cz += double(q.z); }
-                const double recip = 1.0 / double(gn);
-                cx = team_sum_f64(cx) * recip; cy = team_sum_f64(cy) * recip; cz = team_sum_f64(cz) * recip;
-                double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-                for (uint32_t k = tl; k < gn; k += 16) {
-                    const float4 q = point(k);
-                    const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
-                    xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
-                }
-                xx = team_sum_f64(xx); xy = team_sum_f64(xy); xz = team_sum_f64(xz);
-                yy = team_sum_f64(yy); yz = team_sum_f64(yz); zz = team_sum_f64(zz);
-                if (on && tl == 0) {
-                    F3 nrm = plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
-                    const float4 q = point(0);
-                    const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
-                    if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
-                    s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
-                }
+    }
+    // medium neighbourhoods: 16-lane teams, four per wave at a time; a team strides over its points (first from the
+    // staged LDS copy, the rest from HBM) and combines the moments with DPP row reductions
+    {
+        const uint32_t team = lane >> 4, tl = lane & 15u;
+        for (uint32_t r = 0; r * 4u * waves < ((ablate & 8u) ? 0u : nteams); r++) {
+            const uint32_t tg = (r * waves + wave) * 4u + team;
+            const bool on = tg < nteams;
+            const uint32_t g = on ? s.team_list[tg] : 0u;
+            const uint32_t g0 = s.g_first[g], gn = on ? s.g_size[g] : 0u;
+            auto point = [&](uint32_t k) { const uint32_t at = g0 + k; return at < kStagePoints ? s.stage[at] : pts[first + at]; };
+            double cx = 0, cy = 0, cz = 0;
+            for (uint32_t k = tl; k < gn; k += 16) { const float4 q = point(k); cx += double(q.x); cy += double(q.y); cz += double(q.z); }
+            const double recip = 1.0 / double(gn);
+            cx = team_sum_f64(cx) * recip; cy = team_sum_f64(cy) * recip; cz = team_sum_f64(cz) * recip;
+            double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+            for (uint32_t k = tl; k < gn; k += 16) {
+                const float4 q = point(k);
+                const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
+                xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
             }
-        }
-        // small neighbourhoods (8..15 points): one lane each, in the reference's summation order; and the
-        // neighbourhoods below 8 points, which only get their "no fit" mark here
-        if (lane < ngroups && s.g_size[lane] < kTeamPoints) {
-            const uint32_t g0 = s.g_first[lane], gn = s.g_size[lane];
-            float fit = 0.0f;
-            F3 nrm{0, 0, 0};
-            if (gn >= kMinPoints && !(ablate & 16u)) {
-                const bool staged = g0 + gn <= kStagePoints;
-                nrm = staged ? fit_plane(&s.stage[g0], gn) : fit_plane(pts + first + g0, gn);
-                const float4 q = staged ? s.stage[g0] : pts[first + g0];
+            xx = team_sum_f64(xx); xy = team_sum_f64(xy); xz = team_sum_f64(xz);
+            yy = team_sum_f64(yy); yz = team_sum_f64(yz); zz = team_sum_f64(zz);
+            if (on && tl == 0) {
+                F3 nrm = plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
+                const float4 q = point(0);
                 const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
                 if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
-                fit = 1.0f;
+                s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
             }
-            s.g_normal[lane][0] = nrm.x; s.g_normal[lane][1] = nrm.y; s.g_normal[lane][2] = nrm.z; s.g_normal[lane][3] = fit;
         }
-        __syncthreads();
-        for (uint32_t k = lane; k < ((ablate & 32u) ? 0u : len); k += 64) {
-            F3 nrm;
-            bool fitted = false;
-            if (k < grouped) {
-                const uint32_t g = s.group_of[63u - (uint32_t(keys[first + k]) & 63u)];
-                fitted = s.g_normal[g][3] != 0.0f;
-                nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
-            }
-            if (!fitted) {
-                const float4 q = k < kStagePoints ? s.stage[k] : pts[first + k];
-                nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
-            }
-            normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+    }
+    // small neighbourhoods (8..15 points): one lane each, in the reference's summation order; and the
+    // neighbourhoods below 8 points, which only get their "no fit" mark here
+    if (tid < ngroups && s.g_size[tid] < kTeamPoints) {
+        const uint32_t g0 = s.g_first[tid], gn = s.g_size[tid];
+        float fit = 0.0f;
+        F3 nrm{0, 0, 0};
+        if (gn >= kMinPoints && !(ablate & 16u)) {
+            const bool staged = g0 + gn <= kStagePoints;
+            nrm = staged ? fit_plane(&s.stage[g0], gn) : fit_plane(pts + first + g0, gn);
+            const float4 q = staged ? s.stage[g0] : pts[first + g0];
+            const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
+            if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
+            fit = 1.0f;
         }
-        __syncthreads();
-    };
+        s.g_normal[tid][0] = nrm.x; s.g_normal[tid][1] = nrm.y; s.g_normal[tid][2] = nrm.z; s.g_normal[tid][3] = fit;
+    }
+    sync();
+    for (uint32_t k = tid; k < ((ablate & 32u) ? 0u : len); k += stride) {
+        F3 nrm;
+        bool fitted = false;
+        if (k < grouped) {
+            const uint32_t g = s.group_of[63u - (uint32_t(keys[first + k]) & 63u)];
+            fitted = s.g_normal[g][3] != 0.0f;
+            nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
+        }
+        if (!fitted) {
+            const float4 q = k < kStagePoints ? s.stage[k] : pts[first + k];
+            nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
+        }
+        normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+    }
+    sync();
+}
 
-    if (!(n < kSparsePointsPerBlock * nseg)) {  // dense frame (frame_is_sparse): one wave per point block
-        for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) estimate_block(segment(seg));
+// Workgroups of four waves.  In a dense frame the first kNormalBigGroups workgroups take the large point blocks (more than
+// kBigBlock points: k_frame_gather lists them), one block at a time with all four waves; every other wave takes small blocks, one
+// wave per block, the waves of a workgroup sharing nothing.  (The large workgroups have the lowest indices, so they start first:
+// they are the kernel's long pole.)
+__global__ void __launch_bounds__(64 * kNormalWaves, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
+k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ points1, const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+                const uint2* __restrict__ segments, uint32_t list_stride,
+                FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate, uint32_t big_block, uint32_t max_big_groups) {
+    __shared__ NormalScratch scratch[kNormalWaves];
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
+    // ... and their keys: key >> 6 is the point's block, 63 - (key & 63) its voxel in the block (the low 6 code bits)
+    const uint64_t* __restrict__ keys = (h->sort_passes & 1u) ? keys1 : keys0;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // where each stripe's entries begin in the two block lists (all blocks from the front of a stripe, the large ones again from its
+    // back), in LDS: kept in registers the thirty-four prefix sums spill
+    __shared__ uint32_t list_begin[2][kListStripes + 1];
+    if (threadIdx.x < 2 * kListStripes) {   // lanes 0..15: all blocks, 16..31: the large ones; a 16-lane inclusive scan each
+        const uint32_t which = threadIdx.x / kListStripes, stripe = threadIdx.x % kListStripes;
+        uint32_t incl = h->list_count[which ? kListBigBlocks : kListBlocks][stripe * 16];
+#pragma unroll
+        for (int o = 1; o < int(kListStripes); o <<= 1) { const uint32_t t = __shfl_up(incl, o, kListStripes); if (int(stripe) >= o) incl += t; }
+        list_begin[which][stripe + 1] = incl;
+        if (stripe == 0) list_begin[which][0] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n = h->n_usable, nseg = list_begin[0][kListStripes], nbig = list_begin[1][kListStripes];
+    auto locate = [&](uint32_t which, uint32_t i, uint32_t* index) {   // stripe of entry i of a list and its index inside the stripe
+        uint32_t stripe = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < kListStripes; k++) stripe = i >= list_begin[which][k] ? k : stripe;
+        *index = i - list_begin[which][stripe];
+        return stripe;
+    };
+    auto segment = [&](uint32_t i) {   // point block i, counted through the stripes of the list
+        uint32_t index;
+        const uint32_t stripe = locate(0u, i, &index);
+        return segments[stripe * list_stride + index];
+    };
+    const bool sparse = n < kSparsePointsPerBlock * nseg;   // frame_is_sparse
+    // the large blocks' workgroups (none in a sparse frame or when there is no large block)
+    uint32_t big_groups = 0;
+    if (!sparse && !(ablate & 128u)) {
+        big_groups = nbig ? min(min(max_big_groups, nbig), gridDim.x / 2u) : 0u;
+        if (blockIdx.x < big_groups) {
+            for (uint32_t b = blockIdx.x; b < nbig; b += big_groups) {
+                uint32_t index;
+                const uint32_t stripe = locate(1u, b, &index);
+                estimate_block<true>(scratch[0], segments[(stripe + 1u) * list_stride - 1u - index], pts, keys, n, pos, normals, ablate);
+            }
+            return;
+        }
+    }
+    NormalScratch& s = scratch[wave];
+    const uint32_t my_wave = (blockIdx.x - big_groups) * kNormalWaves + wave, all_waves = (gridDim.x - big_groups) * kNormalWaves;
+    if (!sparse) {  // dense frame: one wave per (small) point block
+        for (uint32_t seg = my_wave; seg < nseg; seg += all_waves) {
+            const uint2 record = segment(seg);
+            if (big_groups && (record.y & 0x7fffffffu) > big_block) continue;   // a large block: the workgroups above
+            estimate_block<false>(s, record, pts, keys, n, pos, normals, ablate);
+        }
         return;
     }
     // Sparse frame (about one point per block, e.g. 2 cm voxels outdoors): a block with fewer than kMinPoints points cannot
@@ -720,7 +795,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
     // Batch t holds the blocks lane * batches + t: the larger blocks cluster (next to the sensor), and sixty-four
     // neighbours in one batch would be worked off one after the other by a single wave.
     const uint32_t batches = (nseg + 63u) / 64u;
-    for (uint32_t t = blockIdx.x; t < batches; t += gridDim.x) {
+    for (uint32_t t = my_wave; t < batches; t += all_waves) {
         const uint32_t mine = lane * batches + t;
         const uint2 record = mine < nseg ? segment(mine) : make_uint2(0u, 0u);
         const uint32_t len = record.y & 0x7fffffffu;
@@ -733,7 +808,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
             }
         for (uint64_t big = __ballot(mine < nseg && !small); big; big &= big - 1ull) {
             const uint32_t l = uint32_t(__ffsll((unsigned long long)big)) - 1u;
-            estimate_block(make_uint2(read_lane(record.x, l), read_lane(record.y, l)));
+            estimate_block<false>(s, make_uint2(read_lane(record.x, l), read_lane(record.y, l)), pts, keys, n, pos, normals, ablate);
         }
     }
 }

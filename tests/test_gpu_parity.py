@@ -250,12 +250,12 @@ def test_save_writes_first_submap(chad, tmp_path):
     pts, pos = synth.cfg2_frame(20_000)
     m = chad.TSDFMap(0.05, 0.10)
     m.insert(pts, pos)
-    path = tmp_path / "voxels.ply"
+    path = tmp_path / "mesh.ply"
     m.save(str(path))
     assert m.closed_submaps == 1 and len(m.export_leaves(-1)[0]) == 0  # tsdf.cpp:78-81 archives the active submap
     head = path.read_bytes()[:400].decode(errors="replace")
-    n = len(m.export_leaves(0)[0])
-    assert f"element vertex {n}" in head
+    v, tri = m.mesh(0)                                                 # tsdf.cpp:85: the FIRST submap is reconstructed (tests/test_gpu_readback.py)
+    assert f"element vertex {len(v)}" in head and f"element face {len(tri)}" in head and len(tri) > 0
     m.close()
 
 
