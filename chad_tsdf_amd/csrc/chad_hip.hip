@@ -912,9 +912,13 @@ chad_status chad_map_insert_device_stream(chad_map* m, const float* xyz_device, 
     if (!n) return insert_nothing(m, position);
     FrameSlot* f = nullptr;
     TRY(prepare_slot(m, n, &f));
-    // whatever the producer's stream has been given so far -- the kernels or copies that write the points -- comes first
-    HIP_TRY(hipEventRecord(m->producer_ready, hipStream_t(producer_stream)));
-    HIP_TRY(hipStreamWaitEvent(f->prep, m->producer_ready, 0));
+    // whatever the producer's stream has been given so far -- the kernels or copies that write the points -- comes first.  A
+    // stream that is idle right now has nothing the frame could overtake (a query costs a microsecond; record + wait cost twelve)
+    if (hipStreamQuery(hipStream_t(producer_stream)) != hipSuccess) {
+        (void)hipGetLastError();   // hipErrorNotReady
+        HIP_TRY(hipEventRecord(m->producer_ready, hipStream_t(producer_stream)));
+        HIP_TRY(hipStreamWaitEvent(f->prep, m->producer_ready, 0));
+    }
     return insert_device(m, *f, xyz_device, n, position);
 }
 

@@ -1,15 +1,21 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under profiles/ for the current build.  Run ON THE GPU BOX from the repo root:
-#   gpurun -- 'bash scripts/collect_profiles.sh r01'
+#   gpurun -- 'bash scripts/collect_profiles.sh r02a'
 # Kernel-trace stats and each PMC group are separate runs (rocprofv3 cannot mix them; FETCH_SIZE and WRITE_SIZE do
-# not fit one pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# not fit one pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots").  The program itself follows `--` (python3 bench.py),
+# never a wrapper: the profiler's preloaded library has initialised the GPU by then.
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out"; mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 > "$out/bench_trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 > "$out/bench_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 > "$out/bench_write.log" 2>&1
-rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/tcc" -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 > "$out/bench_tcc.log" 2>&1
+B="--no-extras --cpu-seconds 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 $B > "$out/bench_trace.log" 2>&1
+echo "trace done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 bench.py --steps 6 --warmup 2 $B > "$out/bench_fetch.log" 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 bench.py --steps 6 --warmup 2 $B > "$out/bench_write.log" 2>&1
+echo "write done"
+rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/tcc" -- python3 bench.py --steps 6 --warmup 2 $B > "$out/bench_tcc.log" 2>&1
+echo "tcc done"
 python3 scripts/summarise_profiles.py "$out" "$tag"
