@@ -70,6 +70,29 @@ struct DevBuf {   // device allocation released on every exit path
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+struct Arena {   // grow-only device scratch, carved up again for every use (no hipMalloc / hipFree -- each a device-wide stall -- in steady state)
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    hipError_t reserve(size_t bytes) {   // previous contents are dead
+        used = 0;
+        if (bytes <= cap) return hipSuccess;
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    template <class T> T* take(size_t count) {
+        used = (used + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(base + used);
+        used += count * sizeof(T);
+        return p;
+    }
+    static size_t padded(size_t bytes) { return ((bytes + 255) & ~size_t(255)) + 256; }
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = used = 0; }
+};
+
 enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
 
 }  // namespace
@@ -164,6 +187,18 @@ struct chad_map {
     // submap is closed by merging the ranks' partial bricks (merge_and_close) instead of archiving the local ones.
     chad_comm* comm = nullptr;
     uint64_t stream_frames = 0;                   // inserts seen since the communicator was attached
+    // The exchange runs like the local archive: beside the next frames.  The closing table is this rank's share; three stages, each
+    // enqueued on the map's stream when the previous one's numbers have reached the host (merge_advance): polled by every insert,
+    // waited for by whatever needs the closed submap.
+    chad_comm* closing_comm = nullptr;            // non-null: the closing table is being merged over this communicator
+    int merge_stage = 0;                          // 0: local block count pending, 1: all ranks' counts pending, 2: size of the union pending
+    hipEvent_t merge_event = nullptr;             // behind the device-to-host copy of the current stage's numbers
+    uint64_t* merge_host = nullptr;               // pinned: [0..15] blocks per rank, [16] blocks in the union, [17] this rank's count (source of an H2D copy)
+    Arena merge_a, merge_b, merge_c;              // scratch of the three stages
+    uint32_t merge_blocks = 0;                    // this rank's blocks
+    uint64_t* merge_keys = nullptr; long long* merge_sum = nullptr; uint32_t* merge_cnt = nullptr;   // ... compacted raw (arena a)
+    uint64_t merge_total = 0;                     // blocks over all ranks
+    uint32_t* merge_heads = nullptr;              // (arena b) per-chunk counts of distinct keys
     // stage timing (CHAD_FLAG_TIMING): a ring of event sets, one per insert, read back lazily by chad_map_stats so
     // that timing adds no synchronisation to insert()
     static constexpr int kTimingRing = 64;
@@ -353,6 +388,7 @@ chad_status read_block_count(chad_map* m, uint32_t* blocks) {
 }
 
 chad_status finalize_closed(chad_map* m);  // (further down, with the rest of Submap::finalize)
+chad_status ensure_aux_sort(chad_map* m, size_t n);
 
 void free_submap(Submap& s) {
     (void)hipFree(s.keys); (void)hipFree(s.sum); (void)hipFree(s.cnt);
@@ -395,8 +431,10 @@ chad_status release_finalized(chad_map* m) {
 // Second half of a roll-over: the closing table's block count is on the host (or is waited for if `block`): size the
 // archive, compact the table into it and clear it -- all on the map's stream, beside the frames that already fill the new
 // active table -- and keep the cleared table as the next spare.
+chad_status merge_advance(chad_map* m, bool block);   // (below: the multi-GPU form of the same second half)
 chad_status finish_closing(chad_map* m, bool block) {
     if (!m->closing) return CHAD_OK;
+    if (m->closing_comm) return merge_advance(m, block);
     if (block) HIP_TRY(hipEventSynchronize(m->closing_counted));
     else if (hipEventQuery(m->closing_counted) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
     uint32_t blocks = 0;
@@ -443,6 +481,138 @@ chad_status close_active(chad_map* m) {
     m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
     *m->h_live_blocks = 0;
     return exclusive_end(m, m->stream);    // ... and later updates (into the new table) wait for this point: the spare is ready
+}
+
+
+// ---- multi-GPU: the exchange at a submap close -------------------------------------------------------
+// Collective: every rank of the communicator reaches it at the same point of the frame stream (the roll-over rule depends on the
+// poses only, which every rank sees).  Afterwards every rank holds the same closed submap -- the sum of all ranks' partial bricks,
+// bit for bit what one GPU would have archived from the same frames.  It runs like the local archive, beside the next frames:
+// merge_begin swaps the tables (the closing table is this rank's share), merge_advance enqueues one stage at a time on the map's
+// stream, each as soon as the previous stage's numbers have reached the host:
+//   stage 0 -> 1  (local block count known)  compact the share raw (64-bit sums); all-gather the ranks' block counts
+//   stage 1 -> 2  (all counts known)         all-gather the block keys (lists padded to the longest); sorted union: radix sort + distinct
+//   stage 2 -> done (union size known)       scatter the share into dense [U x 64] buffers over the union; all-reduce(sum) of the i64
+//                                            sums and u32 counts; convert to the archive's format exactly as the local archive does
+// Every rank issues the same four collectives in the same order; between the stages the host only reads a few pinned words.
+#define COMM_TRY(expr) do { if (!(expr)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: " + c->error); } while (0)
+
+chad_status merge_begin(chad_map* m, chad_comm* c) {
+    if (c->device != m->device) return fail(CHAD_ERR_INVALID_ARG, "the communicator was created on another device");
+    TRY(finish_closing(m, true));          // at most one submap closes at a time
+    TRY(flush_pending_clear(m));
+    if (!m->has_spare) {
+        if (alloc_map_storage(m->spare, m->brick_capacity, m->stream, m->d_overflow) != CHAD_OK) { free_map_storage(m->spare); return CHAD_ERR_OUT_OF_MEMORY; }
+        m->has_spare = true;
+    }
+    TRY(exclusive_begin(m));               // the map's stream waits for every update enqueued so far ...
+    HIP_TRY(hipMemcpyAsync(m->closing_count, m->view.brick_count, kCountStripes * 64, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipEventRecord(m->closing_counted, m->stream));
+    m->closing_view = m->view; m->closing = true; m->closing_comm = c; m->merge_stage = 0;
+    m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
+    *m->h_live_blocks = 0;
+    return exclusive_end(m, m->stream);    // ... and later updates (into the new table) wait for this point only
+}
+
+chad_status merge_advance(chad_map* m, bool block) {
+    chad_comm* c = m->closing_comm;
+    hipStream_t s = m->stream;
+    const uint32_t world = uint32_t(c->world);
+    for (;;) {
+        hipEvent_t pending = m->merge_stage == 0 ? m->closing_counted : m->merge_event;
+        if (block) HIP_TRY(hipEventSynchronize(pending));
+        else if (hipEventQuery(pending) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
+        if (m->merge_stage == 0) {
+            uint32_t nb = 0;
+            for (uint32_t k = 0; k < kCountStripes; k++) nb += m->closing_count[k * 16];
+            m->merge_blocks = nb;
+            HIP_TRY(m->merge_a.reserve(Arena::padded(size_t(nb) * 8) + Arena::padded(size_t(nb) * 512) + Arena::padded(size_t(nb) * 256) + Arena::padded(8) + Arena::padded(8 * size_t(world))));
+            m->merge_keys = m->merge_a.take<uint64_t>(nb); m->merge_sum = m->merge_a.take<long long>(size_t(nb) * 64); m->merge_cnt = m->merge_a.take<uint32_t>(size_t(nb) * 64);
+            uint64_t* d_n = m->merge_a.take<uint64_t>(1);
+            uint64_t* d_all_n = m->merge_a.take<uint64_t>(world);
+            if (nb) {
+                HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
+                hipLaunchKernelGGL(k_compact_bricks_raw, dim3(512), dim3(256), 0, s, m->closing_view, m->d_cursor, nb, m->merge_keys, m->merge_sum, m->merge_cnt);
+                HIP_TRY(hipGetLastError());
+            }
+            m->merge_host[17] = nb;
+            HIP_TRY(hipMemcpyAsync(d_n, &m->merge_host[17], 8, hipMemcpyHostToDevice, s));
+            COMM_TRY(c->all_gather(d_n, d_all_n, 8, s));
+            HIP_TRY(hipMemcpyAsync(m->merge_host, d_all_n, 8 * size_t(world), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(m->merge_event, s));
+            m->merge_stage = 1;
+        } else if (m->merge_stage == 1) {
+            uint64_t total = 0, longest = 0;
+            RankCounts rc{};
+            for (uint32_t r = 0; r < world; r++) {
+                const uint64_t n = m->merge_host[r];
+                if (n >= (1ull << 31)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible block count from a rank");
+                rc.count[r] = uint32_t(n); rc.begin[r] = uint32_t(total);
+                total += n; longest = std::max(longest, n);
+            }
+            if (total >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks over all ranks");
+            m->merge_total = total;
+            const uint32_t chunks = uint32_t((total + kUniqueChunk - 1) / kUniqueChunk);
+            HIP_TRY(m->merge_b.reserve(Arena::padded(longest * 8) + Arena::padded(longest * 8 * world) + Arena::padded(size_t(chunks) * 4) + Arena::padded(4)));
+            uint64_t* send = m->merge_b.take<uint64_t>(longest);
+            uint64_t* recv = m->merge_b.take<uint64_t>(longest * world);
+            m->merge_heads = m->merge_b.take<uint32_t>(chunks);
+            uint32_t* d_union_n = m->merge_b.take<uint32_t>(1);
+            if (total) {
+                // all ranks' keys (lists padded to the longest), then the sorted union -- the same on every rank
+                hipLaunchKernelGGL(k_fill_u64, grid_for(longest), dim3(256), 0, s, send, size_t(longest), kEmptyKey);
+                if (m->merge_blocks) HIP_TRY(hipMemcpyAsync(send, m->merge_keys, size_t(m->merge_blocks) * 8, hipMemcpyDeviceToDevice, s));
+                COMM_TRY(c->all_gather(send, recv, longest * 8, s));
+                TRY(ensure_aux_sort(m, total));
+                hipLaunchKernelGGL(k_concat_keys, grid_for(longest), dim3(256), 0, s, recv, uint32_t(longest), rc, world, m->aux_sort.keys[0]);
+                RadixSortSignals sig;
+                sig.fault = m->d_overflow;
+                radix_sort_enqueue(m->aux_sort, uint32_t(total), kMaxPasses, nullptr, s, 0, 0, sig);   // an even number of passes: sorted keys end up in keys[0]
+                hipLaunchKernelGGL(k_unique_count, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(total), m->merge_heads);
+                hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, s, m->merge_heads, chunks, d_union_n);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(&m->merge_host[16], d_union_n, 4, hipMemcpyDeviceToHost, s));
+            } else m->merge_host[16] = 0;   // (nothing to gather: every rank sees total == 0 and skips the collective alike)
+            HIP_TRY(hipEventRecord(m->merge_event, s));
+            m->merge_stage = 2;
+        } else {
+            const uint32_t n_union = m->merge_total ? uint32_t(m->merge_host[16] & 0xffffffffull) : 0u;
+            Submap arch;
+            TRY(alloc_submap(arch, n_union));
+            if (n_union) {
+                const uint32_t chunks = uint32_t((m->merge_total + kUniqueChunk - 1) / kUniqueChunk);
+                const size_t cells = size_t(n_union) * 64;
+                HIP_TRY(m->merge_c.reserve(Arena::padded(cells * 8) + Arena::padded(cells * 4)));
+                long long* dense_sum = m->merge_c.take<long long>(cells);
+                uint32_t* dense_cnt = m->merge_c.take<uint32_t>(cells);
+                hipLaunchKernelGGL(k_unique_write, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(m->merge_total), m->merge_heads, arch.keys);
+                // this rank's bricks into dense buffers over the union; the all-reduce: 64-bit integer sums and counts, exact in any order
+                HIP_TRY(hipMemsetAsync(dense_sum, 0, cells * 8, s));
+                HIP_TRY(hipMemsetAsync(dense_cnt, 0, cells * 4, s));
+                if (m->merge_blocks) hipLaunchKernelGGL(k_scatter_bricks_dense, grid_for(size_t(m->merge_blocks) * 64), dim3(256), 0, s, m->merge_keys, m->merge_sum, m->merge_cnt, m->merge_blocks,
+                                                        arch.keys, n_union, dense_sum, dense_cnt);
+                HIP_TRY(hipGetLastError());
+                COMM_TRY(c->all_reduce(dense_sum, cells, CHAD_REDUCE_I64, s));
+                COMM_TRY(c->all_reduce(dense_cnt, cells, CHAD_REDUCE_U32, s));
+                // the archive's format, converted exactly as the single-GPU archive converts (k_compact_bricks)
+                hipLaunchKernelGGL(k_dense_to_archive, grid_for(cells), dim3(256), 0, s, dense_sum, dense_cnt, cells, m->trunc, arch.sum, arch.cnt);
+            }
+            hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, s, m->closing_view, 0u);
+            HIP_TRY(hipGetLastError());
+            m->closed.push_back(arch);
+            m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: whoever swaps it in does so on this stream
+            m->closing_view = MapView{}; m->closing = false; m->closing_comm = nullptr; m->merge_stage = 0;
+            return release_finalized(m);
+        }
+    }
+}
+#undef COMM_TRY
+
+// The exchange, start to finish (explicit calls; the roll-over inside insert() only begins it).
+chad_status merge_and_close(chad_map* m, chad_comm* c) {
+    if (!c || !c->exchanges()) return close_active(m);
+    TRY(merge_begin(m, c));
+    return CHAD_OK;
 }
 
 chad_status select_submap(chad_map* m, int32_t submap, uint32_t* blocks, const uint64_t** keys, const float** sum, const uint32_t** cnt) {
@@ -628,6 +798,7 @@ chad_status note_pose(chad_map* m, const float position[3]) {
 // the frame): nothing is enqueued.
 chad_status insert_nothing(chad_map* m, const float position[3]) {
     TRY(note_pose(m, position));
+    if (m->closing_comm) TRY(finish_closing(m, false));   // a rank that owns none of the coming frames still moves the exchange along
     m->frames_empty_tail++;
     m->last_points_in = 0;
     return CHAD_OK;
@@ -821,6 +992,8 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     std::memset(const_cast<uint32_t*>(m->h_consumed), 0, chad_map::kMaxSlots * 64);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_consumed), const_cast<uint32_t*>(m->h_consumed), 0));
     CREATE_TRY(hipEventCreateWithFlags(&m->producer_ready, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&m->merge_event, hipEventDisableTiming));
+    CREATE_TRY(hipHostMalloc(&m->merge_host, 32 * 8));
     // what the look-back sort may assume about residency: the pass kernel's real occupancy, shared among the frames in flight
     m->sort_resident = radix_resident_workgroups<PointPayload>();
     m->aux_resident = radix_resident_workgroups<IndexPayload>() / (m->serial ? 1u : m->n_slots + 1u);
@@ -872,6 +1045,9 @@ void chad_map_destroy(chad_map* m) {
     }
     if (m->caller_ready) (void)hipEventDestroy(m->caller_ready);
     if (m->producer_ready) (void)hipEventDestroy(m->producer_ready);
+    if (m->merge_event) (void)hipEventDestroy(m->merge_event);
+    if (m->merge_host) (void)hipHostFree(m->merge_host);
+    m->merge_a.release(); m->merge_b.release(); m->merge_c.release();
     if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
     free_sort_buffers(m->aux_sort);
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
@@ -960,6 +1136,7 @@ chad_status chad_map_sync(chad_map* m) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
     uint32_t overflow = 0;
+    TRY(finish_closing(m, true));   // a roll-over's archive (or exchange: every rank syncs at the same point) is part of "all enqueued work"
     TRY(read_back_header(m, &overflow));
     if (overflow & kSortFaultStalled) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors (workgroups not dispatched in index order?): at least one frame was sorted incompletely");
     if (overflow) return fail(CHAD_ERR_CAPACITY, "block capacity of the active submap exceeded; raise chad_options.max_blocks");
@@ -1151,95 +1328,7 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
 }
 
 
-// ---- multi-GPU: communicators and the exchange at a submap close -----------------------------------
-namespace {
-
-#define COMM_TRY(expr) do { if (!(expr)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: " + c->error); } while (0)
-
-// The exchange step.  Collective: every rank of `c` calls it at the same point of the frame stream (the roll-over rule depends
-// on the poses only, which every rank sees).  Afterwards every rank holds the same closed submap -- the sum of all ranks'
-// partial bricks, bit for bit what one GPU would have archived from the same frames -- and an empty active submap.
-chad_status merge_and_close(chad_map* m, chad_comm* c) {
-    if (!c || !c->exchanges()) return close_active(m);
-    if (c->device != m->device) return fail(CHAD_ERR_INVALID_ARG, "the communicator was created on another device");
-    TRY(finish_closing(m, true));
-    uint32_t nb = 0;
-    TRY(read_block_count(m, &nb));   // carries out a pending reset, waits for every frame in flight
-    hipStream_t s = m->stream;
-    const uint32_t world = uint32_t(c->world);
-
-    // 1. this rank's live bricks, dense and raw (64-bit sums)
-    DevBuf keys, sum, cnt;
-    HIP_TRY(keys.alloc(size_t(nb) * 8)); HIP_TRY(sum.alloc(size_t(nb) * 512)); HIP_TRY(cnt.alloc(size_t(nb) * 256));
-    if (nb) {
-        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
-        hipLaunchKernelGGL(k_compact_bricks_raw, dim3(512), dim3(256), 0, s, m->view, m->d_cursor, nb, keys.as<uint64_t>(), sum.as<long long>(), cnt.as<uint32_t>());
-        HIP_TRY(hipGetLastError());
-    }
-    // 2. how many blocks every rank holds
-    DevBuf d_n, d_all_n;
-    HIP_TRY(d_n.alloc(8)); HIP_TRY(d_all_n.alloc(8 * size_t(world)));
-    const uint64_t n_local = nb;
-    HIP_TRY(hipMemcpyAsync(d_n.p, &n_local, 8, hipMemcpyHostToDevice, s));
-    COMM_TRY(c->all_gather(d_n.p, d_all_n.p, 8, s));
-    std::vector<uint64_t> counts(world);
-    HIP_TRY(hipMemcpyAsync(counts.data(), d_all_n.p, 8 * size_t(world), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    uint64_t total = 0, longest = 0;
-    RankCounts rc{};
-    for (uint32_t r = 0; r < world; r++) {
-        if (counts[r] >= (1ull << 31)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible block count from a rank");
-        rc.count[r] = uint32_t(counts[r]); rc.begin[r] = uint32_t(total);
-        total += counts[r]; longest = std::max(longest, counts[r]);
-    }
-    if (total >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks over all ranks");
-    Submap arch;
-    if (total) {
-        // 3. all ranks' keys (lists padded to the longest), then the sorted union -- the same on every rank
-        DevBuf send, recv;
-        HIP_TRY(send.alloc(longest * 8)); HIP_TRY(recv.alloc(longest * 8 * world));
-        hipLaunchKernelGGL(k_fill_u64, grid_for(longest), dim3(256), 0, s, send.as<uint64_t>(), size_t(longest), kEmptyKey);
-        if (nb) HIP_TRY(hipMemcpyAsync(send.p, keys.p, size_t(nb) * 8, hipMemcpyDeviceToDevice, s));
-        COMM_TRY(c->all_gather(send.p, recv.p, longest * 8, s));
-        TRY(ensure_aux_sort(m, total));
-        hipLaunchKernelGGL(k_concat_keys, grid_for(longest), dim3(256), 0, s, recv.as<uint64_t>(), uint32_t(longest), rc, world, m->aux_sort.keys[0]);
-        RadixSortSignals sig;
-        sig.fault = m->d_overflow;
-        radix_sort_enqueue(m->aux_sort, uint32_t(total), kMaxPasses, nullptr, s, 0, 0, sig);   // an even number of passes: sorted keys end up in keys[0]
-        const uint32_t chunks = uint32_t((total + kUniqueChunk - 1) / kUniqueChunk);
-        DevBuf heads, d_union_n;
-        HIP_TRY(heads.alloc(size_t(chunks) * 4)); HIP_TRY(d_union_n.alloc(4));
-        hipLaunchKernelGGL(k_unique_count, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(total), heads.as<uint32_t>());
-        hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, s, heads.as<uint32_t>(), chunks, d_union_n.as<uint32_t>());
-        uint32_t n_union = 0;
-        HIP_TRY(hipMemcpyAsync(&n_union, d_union_n.p, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        TRY(alloc_submap(arch, n_union));
-        hipLaunchKernelGGL(k_unique_write, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(total), heads.as<uint32_t>(), arch.keys);
-        // 4. this rank's bricks into dense buffers over the union; 5. the all-reduce: 64-bit integer sums and counts, exact in any order
-        const size_t cells = size_t(n_union) * 64;
-        DevBuf dense_sum, dense_cnt;
-        HIP_TRY(dense_sum.alloc(cells * 8)); HIP_TRY(dense_cnt.alloc(cells * 4));
-        HIP_TRY(hipMemsetAsync(dense_sum.p, 0, cells * 8, s));
-        HIP_TRY(hipMemsetAsync(dense_cnt.p, 0, cells * 4, s));
-        if (nb) hipLaunchKernelGGL(k_scatter_bricks_dense, grid_for(size_t(nb) * 64), dim3(256), 0, s, keys.as<uint64_t>(), sum.as<long long>(), cnt.as<uint32_t>(), nb, arch.keys, n_union,
-                                   dense_sum.as<long long>(), dense_cnt.as<uint32_t>());
-        HIP_TRY(hipGetLastError());
-        COMM_TRY(c->all_reduce(dense_sum.p, cells, CHAD_REDUCE_I64, s));
-        COMM_TRY(c->all_reduce(dense_cnt.p, cells, CHAD_REDUCE_U32, s));
-        // 6. the archive's format, converted exactly as the single-GPU archive converts (k_compact_bricks)
-        hipLaunchKernelGGL(k_dense_to_archive, grid_for(cells), dim3(256), 0, s, dense_sum.as<long long>(), dense_cnt.as<uint32_t>(), cells, m->trunc, arch.sum, arch.cnt);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(s));   // the temporaries go out of scope
-    } else TRY(alloc_submap(arch, 0));
-    m->closed.push_back(arch);
-    m->positions.clear();
-    TRY(clear_active(m));
-    return release_finalized(m);
-}
-#undef COMM_TRY
-
-}  // namespace
+// ---- multi-GPU: communicators (the exchange itself: merge_begin / merge_advance above) ---------------------------------------
 
 chad_status chad_comm_unique_id(uint8_t id[CHAD_COMM_ID_BYTES]) {
     if (!id) return fail(CHAD_ERR_INVALID_ARG, "null argument");
@@ -1302,7 +1391,9 @@ chad_status chad_map_attach_comm(chad_map* m, chad_comm* c) {
 chad_status chad_map_merge_and_close(chad_map* m, chad_comm* c) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
-    return merge_and_close(m, c ? c : m->comm);
+    TRY(merge_and_close(m, c ? c : m->comm));
+    m->positions.clear();
+    return finish_closing(m, true);   // an explicit exchange is complete when the call returns
 }
 
 // ---- Submap::finalize (submap.hpp:10-106): leaf clusters on the device, the DAG of NodeLevels on the host ----
