@@ -116,3 +116,66 @@ def test_one_rank_rccl_communicator_goes_through_rccl(monkeypatch):
     shard.attach_comm(None)
     shard.close(); plain.close()
     lib.chad_comm_destroy(comm)
+
+
+def _cfg4_rank(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from chad_tsdf_amd import synth
+
+    n_frames = 500
+    mine = {k: synth.cfg3_frame(k)[0] for k in range(rank, n_frames, world)}     # a rank only ever sees the points of its own frames
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chad_tsdf_amd.sharded import ShardedTSDFMap
+
+    dev = {k: torch.from_numpy(p).cuda() for k, p in mine.items()}
+    torch.cuda.synchronize()
+    sm = ShardedTSDFMap(0.05, 0.10)
+    for k in range(n_frames):
+        sm.insert(dev.get(k), np.asarray((-12.0 + 0.05 * k, 0.1, 0.0), dtype=np.float32))   # no synchronisation: the exchanges ride beside the frames
+    sm.merge_and_close()
+    sm.local.sync()
+    assert sm.closed_submaps == 5 and sm.local.stats()["overflow"] == 0
+    if rank == 0:
+        for s in range(5):
+            mc, sd, w = sm.export_leaves(s)
+            np.savez(os.path.join(outdir, f"cfg4_submap{s}.npz"), mc=mc, sd=sd, w=w)
+    else:   # the other rank: its submaps must be the same arrays -- a checksum is enough to carry over
+        sums = [[int(a.view(np.uint32).astype(np.uint64).sum()) for a in sm.export_leaves(s)] for s in range(5)]
+        np.save(os.path.join(outdir, f"cfg4_rank{rank}_sums.npy"), np.array(sums, dtype=np.uint64))
+    sm.local.close()
+    dist.destroy_process_group()
+
+
+def test_cfg4_full_stream_on_two_ranks(tmp_path):
+    """BASELINE config 4 at the stream's stated size -- 500 frames x 200 k points dealt round-robin, the block partials merged at
+    every submap close (roll-overs at frames 101 / 202 / 303 / 404, plus the open submap at the end) -- with the two ranks this box
+    can hold (they share its GPU, so the library's exchange runs over its callback transport; RCCL over xGMI is the 8-GPU node's).
+    Every closed submap must equal, bit for bit, the submap one process builds from the whole stream."""
+    import torch.multiprocessing as mp
+
+    import chad_tsdf_amd
+    from chad_tsdf_amd import synth
+
+    world, port = 2, 29541
+    mp.spawn(_cfg4_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import torch
+
+    single = chad_tsdf_amd.TSDFMap(0.05, 0.10)
+    for k in range(500):
+        pts, pos = synth.cfg3_frame(k)
+        single.insert(torch.from_numpy(pts).cuda(), pos)
+    single.close_submap()
+    assert single.closed_submaps == 5
+    other = np.load(tmp_path / "cfg4_rank1_sums.npy")
+    for s in range(5):
+        want = single.export_leaves(s)
+        got = np.load(tmp_path / f"cfg4_submap{s}.npz")
+        assert np.array_equal(got["mc"], want[0]) and np.array_equal(got["w"], want[2]), f"submap {s}"
+        assert np.array_equal(got["sd"].view(np.uint32), want[1].view(np.uint32)), f"submap {s}: two ranks == one GPU, bit for bit"
+        assert [int(a.view(np.uint32).astype(np.uint64).sum()) for a in want] == other[s].tolist(), f"submap {s} on rank 1"
+    single.close()
