@@ -176,6 +176,7 @@ struct chad_map {
     // part of it -- sizing the archive -- whenever the count has arrived.  At most one submap is closing at a time.
     MapView spare{};
     bool has_spare = false;
+    bool spare_unaffordable = false;              // a second table did not fit once: resets clear in place from then on
     MapView closing_view{};
     bool closing = false;
     hipEvent_t closing_counted = nullptr;         // the closing table's block count has reached closing_count
@@ -747,7 +748,8 @@ chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
     // stores the frame's number into host-mapped memory: no event, nothing added to the stream); this also bounds how far the
     // host runs ahead of the device -- n_slots frames.  Normally the number is already there; otherwise poll briefly, then wait
     // for the slot's stream (always sufficient: everything of that frame ran on it).
-    if (f.input_seq && m->h_consumed[turn * 16] != f.input_seq) {
+    static const bool no_throttle = std::getenv("CHAD_DEBUG_NO_THROTTLE") != nullptr;   // measurement of the host's own cost per insert only: voids the lifetime contract
+    if (f.input_seq && m->h_consumed[turn * 16] != f.input_seq && !no_throttle) {
         const auto t0 = std::chrono::steady_clock::now();
         while (m->h_consumed[turn * 16] != f.input_seq) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { HIP_TRY(hipStreamSynchronize(f.prep)); break; }
@@ -959,7 +961,8 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         m->own_stream = true;
     }
     if (const char* e = std::getenv("CHAD_SLOTS")) m->n_slots = std::min<uint32_t>(chad_map::kMaxSlots, std::max(1, std::atoi(e)));
-    m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE | CHAD_FLAG_TIME_KERNELS)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr;
+    m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr ||
+                ((m->flags & CHAD_FLAG_TIME_KERNELS) && !std::getenv("CHAD_DEBUG_TIME_PIPELINED"));   // (experiment: per-kernel time stamps with three frames in flight)
 
     uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
     if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
@@ -1157,8 +1160,29 @@ chad_status chad_map_reset(chad_map* m) {
     m->dag_generation++;
     m->mesh_submap = INT32_MIN;
     m->positions.clear();
-    // The clear itself is deferred to the stream of the next insert (right in front of its update), so that the next
-    // frame's preparation does not queue behind it; anything else that looks at the map first carries it out (flush_pending_clear).
+    // Octree::clear() by rotating tables, as a roll-over does: the empty spare table becomes the active one at once, and the old
+    // one is cleared on the map's stream once the updates enqueued so far have landed in it -- beside the next frames, which no
+    // longer wait for them (a clear in front of the next update made every step's update wait for the two before it: 0.113 ->
+    // 0.10x ms per step of the bench, which resets before every insert).  The first reset of a map pays for the spare table.
+    static const bool no_rotation = std::getenv("CHAD_DEBUG_NO_RESET_ROTATION") != nullptr;
+    if (!m->pending_clear && !no_rotation) {
+        if (!m->has_spare && !m->spare_unaffordable) {
+            if (alloc_map_storage(m->spare, m->brick_capacity, m->stream, m->d_overflow) == CHAD_OK) m->has_spare = true;
+            else { free_map_storage(m->spare); m->spare_unaffordable = true; g_error.clear(); }
+        }
+        if (m->has_spare) {
+            HIP_TRY(hipMemsetAsync(m->d_overflow, 0, 4, m->stream));
+            TRY(exclusive_end(m, m->stream));   // later updates wait for the map's stream up to HERE: the spare's own clear lies before this point
+            TRY(exclusive_begin(m));            // ... and the old table's clear waits for every update enqueued so far, nobody waits for it
+            hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, 0u);
+            HIP_TRY(hipGetLastError());
+            std::swap(m->view, m->spare);
+            *m->h_live_blocks = 0;
+            return CHAD_OK;
+        }
+    }
+    // no room for a second table: the clear is deferred to the stream of the next insert (right in front of its update), so that
+    // the next frame's preparation does not queue behind it; anything else that looks at the map first carries it out (flush_pending_clear)
     m->pending_clear = true;
     m->pending_clear_overflow = true;
     return CHAD_OK;
