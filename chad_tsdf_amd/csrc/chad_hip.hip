@@ -845,8 +845,9 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
                      points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
         record(m, T_SORT, prep);
-        static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 24;
-        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(256 * normal_waves_per_cu / kNormalWaves), dim3(64 * kNormalWaves), 0, prep, points0, points1, f.sort.keys[0], f.sort.keys[1], reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, big_groups);
+        static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 20;
+        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(256 * normal_waves_per_cu / kNormalWaves), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
+                     reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, big_groups);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -1823,13 +1824,13 @@ chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, floa
     if (!k) return CHAD_OK;
     std::vector<float> tmp(k * 4);
     if (order) {
-        HIP_TRY(hipMemcpy(tmp.data(), f.sort.points[m->h_hdr->sort_passes & 1u], k * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tmp.data(), f.sort.points[(m->h_hdr->sort_passes & 1u) ^ 1u], k * 16, hipMemcpyDeviceToHost));   // (k_frame_normals' ordered output)
         for (size_t i = 0; i < k; i++) std::memcpy(&order[i], &tmp[4 * i + 3], 4);
     }
     if (mc) {  // the codes are not kept (the frame kernels work from the sort keys): recompute them from the points
         uint64_t* d_mc = nullptr;
         HIP_TRY(hipMalloc(&d_mc, k * 8));
-        hipLaunchKernelGGL(k_morton_codes_of_points, grid_for(k, 256, 1 << 22), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(f.sort.points[m->h_hdr->sort_passes & 1u]),
+        hipLaunchKernelGGL(k_morton_codes_of_points, grid_for(k, 256, 1 << 22), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(f.sort.points[(m->h_hdr->sort_passes & 1u) ^ 1u]),
                            uint32_t(k), m->recip, d_mc);
         HIP_TRY(hipMemcpyAsync(mc, d_mc, k * 8, hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));

@@ -6,10 +6,13 @@
 // never crosses a change of code >> 6, and every block's first neighbourhood starts at the block's first
 // point), except one thing: the globally last point is never absorbed into a neighbourhood (normals.hpp:100).
 // So the device sorts by a SHORT key -- the position of the voxel's block inside the frame's bounding box (whose
-// corner is aligned to 8 voxels, so the block partition is that of the global code) followed by the voxel's low
-// 6 code bits -- and finds the reference's "last point" (smallest global code, largest input index among equals)
-// with a reduction.  A room-sized frame needs 3 radix passes instead of 8.
-// Inside a block the order is the reference's: descending voxel code, ties by ascending input index.
+// corner is aligned to 8 voxels, so the block partition is that of the global code) and nothing else -- and finds the
+// reference's "last point" (smallest global code, largest input index among equals) with a reduction.  A room-sized
+// frame needs 2 radix passes instead of 8 (16 key bits; with the voxel's six code bits in the key it was 3).
+// Inside a block the order must be the reference's -- descending voxel code, ties by ascending input index -- because
+// the neighbourhoods are runs of that order: the radix sort is stable, so a block's points arrive in input order, and
+// the normals kernel, which stages a block anyway, finishes the job with a stable counting sort by voxel (64 bins, in
+// LDS) and writes the block out in that order for the update kernel (estimate_block).
 // The ORDER OF THE BLOCKS is free, and is chosen for the update kernel: the block position is split into the
 // position of its 2x2x2-block "super block" (8x8x8 voxels, the unit the update kernel stages in LDS) and three bits
 // for the block inside it, so that the points of a super block are contiguous as well.
@@ -180,7 +183,7 @@ k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, F
 
 struct LocalFrame {  // geometry of the frame-local sort key
     int ox, oy, oz;          // super-block-aligned (8 voxels) corner of the frame's voxel bounds
-    uint32_t wx, wy, wz;     // bits needed for the super-block index along each axis
+    uint32_t nx, ny, nz;     // super blocks along each axis inside the bounds
     uint32_t bits, kept;     // bits of a usable key; usable points
     int lo[3], hi[3];
 };
@@ -216,24 +219,25 @@ __device__ __forceinline__ LocalFrame combine_bounds(const FramePartial* __restr
         }
         f.kept = uint32_t(red[0][6]) + uint32_t(red[1][6]) + uint32_t(red[2][6]) + uint32_t(red[3][6]);
         f.ox = f.lo[0] & ~7; f.oy = f.lo[1] & ~7; f.oz = f.lo[2] & ~7;  // align down to a super-block corner
-        // super-block index widths: super blocks 0 .. (hi - o) >> 3 along each axis; at most 18 bits (beyond 2^21
-        // voxels the reference's code aliases as well, morton.hpp:22)
-        auto width = [](int span_voxels) { const uint32_t last = uint32_t(span_voxels) >> 3; return last ? min(18u, 32u - uint32_t(__clz(last))) : 0u; };
-        f.wx = f.kept ? width(f.hi[0] - f.ox) : 0u; f.wy = f.kept ? width(f.hi[1] - f.oy) : 0u; f.wz = f.kept ? width(f.hi[2] - f.oz) : 0u;
-        f.bits = f.wx + f.wy + f.wz + 3u + 6u;
+        // super blocks 0 .. (hi - o) >> 3 along each axis, at most 2^18 of them (beyond 2^21 voxels the reference's code aliases as
+        // well, morton.hpp:22); their index is x + nx * (y + ny * z): mixed radix, not bit fields -- a 25 x 20 x 8 room is
+        // 4000 < 2^12 super blocks where bit fields need 13 bits, and that bit decides between two sort passes and three
+        auto extent = [](int span_voxels) { return min(uint32_t(span_voxels) >> 3, (1u << 18) - 1u) + 1u; };
+        f.nx = f.kept ? extent(f.hi[0] - f.ox) : 1u; f.ny = f.kept ? extent(f.hi[1] - f.oy) : 1u; f.nz = f.kept ? extent(f.hi[2] - f.oz) : 1u;
+        const unsigned long long last = (unsigned long long)f.nx * f.ny * f.nz - 1ull;
+        f.bits = (last ? 64u - uint32_t(__clzll((long long)last)) : 0u) + 3u;
         shared_frame = f;
     }
     __syncthreads();
     return shared_frame;
 }
 
-// Stage 2: sort keys.  key = [super-block index : wx + wy + wz bits][block in super block : 3 bits]
-// [63 - voxel in block : 6 bits], the super-block index being its x | y << wx | z << (wx + wy) position inside the
-// frame's bounds.  Ascending keys therefore group the points by super block, then by block, and order them by
-// descending voxel code inside a block (ties keep input order: the sort is stable); the order of the blocks themselves
-// is irrelevant (see the header of this file), so it need not be Morton order -- and a room-sized frame needs 22 key
-// bits (3 radix passes) instead of 3*8 + 1.  Unusable points get 2^bits, above every usable key, so they end up
-// behind the n_usable usable points.
+// Stage 2: sort keys.  key = [super-block index][block in super block : 3 bits], the super-block index being its
+// x + nx * (y + ny * z) position inside the frame's bounds.  Ascending keys therefore group the points by super block,
+// then by block; inside a block they keep input order (the sort is stable) and the normals kernel orders them by voxel.
+// The order of the blocks themselves is irrelevant (see the header of this file), so it need not be Morton order -- and
+// a room-sized frame needs 15 key bits + 1 (2 radix passes) instead of 3*8 + 1.  Unusable points get 2^bits, above every
+// usable key, so they end up behind the n_usable usable points.
 __global__ void __launch_bounds__(256)
 k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
              FramePartial* __restrict__ part, uint64_t* __restrict__ keys,
@@ -263,7 +267,6 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
     for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += blockDim.x) (&hist[0][0])[k] = 0;
     __syncthreads();
     const uint64_t top = 1ull << f.bits;
-    const uint32_t mask_x = (1u << f.wx) - 1u, mask_y = (1u << f.wy) - 1u, mask_z = (1u << f.wz) - 1u;
     unsigned long long mc_min = ~0ull;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const F3 p = load_point(xyz, i);
@@ -272,9 +275,9 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             const I3 v = voxel_of(p, recip);
             const unsigned long long mc = morton_encode(v.x, v.y, v.z);
             const uint32_t rx = uint32_t(v.x - f.ox), ry = uint32_t(v.y - f.oy), rz = uint32_t(v.z - f.oz);  // voxel inside the frame's bounds
-            const uint64_t sx = (rx >> 3) & mask_x, sy = (ry >> 3) & mask_y, sz = (rz >> 3) & mask_z;
+            const uint64_t sx = min(rx >> 3, f.nx - 1u), sy = min(ry >> 3, f.ny - 1u), sz = min(rz >> 3, f.nz - 1u);   // (clamped only beyond 2^21 voxels)
             const uint32_t inner = ((rx >> 2) & 1u) | (((ry >> 2) & 1u) << 1) | (((rz >> 2) & 1u) << 2);
-            key = ((((sx | (sy << f.wx) | (sz << (f.wx + f.wy))) << 3) | inner) << 6) | (63u - (uint32_t(mc) & 63u));
+            key = ((sx + f.nx * (sy + f.ny * sz)) << 3) | inner;
             mc_min = mc < mc_min ? mc : mc_min;
         }
         keys[i] = key;
@@ -303,19 +306,19 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
     }
 }
 
-// Length of the run of points of `block` (sort key >> 6) starting at `first`, capped at `limit`.
+// Length of the run of points of `block` (= the sort key of a usable point) starting at `first`, capped at `limit`.
 // Two dependent loads instead of one per 64 points: lanes first probe the starts of the next 64 chunks of 64
 // points, then the points of the chunk where the run ends.  Wave-uniform result.
 __device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ keys, uint32_t first, uint32_t limit, uint64_t block, uint32_t lane) {
     uint32_t len = 0;
     for (;;) {
         const uint32_t probe = first + len + 64u * (lane + 1u);                 // first point of chunk lane+1
-        const uint64_t more = __ballot(probe < limit && (keys[probe] >> 6) == block);
+        const uint64_t more = __ballot(probe < limit && keys[probe] == block);
         const uint32_t full = more == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~more)) - 1u;  // chunks 1..full start inside the run
         len += 64u * full;
         if (full == 64u) continue;                                               // the run is longer than 4160 points: go on
         const uint32_t i = first + len + lane;                                   // the chunk where the run ends
-        const uint64_t same = __ballot(i < limit && (keys[i] >> 6) == block);
+        const uint64_t same = __ballot(i < limit && keys[i] == block);
         return len + (same == ~0ull ? 64u : uint32_t(__ffsll((unsigned long long)~same)) - 1u);
     }
 }
@@ -375,7 +378,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
                 const uint64_t kcur = keys[i], kprev = i ? keys[i - 1] : ~0ull;   // nothing precedes point 0: it opens a block
                 const float4 q = pts[i];
                 const I3 v = voxel_of(F3{q.x, q.y, q.z}, recip);
-                const bool head = (kcur >> 6) != (kprev >> 6), super_head = (kcur >> 9) != (kprev >> 9);
+                const bool head = kcur != kprev, super_head = (kcur >> 3) != (kprev >> 3);   // key = [super block][block in it : 3]
                 if (head) atomicOr(&head_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (super_head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (v.x == v_min.x && v.y == v_min.y && v.z == v_min.z) atomicMax(&h->last_idx, __float_as_uint(q.w));   // a point of the frame's smallest code
@@ -410,7 +413,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             const int last_in_word = word ? int(lane * 32u) + 31 - __clz(int(word)) : -1;
             const int last_head = wave_max(last_in_word);
             uint32_t extra = 0;
-            if (last_head >= 0 && c + 1 < chunks) extra = run_length(keys, (c + 1u) * kGatherChunk, n, keys[c * kGatherChunk + uint32_t(last_head)] >> 6, lane);
+            if (last_head >= 0 && c + 1 < chunks) extra = run_length(keys, (c + 1u) * kGatherChunk, n, keys[c * kGatherChunk + uint32_t(last_head)], lane);
             if (lane == 0) trail_extra = extra;
         }
         __syncthreads();
@@ -473,18 +476,19 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
 // neighbourhood has < 8 points).
 
 constexpr uint32_t kMinPoints = 8;    // normals.hpp:88
+constexpr int kMaxNormalWaves = 4;    // waves that may share a point block (k_frame_normals' workgroup)
 constexpr uint32_t kStagePoints = 256;  // points of a block kept in LDS for the fits (4 KiB)
 constexpr uint32_t kTeamPoints = 16;    // neighbourhoods of 16..255 points are fitted by a 16-lane team (4 at a time)
 constexpr uint32_t kCoopPoints = 256;   // neighbourhoods at least this large are fitted by the whole wave
 
 struct NormalScratch {         // per wave, in LDS
-    uint32_t count[64];        // points per voxel of the block (index = low 6 code bits)
     uint32_t group_of[64];     // neighbourhood of voxel v
     uint32_t g_first[64];      // first point (offset in the segment) of neighbourhood g
     uint32_t g_size[64];
     float g_normal[64][4];     // fitted normal; [3] != 0 marks "fit" (else per-point fallback)
     uint32_t team_list[64];    // neighbourhoods fitted by 16-lane teams
-    float4 stage[kStagePoints];  // the block's first points (x, y, z, input index)
+    uint32_t run[kMaxNormalWaves][64];   // counting sort by voxel: wave w's points per voxel, then the next free position of voxel v for wave w
+    float4 stage[kStagePoints];  // the block's first points IN VOXEL ORDER (x, y, z, input index)
 };
 
 // normals.hpp:39-79 -- normal from the covariance terms: three determinant-weighted axis directions, each aligned
@@ -586,50 +590,93 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // everything (the other waves of the workgroup work on other blocks, nothing is shared).  kTeam true: the whole workgroup of four
 // waves -- the two passes over the points, the team fits and the whole-wave fits are dealt over the waves; the greedy walk is
 // repeated by every wave (it runs in registers on the 64 voxel counters) and only wave 0 publishes it.
+// low six code bits of a point's voxel: its place inside the 4x4x4 block (x -> bit 0, y -> bit 1, z -> bit 2, twice)
+__device__ __forceinline__ uint32_t voxel_in_block(float4 q, float recip) {
+    const I3 v = voxel_of(F3{q.x, q.y, q.z}, recip);
+    const uint32_t x = uint32_t(v.x) & 3u, y = uint32_t(v.y) & 3u, z = uint32_t(v.z) & 3u;
+    return (x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2) | ((x >> 1) << 3) | ((y >> 1) << 4) | ((z >> 1) << 5);
+}
+
 template <bool kTeam>
-__device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 record, const float4* __restrict__ pts, const uint64_t* __restrict__ keys, uint32_t n, F3 pos,
-                                               float4* __restrict__ normals, uint32_t ablate) {
+__device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 record, const float4* __restrict__ pts, float4* __restrict__ ordered, float recip,
+                                               F3 pos, float4* __restrict__ normals, uint32_t ablate) {
     const uint32_t lane = threadIdx.x & 63u, wave = kTeam ? threadIdx.x >> 6 : 0u;
     const uint32_t tid = kTeam ? threadIdx.x : lane, stride = kTeam ? 64u * kNormalWaves : 64u, waves = kTeam ? uint32_t(kNormalWaves) : 1u;
     auto sync = [&]() { if (kTeam) __syncthreads(); else wave_lds_fence(); };
-    const uint32_t first = record.x;
-    uint32_t len = record.y & 0x7fffffffu;
-    if (len == 0u) len = run_length(keys, first, n, keys[first] >> 6, lane);   // (k_frame_gather measures every block now; kept for safety)
+    const uint32_t first = record.x, len = record.y & 0x7fffffffu;
     if ((ablate >> 16) && len > (ablate >> 16)) return;   // timing experiment: blocks above a size are skipped (results are wrong)
-    // normals.hpp:100 -- the frame's last point never joins a neighbourhood; it is the last point of this segment
+    // normals.hpp:100 -- the frame's last point never joins a neighbourhood.  It is the point with the smallest code and, among
+    // those, the largest input index (k_frame_gather: last_idx): the LAST point of this block in the reference's order.
     const bool holds_last = (record.y >> 31) != 0u;
     const uint32_t grouped = holds_last ? len - 1 : len;
 
-    // pass 1 over the block: voxel histogram in LDS, first kStagePoints points staged in LDS
-    if (tid < 64u) s.count[tid] = 0;
+    // ---- the block in the reference's order: a stable counting sort by voxel, descending (the radix sort delivered input order) ----
+    // Every wave takes a contiguous share of the block (a multiple of 64 points): the shares keep their order, and inside a
+    // share the 64-point steps do.  Pass 1: points per (wave, voxel).
+    const uint32_t share = ((len + waves - 1u) / waves + 63u) & ~63u, begin = wave * share, end = min(len, begin + share);
+    for (uint32_t k = tid; k < waves * 64u; k += stride) (&s.run[0][0])[k] = 0u;
     sync();
-    for (uint32_t k = tid; k < len; k += stride) {
-        const uint32_t v = 63u - (uint32_t(keys[first + k]) & 63u);
-        if (k < kStagePoints) s.stage[k] = pts[first + k];
-        if (k < grouped) atomicAdd(&s.count[v], 1u);
-    }
+    for (uint32_t k = begin + lane; k < end; k += 64u) atomicAdd(&s.run[wave][voxel_in_block(pts[first + k], recip)], 1u);
     sync();
-
-    // greedy neighbourhood walk (normals.hpp:86-138) over the voxel runs, in registers: lane l holds voxel 63 - l,
-    // the order the points are in.  before = points in higher voxels, upto = before + own.
-    const uint32_t own = s.count[63 - lane];
+    // lane l holds voxel 63 - l, the order the points go in.  before = points in higher voxels, upto = before + own.
+    uint32_t own = 0, mine_before = 0;   // points of this lane's voxel in the whole block / in the shares of lower waves
+#pragma unroll
+    for (uint32_t w = 0; w < uint32_t(kNormalWaves); w++)
+        if (w < waves) { const uint32_t c = s.run[w][63u - lane]; if (w < wave) mine_before += c; own += c; }
     uint32_t upto = own;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(upto, o); if (int(lane) >= o) upto += t; }
     const uint32_t before = upto - own;
-    uint64_t rest = (ablate & 64u) ? 0ull : __ballot(own != 0);  // voxel runs not yet in a neighbourhood
+    sync();                                   // (every wave has read the counts)
+    s.run[wave][63u - lane] = before + mine_before;   // next free position of this voxel for this wave's share
+    sync();
+    // Pass 2: every point to its position -- the staged copy in LDS for the first kStagePoints positions, and the frame's ordered
+    // point array (what the update kernel reads).  Inside a step the lanes holding one voxel rank themselves by ballots.
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    for (uint32_t k0 = begin; k0 < end; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        const bool live = k < end;
+        const float4 q = live ? pts[first + k] : make_float4(0, 0, 0, 0);
+        const uint32_t v = live ? voxel_in_block(q, recip) : 0u;
+        uint64_t same = __ballot(live);
+#pragma unroll
+        for (uint32_t bit = 0; bit < 6; bit++) { const bool b = (v >> bit) & 1u; const uint64_t vote = __ballot(b); same &= b ? vote : ~vote; }
+        if (live) {
+            const uint32_t leader = uint32_t(__ffsll((unsigned long long)same)) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) { base = s.run[wave][v]; s.run[wave][v] = base + uint32_t(__popcll(same)); }
+            base = __shfl(base, int(leader));
+            const uint32_t at = base + uint32_t(__popcll(same & lanes_below));
+            ordered[first + at] = q;
+            if (at < kStagePoints) s.stage[at] = q;
+        }
+        wave_lds_fence();   // the next step's leaders read what this step's leaders wrote
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // positions beyond the staged ones are read back from `ordered` below (by every wave of a team)
+    sync();
+
+    // greedy neighbourhood walk (normals.hpp:86-138) over the voxel runs, in registers.  The last point (if this block holds it)
+    // sits in the lowest occupied voxel: that voxel counts one point less.
+    const uint64_t occupied = __ballot(own != 0u);
+    const uint32_t lowest = occupied ? 63u - uint32_t(__clzll((long long)occupied)) : 0u;   // highest lane with points = lowest voxel
+    const uint32_t cnt = own - ((holds_last && lane == lowest && own != 0u) ? 1u : 0u);
+    uint32_t cupto = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(cupto, o); if (int(lane) >= o) cupto += t; }
+    const uint32_t cbefore = cupto - cnt;     // (== before everywhere: the missing point is the very last one)
+    uint64_t rest = (ablate & 64u) ? 0ull : __ballot(cnt != 0);  // voxel runs not yet in a neighbourhood
     uint32_t ngroups = 0, my_group = 0, nteams = 0, ncoop = 0;
     while (rest) {
         const uint32_t l = uint32_t(__ffsll((unsigned long long)rest)) - 1u;  // highest remaining voxel
-        const uint32_t start = read_lane(before, l);
-        uint32_t size = read_lane(own, l);
+        const uint32_t start = read_lane(cbefore, l);
+        uint32_t size = read_lane(cnt, l);
         uint32_t l_end = l;                            // lane of the lowest voxel taken into the neighbourhood
         if (size < kMinPoints) {                       // depth 1: the rest of the 2x2x2 octant (voxel & ~7)
             l_end = l | 7u;
-            size = read_lane(upto, l_end) - start;
+            size = read_lane(cupto, l_end) - start;
             if (size < kMinPoints) {                   // depth 2: the rest of the block
                 l_end = 63u;
-                size = read_lane(upto, 63u) - start;
+                size = read_lane(cupto, 63u) - start;
             }
         }
         if (lane == 0 && wave == 0) {
@@ -644,6 +691,7 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
     }
     if (wave == 0) s.group_of[63 - lane] = my_group;
     sync();
+    const float4* __restrict__ sorted = ordered + first;   // the block in order (written above; positions below kStagePoints are in LDS too)
 
     // large neighbourhoods: a whole wave each, one after the other (dealt over the waves of a team)
     if (ncoop && !(ablate & 8u)) {
@@ -652,9 +700,9 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
             const uint32_t g0 = s.g_first[g], gn = s.g_size[g];
             if (gn < kCoopPoints) continue;
             if ((turn++ % waves) != wave) continue;
-            F3 nrm = g0 + gn <= kStagePoints ? fit_plane_wave(&s.stage[g0], gn, lane) : fit_plane_wave(pts + first + g0, gn, lane);
+            F3 nrm = g0 + gn <= kStagePoints ? fit_plane_wave(&s.stage[g0], gn, lane) : fit_plane_wave(sorted + g0, gn, lane);
             if (lane == 0) {
-                const float4 q = pts[first + g0];
+                const float4 q = g0 < kStagePoints ? s.stage[g0] : sorted[g0];
                 const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
                 if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
                 s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
@@ -670,11 +718,11 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
             const bool on = tg < nteams;
             const uint32_t g = on ? s.team_list[tg] : 0u;
             const uint32_t g0 = s.g_first[g], gn = on ? s.g_size[g] : 0u;
-            auto point = [&](uint32_t k) { const uint32_t at = g0 + k; return at < kStagePoints ? s.stage[at] : pts[first + at]; };
+            auto point = [&](uint32_t k) { const uint32_t at = g0 + k; return at < kStagePoints ? s.stage[at] : sorted[at]; };
             double cx = 0, cy = 0, cz = 0;
             for (uint32_t k = tl; k < gn; k += 16) { const float4 q = point(k); cx += double(q.x); cy += double(q.y); cz += double(q.z); }
-            const double recip = 1.0 / double(gn);
-            cx = team_sum_f64(cx) * recip; cy = team_sum_f64(cy) * recip; cz = team_sum_f64(cz) * recip;
+            const double rcp = 1.0 / double(gn);
+            cx = team_sum_f64(cx) * rcp; cy = team_sum_f64(cy) * rcp; cz = team_sum_f64(cz) * rcp;
             double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
             for (uint32_t k = tl; k < gn; k += 16) {
                 const float4 q = point(k);
@@ -684,7 +732,7 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
             xx = team_sum_f64(xx); xy = team_sum_f64(xy); xz = team_sum_f64(xz);
             yy = team_sum_f64(yy); yz = team_sum_f64(yz); zz = team_sum_f64(zz);
             if (on && tl == 0) {
-                F3 nrm = plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
+                F3 nrm = plane_from_covariance(xx * rcp, xy * rcp, xz * rcp, yy * rcp, yz * rcp, zz * rcp);
                 const float4 q = point(0);
                 const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
                 if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
@@ -700,8 +748,8 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
         F3 nrm{0, 0, 0};
         if (gn >= kMinPoints && !(ablate & 16u)) {
             const bool staged = g0 + gn <= kStagePoints;
-            nrm = staged ? fit_plane(&s.stage[g0], gn) : fit_plane(pts + first + g0, gn);
-            const float4 q = staged ? s.stage[g0] : pts[first + g0];
+            nrm = staged ? fit_plane(&s.stage[g0], gn) : fit_plane(sorted + g0, gn);
+            const float4 q = staged ? s.stage[g0] : sorted[g0];
             const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
             if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
             fit = 1.0f;
@@ -710,17 +758,15 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
     }
     sync();
     for (uint32_t k = tid; k < ((ablate & 32u) ? 0u : len); k += stride) {
+        const float4 q = k < kStagePoints ? s.stage[k] : sorted[k];
         F3 nrm;
         bool fitted = false;
         if (k < grouped) {
-            const uint32_t g = s.group_of[63u - (uint32_t(keys[first + k]) & 63u)];
+            const uint32_t g = s.group_of[voxel_in_block(q, recip)];
             fitted = s.g_normal[g][3] != 0.0f;
             nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
         }
-        if (!fitted) {
-            const float4 q = k < kStagePoints ? s.stage[k] : pts[first + k];
-            nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
-        }
+        if (!fitted) nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
         normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
     }
     sync();
@@ -730,14 +776,13 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
 // kBigBlock points: k_frame_gather lists them), one block at a time with all four waves; every other wave takes small blocks, one
 // wave per block, the waves of a workgroup sharing nothing.  (The large workgroups have the lowest indices, so they start first:
 // they are the kernel's long pole.)
-__global__ void __launch_bounds__(64 * kNormalWaves, 6)  // <= 80 VGPRs: 24 waves per CU, what the 6.4 KiB of LDS per wave allows
-k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ points1, const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+__global__ void __launch_bounds__(64 * kNormalWaves, 5)  // <= 96 VGPRs: 20 waves per CU (7.2 KiB of LDS per wave)
+k_frame_normals(float4* __restrict__ points0, float4* __restrict__ points1, float recip,
                 const uint2* __restrict__ segments, uint32_t list_stride,
                 FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate, uint32_t big_block, uint32_t max_big_groups) {
     __shared__ NormalScratch scratch[kNormalWaves];
-    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
-    // ... and their keys: key >> 6 is the point's block, 63 - (key & 63) its voxel in the block (the low 6 code bits)
-    const uint64_t* __restrict__ keys = (h->sort_passes & 1u) ? keys1 : keys0;
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points: by block, input order inside
+    float4* __restrict__ ordered = (h->sort_passes & 1u) ? points0 : points1;     // the sort's other buffer: the same blocks, each in the reference's order
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // where each stripe's entries begin in the two block lists (all blocks from the front of a stripe, the large ones again from its
     // back), in LDS: kept in registers the thirty-four prefix sums spill
@@ -773,7 +818,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
             for (uint32_t b = blockIdx.x; b < nbig; b += big_groups) {
                 uint32_t index;
                 const uint32_t stripe = locate(1u, b, &index);
-                estimate_block<true>(scratch[0], segments[(stripe + 1u) * list_stride - 1u - index], pts, keys, n, pos, normals, ablate);
+                estimate_block<true>(scratch[0], segments[(stripe + 1u) * list_stride - 1u - index], pts, ordered, recip, pos, normals, ablate);
             }
             return;
         }
@@ -784,7 +829,7 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
         for (uint32_t seg = my_wave; seg < nseg; seg += all_waves) {
             const uint2 record = segment(seg);
             if (big_groups && (record.y & 0x7fffffffu) > big_block) continue;   // a large block: the workgroups above
-            estimate_block<false>(s, record, pts, keys, n, pos, normals, ablate);
+            estimate_block<false>(s, record, pts, ordered, recip, pos, normals, ablate);
         }
         return;
     }
@@ -800,15 +845,22 @@ k_frame_normals(const float4* __restrict__ points0, const float4* __restrict__ p
         const uint2 record = mine < nseg ? segment(mine) : make_uint2(0u, 0u);
         const uint32_t len = record.y & 0x7fffffffu;
         const bool small = mine < nseg && len != 0u && len < kMinPoints;
-        if (small)
+        if (small)   // the block's points into the reference's order (descending voxel, ties in input order = arrival order) by counting, then the fallback normal
             for (uint32_t k = 0; k < len; k++) {
                 const float4 q = pts[record.x + k];
+                const uint32_t v = voxel_in_block(q, recip);
+                uint32_t at = 0;
+                for (uint32_t j = 0; j < len; j++) {
+                    const uint32_t u = voxel_in_block(pts[record.x + j], recip);
+                    at += (u > v || (u == v && j < k)) ? 1u : 0u;
+                }
                 const F3 nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
-                normals[record.x + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+                ordered[record.x + at] = q;
+                normals[record.x + at] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
             }
         for (uint64_t big = __ballot(mine < nseg && !small); big; big &= big - 1ull) {
             const uint32_t l = uint32_t(__ffsll((unsigned long long)big)) - 1u;
-            estimate_block<false>(s, make_uint2(read_lane(record.x, l), read_lane(record.y, l)), pts, keys, n, pos, normals, ablate);
+            estimate_block<false>(s, make_uint2(read_lane(record.x, l), read_lane(record.y, l)), pts, ordered, recip, pos, normals, ablate);
         }
     }
 }

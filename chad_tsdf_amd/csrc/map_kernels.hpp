@@ -126,7 +126,7 @@ __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, c
 __global__ void __launch_bounds__(256)
 k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
                  F3 pos, float res, float recip, float trunc, MapView m) {
-    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order: k_frame_normals' output (the sort's other buffer)
     scatter_update(pts, normals, h, pos, res, recip, trunc, m);
 }
 

@@ -94,7 +94,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
                FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t items_capacity /* entries per stripe of items[] */,
                unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
-    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order: k_frame_normals' output (the sort's other buffer)
     if (adaptive && frame_is_sparse(h)) {  // about one point per block: staging tiles is pure overhead, take the general form
         scatter_update(pts, normals, h, pos, res, recip, trunc, m);
         return;
