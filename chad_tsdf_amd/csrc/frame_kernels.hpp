@@ -612,11 +612,43 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
 
     // ---- the block in the reference's order: a stable counting sort by voxel, descending (the radix sort delivered input order) ----
     // Every wave takes a contiguous share of the block (a multiple of 64 points): the shares keep their order, and inside a
-    // share the 64-point steps do.  Pass 1: points per (wave, voxel).
+    // share the 64-point steps do.  A share of at most kKeep steps (every block of up to 256 points, every team block of up to
+    // 1024) is read ONCE: the points stay in registers and each gets its rank among the share's points of its voxel as the
+    // steps go by (the lanes holding one voxel rank themselves by ballots; the step's first such lane keeps the count).  Longer
+    // shares are counted first and ranked in a second pass over the points.
+    constexpr uint32_t kKeep = 4;
     const uint32_t share = ((len + waves - 1u) / waves + 63u) & ~63u, begin = wave * share, end = min(len, begin + share);
+    const bool kept = share <= 64u * kKeep;   // (uniform over the team)
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    auto same_voxel = [&](uint32_t v, bool live) {   // lanes of this wave whose point lies in the same voxel
+        uint64_t same = __ballot(live);
+#pragma unroll
+        for (uint32_t bit = 0; bit < 6; bit++) { const bool b = (v >> bit) & 1u; const uint64_t vote = __ballot(b); same &= b ? vote : ~vote; }
+        return same;
+    };
     for (uint32_t k = tid; k < waves * 64u; k += stride) (&s.run[0][0])[k] = 0u;
     sync();
-    for (uint32_t k = begin + lane; k < end; k += 64u) atomicAdd(&s.run[wave][voxel_in_block(pts[first + k], recip)], 1u);
+    float4 q[kKeep];
+    uint32_t vr[kKeep];   // voxel | rank among the share's points of that voxel << 8
+    if (kept) {
+#pragma unroll
+        for (uint32_t j = 0; j < kKeep; j++) { const uint32_t k = begin + 64u * j + lane; q[j] = k < end ? pts[first + k] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+        for (uint32_t j = 0; j < kKeep; j++) {
+            const bool live = begin + 64u * j + lane < end;
+            const uint32_t v = live ? voxel_in_block(q[j], recip) : 0u;
+            const uint64_t same = same_voxel(v, live);
+            vr[j] = 0u;
+            if (live) {
+                const uint32_t leader = uint32_t(__ffsll((unsigned long long)same)) - 1u;
+                uint32_t base = 0;
+                if (lane == leader) { base = s.run[wave][v]; s.run[wave][v] = base + uint32_t(__popcll(same)); }
+                vr[j] = v | ((uint32_t(__shfl(base, int(leader))) + uint32_t(__popcll(same & lanes_below))) << 8);
+            }
+            wave_lds_fence();   // the next step's leaders read what this step's leaders wrote
+        }
+    } else
+        for (uint32_t k = begin + lane; k < end; k += 64u) atomicAdd(&s.run[wave][voxel_in_block(pts[first + k], recip)], 1u);
     sync();
     // lane l holds voxel 63 - l, the order the points go in.  before = points in higher voxels, upto = before + own.
     uint32_t own = 0, mine_before = 0;   // points of this lane's voxel in the whole block / in the shares of lower waves
@@ -628,31 +660,36 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(upto, o); if (int(lane) >= o) upto += t; }
     const uint32_t before = upto - own;
     sync();                                   // (every wave has read the counts)
-    s.run[wave][63u - lane] = before + mine_before;   // next free position of this voxel for this wave's share
+    s.run[wave][63u - lane] = before + mine_before;   // first position of this voxel's points from this wave's share
     sync();
-    // Pass 2: every point to its position -- the staged copy in LDS for the first kStagePoints positions, and the frame's ordered
-    // point array (what the update kernel reads).  Inside a step the lanes holding one voxel rank themselves by ballots.
-    const uint64_t lanes_below = (1ull << lane) - 1ull;
-    for (uint32_t k0 = begin; k0 < end; k0 += 64u) {
-        const uint32_t k = k0 + lane;
-        const bool live = k < end;
-        const float4 q = live ? pts[first + k] : make_float4(0, 0, 0, 0);
-        const uint32_t v = live ? voxel_in_block(q, recip) : 0u;
-        uint64_t same = __ballot(live);
+    // every point to its position -- the staged copy in LDS for the first kStagePoints positions, and the frame's ordered point
+    // array (what the update kernel reads)
+    if (kept) {
 #pragma unroll
-        for (uint32_t bit = 0; bit < 6; bit++) { const bool b = (v >> bit) & 1u; const uint64_t vote = __ballot(b); same &= b ? vote : ~vote; }
-        if (live) {
-            const uint32_t leader = uint32_t(__ffsll((unsigned long long)same)) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) { base = s.run[wave][v]; s.run[wave][v] = base + uint32_t(__popcll(same)); }
-            base = __shfl(base, int(leader));
-            const uint32_t at = base + uint32_t(__popcll(same & lanes_below));
-            ordered[first + at] = q;
-            if (at < kStagePoints) s.stage[at] = q;
+        for (uint32_t j = 0; j < kKeep; j++)
+            if (begin + 64u * j + lane < end) {
+                const uint32_t at = s.run[wave][vr[j] & 63u] + (vr[j] >> 8);
+                ordered[first + at] = q[j];
+                if (at < kStagePoints) s.stage[at] = q[j];
+            }
+    } else
+        for (uint32_t k0 = begin; k0 < end; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            const bool live = k < end;
+            const float4 p = live ? pts[first + k] : make_float4(0, 0, 0, 0);
+            const uint32_t v = live ? voxel_in_block(p, recip) : 0u;
+            const uint64_t same = same_voxel(v, live);
+            if (live) {
+                const uint32_t leader = uint32_t(__ffsll((unsigned long long)same)) - 1u;
+                uint32_t base = 0;
+                if (lane == leader) { base = s.run[wave][v]; s.run[wave][v] = base + uint32_t(__popcll(same)); }
+                const uint32_t at = uint32_t(__shfl(base, int(leader))) + uint32_t(__popcll(same & lanes_below));
+                ordered[first + at] = p;
+                if (at < kStagePoints) s.stage[at] = p;
+            }
+            wave_lds_fence();
         }
-        wave_lds_fence();   // the next step's leaders read what this step's leaders wrote
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // positions beyond the staged ones are read back from `ordered` below (by every wave of a team)
+    if (len > kStagePoints) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // positions beyond the staged ones are read back from `ordered` below (by every wave of a team)
     sync();
 
     // greedy neighbourhood walk (normals.hpp:86-138) over the voxel runs, in registers.  The last point (if this block holds it)
