@@ -40,8 +40,8 @@ struct FrameHeader {
     uint32_t axis_bits;         // bits of a usable sort key
     uint32_t sort_passes;       // radix passes needed: ceil((axis_bits + 1 if any point is unusable) / 8)
     uint32_t reserved1;
-    unsigned long long mc_min;  // smallest global Morton code of the frame ...
-    uint32_t last_idx;          // ... and the largest input index among the points having it (normals.hpp:100)
+    unsigned long long mc_min;  // smallest global Morton code of the frame: its block holds the reference's last point (normals.hpp:100),
+    uint32_t last_idx;          // (unused: that point is simply the last one of its block in the reference's order)
     uint32_t reserved0;
     uint32_t reserved2, reserved3;
     unsigned long long n_updates[kUpdateStripes * 16];  // voxel updates applied by the last insert, striped over cache lines
@@ -139,6 +139,21 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 
 __device__ __forceinline__ F3 load_point(const float* __restrict__ xyz, size_t i) { return {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}; }
 
+// The frame's points four at a time: three 16-byte loads per lane (48 contiguous bytes) instead of twelve 4-byte ones at a stride
+// of 12 -- when the array is 16-byte aligned (any hipMalloc-ed buffer).  visit(i, p) is called for every point; the last n % 4
+// points, or all of them when the array is not aligned, go one by one.
+template <class Visit>
+__device__ __forceinline__ void for_each_point(const float* __restrict__ xyz, uint32_t n, Visit visit) {
+    const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x, threads = size_t(gridDim.x) * blockDim.x;
+    const uint32_t quads = (reinterpret_cast<uintptr_t>(xyz) & 15u) == 0u ? n / 4u : 0u;
+    const float4* __restrict__ wide = reinterpret_cast<const float4*>(xyz);
+    for (size_t g = t; g < quads; g += threads) {
+        const float4 a = wide[3 * g], b = wide[3 * g + 1], c = wide[3 * g + 2];
+        visit(4 * g, F3{a.x, a.y, a.z}); visit(4 * g + 1, F3{a.w, b.x, b.y}); visit(4 * g + 2, F3{b.z, b.w, c.x}); visit(4 * g + 3, F3{c.y, c.z, c.w});
+    }
+    for (size_t i = size_t(quads) * 4 + t; i < n; i += threads) visit(i, load_point(xyz, i));
+}
+
 // Stage 1: voxel bounds and the count of usable points, one partial per workgroup.
 __global__ void __launch_bounds__(256)
 k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FramePartial* __restrict__ part, uint32_t* __restrict__ digit_total) {
@@ -147,15 +162,14 @@ k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, F
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < kBaseStripes * kMaxPasses * kRadix; k += gridDim.x * blockDim.x) digit_total[k] = 0u;
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {int(0x80000000), int(0x80000000), int(0x80000000)};
     uint32_t kept = 0;
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
-        const F3 p = load_point(xyz, i);
+    for_each_point(xyz, n, [&](size_t, F3 p) {
         if (point_usable(p, pos, recip)) {
             const I3 v = voxel_of(p, recip);
             lo[0] = min(lo[0], v.x); lo[1] = min(lo[1], v.y); lo[2] = min(lo[2], v.z);
             hi[0] = max(hi[0], v.x); hi[1] = max(hi[1], v.y); hi[2] = max(hi[2], v.z);
             kept++;
         }
-    }
+    });
 #pragma unroll
     for (int a = 0; a < 3; a++) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
     kept = wave_sum(kept);
@@ -268,8 +282,7 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
     __syncthreads();
     const uint64_t top = 1ull << f.bits;
     unsigned long long mc_min = ~0ull;
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
-        const F3 p = load_point(xyz, i);
+    for_each_point(xyz, n, [&](size_t i, F3 p) {
         uint64_t key = top;
         if (point_usable(p, pos, recip)) {
             const I3 v = voxel_of(p, recip);
@@ -281,8 +294,8 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             mc_min = mc < mc_min ? mc : mc_min;
         }
         keys[i] = key;
-        for (uint32_t p = 0; p < passes; p++) atomicAdd(&hist[p][uint32_t(key >> (p * kRadixBits)) & (kRadix - 1)], 1u);
-    }
+        for (uint32_t pass = 0; pass < passes; pass++) atomicAdd(&hist[pass][uint32_t(key >> (pass * kRadixBits)) & (kRadix - 1)], 1u);
+    });
     __syncthreads();
     // digit totals of the radix passes (RadixSortBuffers::digit_base): one of kBaseStripes copies per workgroup, zero counts skipped
     for (uint32_t p = 0; p < passes; p++) {
@@ -359,7 +372,6 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
         __syncthreads();
     }
     const unsigned long long mc_min = block_mc_min;
-    const I3 v_min = morton_decode(mc_min);   // the voxel of the frame's smallest code (wave-uniform)
     const uint32_t n = h->n_usable;
     const bool odd = h->sort_passes & 1u;
     const uint64_t* keys = odd ? keys1 : keys0;
@@ -376,12 +388,9 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             const uint32_t i = c * kGatherChunk + j * 256 + threadIdx.x;
             if (i < n) {
                 const uint64_t kcur = keys[i], kprev = i ? keys[i - 1] : ~0ull;   // nothing precedes point 0: it opens a block
-                const float4 q = pts[i];
-                const I3 v = voxel_of(F3{q.x, q.y, q.z}, recip);
                 const bool head = kcur != kprev, super_head = (kcur >> 3) != (kprev >> 3);   // key = [super block][block in it : 3]
                 if (head) atomicOr(&head_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
                 if (super_head || (i % kItemPoints) == 0) atomicOr(&mark_bits[(j * 256 + threadIdx.x) >> 5], 1u << (threadIdx.x & 31u));
-                if (v.x == v_min.x && v.y == v_min.y && v.z == v_min.z) atomicMax(&h->last_idx, __float_as_uint(q.w));   // a point of the frame's smallest code
             }
         }
         __syncthreads();
@@ -606,7 +615,7 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
     const uint32_t first = record.x, len = record.y & 0x7fffffffu;
     if ((ablate >> 16) && len > (ablate >> 16)) return;   // timing experiment: blocks above a size are skipped (results are wrong)
     // normals.hpp:100 -- the frame's last point never joins a neighbourhood.  It is the point with the smallest code and, among
-    // those, the largest input index (k_frame_gather: last_idx): the LAST point of this block in the reference's order.
+    // those, the largest input index: the LAST point of this block in the reference's order.
     const bool holds_last = (record.y >> 31) != 0u;
     const uint32_t grouped = holds_last ? len - 1 : len;
 
