@@ -487,7 +487,7 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
 constexpr uint32_t kMinPoints = 8;    // normals.hpp:88
 constexpr int kMaxNormalWaves = 4;    // waves that may share a point block (k_frame_normals' workgroup)
 constexpr uint32_t kStagePoints = 256;  // points of a block kept in LDS for the fits (4 KiB)
-constexpr uint32_t kTeamPoints = 16;    // neighbourhoods of 16..255 points are fitted by a 16-lane team (4 at a time)
+constexpr uint32_t kTeamPoints = 16;    // neighbourhoods of 16..255 points are fitted by a 16-lane team (4 at a time); from 8 on: no faster, and the one-lane fits keep the reference's summation order
 constexpr uint32_t kCoopPoints = 256;   // neighbourhoods at least this large are fitted by the whole wave
 
 struct NormalScratch {         // per wave, in LDS

@@ -9,7 +9,7 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out"; mkdir -p "$out"
-B="--no-extras --cpu-seconds 0"
+B="--no-extras --cpu-seconds 0 --frames-per-step 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 $B > "$out/bench_trace.log" 2>&1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 bench.py --steps 6 --warmup 2 $B > "$out/bench_fetch.log" 2>&1
