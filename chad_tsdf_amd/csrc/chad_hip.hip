@@ -24,6 +24,7 @@
 #include "mesh_kernels.hpp"
 #include "query_kernels.hpp"
 #include "radix_sort.hpp"
+#include "staging.hpp"
 #include "tile_update.hpp"
 
 using namespace chadhip;
@@ -186,6 +187,7 @@ struct chad_map {
     uint64_t frames_empty_tail = 0;               // empty inserts since the last one with points (they use no slot)
     // Frame-sharded multi-GPU map (chad_map_attach_comm): insert k of the stream is integrated by rank k % world only, and a
     // submap is closed by merging the ranks' partial bricks (merge_and_close) instead of archiving the local ones.
+    std::unique_ptr<CopyPool> copy_pool;          // helper threads of chad_map_insert's staging copy (made by the first large host frame)
     chad_comm* comm = nullptr;
     uint64_t stream_frames = 0;                   // inserts seen since the communicator was attached
     // The exchange runs like the local archive: beside the next frames.  The closing table is this rank's share; three stages, each
@@ -1116,12 +1118,23 @@ chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float
         // returns as soon as the last chunk is staged, and the host copy of frame k+1 overlaps the kernels of frame k.
         if (!f.h_stage) HIP_TRY(hipHostMalloc(&f.h_stage, f.cap_points * 12, hipHostMallocDefault));
         else HIP_TRY(hipEventSynchronize(f.stage_done));  // its previous frame (two inserts ago) has left the buffer
-        const size_t chunk = size_t(1) << 18;  // points per chunk (3 MiB)
-        for (size_t at = 0; at < n; at += chunk) {
-            const size_t len = std::min(chunk, n - at);
-            std::memcpy(f.h_stage + 3 * at, xyz + 3 * at, len * 12);
-            HIP_TRY(hipMemcpyAsync(f.d_xyz + 3 * at, f.h_stage + 3 * at, len * 12, hipMemcpyHostToDevice, f.prep));
-        }
+        static const size_t chunk = std::getenv("CHAD_STAGE_CHUNK_KB") ? size_t(std::atoi(std::getenv("CHAD_STAGE_CHUNK_KB"))) << 10 : size_t(2) << 20;  // bytes per chunk (scripts/host_insert_sweep.py)
+        static const int helpers = std::getenv("CHAD_STAGE_THREADS") ? std::max(0, std::atoi(std::getenv("CHAD_STAGE_THREADS")) - 1) : 1;   // one helper beside the caller: 0.57 -> 0.40 ms per 12 MB frame; a third thread gains nothing (the DMA is the bound then)
+        const char* src = reinterpret_cast<const char*>(xyz);
+        char* pinned = reinterpret_cast<char*>(f.h_stage);
+        char* device = reinterpret_cast<char*>(f.d_xyz);
+        hipError_t dma = hipSuccess;
+        auto start_dma = [&](size_t at, size_t len) { if (dma == hipSuccess) dma = hipMemcpyAsync(device + at, pinned + at, len, hipMemcpyHostToDevice, f.prep); };
+        if (helpers > 0 && n * 12 >= 3 * chunk) {   // a helper thread shares the copy (one thread: ~25 GB/s; the DMA: ~30-50)
+            if (!m->copy_pool) m->copy_pool.reset(new CopyPool(helpers));
+            m->copy_pool->copy(src, pinned, n * 12, chunk, start_dma);
+        } else
+            for (size_t at = 0; at < n * 12; at += chunk) {
+                const size_t len = std::min(chunk, n * 12 - at);
+                std::memcpy(pinned + at, src + at, len);
+                start_dma(at, len);
+            }
+        HIP_TRY(dma);
         HIP_TRY(hipEventRecord(f.stage_done, f.prep));
     }
     return insert_device(m, f, f.d_xyz, n, position);
