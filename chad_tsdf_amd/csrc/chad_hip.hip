@@ -1730,6 +1730,7 @@ void weld_mesh(const std::vector<float>& soup, std::vector<float>& vertices, std
 
 // sorted block keys and per-voxel means (NaN = no leaf) of a submap on the device
 chad_status mesh_source(chad_map* m, int32_t submap, DevBuf& keys_sorted, DevBuf& means, uint32_t* blocks_out) {
+    TRY(finish_closing(m, true));   // (a roll-over still in progress: its archive may be released right behind it, CHAD_FLAG_DAG_ONLY)
     const bool from_dag = submap >= 0 && ((m->flags & CHAD_FLAG_MESH_FROM_DAG) || (size_t(submap) < m->closed.size() && m->closed[size_t(submap)].released));
     if (from_dag) {
         // what the reference meshes (lvr2.cpp:30-90): the leaves read back through the DAG, signed distances de-quantised from 8 bits

@@ -265,3 +265,22 @@ def test_mesh_of_a_room_and_of_the_active_submap(chad):
     _, _, count, _ = edge_use(tri)
     assert count.max() == 2
     m.close()
+
+
+def test_mesh_and_iterator_when_only_the_dag_is_kept(chad):
+    """CHAD_FLAG_DAG_ONLY releases a closed submap's dense bricks once it is folded into the DAG (what the reference keeps): the
+    mesh is then reconstructed from the leaves read back through the DAG, as the reference's own mesher does (lvr2.cpp:30-90), and
+    equals the mesh a map with CHAD_FLAG_MESH_FROM_DAG makes from the same scan."""
+    pts, pos = sphere_scan(300_000)
+    a = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    b = chad.TSDFMap(0.05, 0.10, mesh_from_dag=True)
+    for m in (a, b):
+        m.insert(pts, pos)
+        m.close_submap()
+    va, ta = a.mesh(0)
+    vb, tb = b.mesh(0)
+    assert len(ta) > 50_000 and np.array_equal(va, vb) and np.array_equal(ta, tb)
+    with pytest.raises(chad._lib.ChadError):
+        a.export_leaves(0)            # the dense copy is gone ...
+    assert len(np.concatenate(list(a.iter_leaves(0)))) == len(b.export_leaves(0)[0])   # ... the DAG is not
+    a.close(); b.close()
