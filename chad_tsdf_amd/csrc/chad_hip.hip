@@ -304,7 +304,7 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
         HIP_TRY(hipMalloc(&f.sort.points[i], cap * 16));  // the points travel with their keys; the last pass's output is the frame in processing order
     }
     HIP_TRY(hipMalloc(&f.sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
+    HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadixMax * 4));
     HIP_TRY(hipMalloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     f.sort.tiles_capacity = radix_tiles(cap);
     HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
@@ -826,18 +826,26 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, prep, f.d_hdr);
     if (count) {
         if (times_kernels(m) && m->ktimed_end - m->ktimed_begin >= uint64_t(chad_map::kKernelRing)) { TRY(join_streams(m)); collect_kernel_times(m); }
+        // digit width of this frame's sort, from the key width the last finished frame reported (host-mapped): 9-bit digits where they
+        // save a pass (17-18 key bits: two passes instead of three); the keys kernel derives the pass count from the same number
+        static const uint32_t forced_bits = std::getenv("CHAD_DEBUG_DIGIT_BITS") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_DIGIT_BITS"))) : 0u;
+        const uint32_t key_bits_hint = uint32_t(m->h_live_blocks[2]);
+        const uint32_t digit_bits = forced_bits == 8u || forced_bits == 9u ? forced_bits : (key_bits_hint ? radix_digit_bits(key_bits_hint) : uint32_t(kRadixBits));
         LAUNCH_TIMED(m, CHAD_KERNEL_BOUNDS, k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
         LAUNCH_TIMED(m, CHAD_KERNEL_KEYS, k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
-                     f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks);
+                     f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks, digit_bits);
         record(m, T_CALC, prep);
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
         // last of them covering whatever else the frame turns out to need (radix_sort.hpp, k_radix_onesweep to_limit)
-        const uint32_t hint = m->sort_passes_forced ? m->sort_passes_forced : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1])));
+        // launches: what a key of the reported width needs at this frame's digit width (all eight until a frame has reported)
+        const uint32_t hint = m->sort_passes_forced ? m->sort_passes_forced
+                              : (key_bits_hint ? std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, (key_bits_hint + digit_bits - 1u) / digit_bits))
+                                               : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1]))));
         RadixSortSignals sig;
         sig.fault = m->d_overflow; sig.consumed = m->d_consumed + m->last_slot * 16u; sig.seq = ++f.input_seq;
         uint32_t pass_launches = 0;
         if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
-        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used, sig);
+        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used, sig, digit_bits);
         static const uint32_t big_block = std::getenv("CHAD_DEBUG_BIG_BLOCK") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_BLOCK"))) : kBigBlock;
         static const uint32_t big_groups = std::getenv("CHAD_DEBUG_BIG_GROUPS") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_GROUPS"))) : kNormalBigGroups;
         m->sort_turn_used = true;   // (recorded by the hinted path only; an unrecorded event makes the wait a no-op)
@@ -992,6 +1000,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
     m->h_live_blocks[0] = 0;
     m->h_live_blocks[1] = kMaxPasses;  // sort pass hint: all passes as single launches until the first frame has reported
+    m->h_live_blocks[2] = 0;           // key width hint: none yet (8-bit digits)
     if (const char* e = std::getenv("CHAD_DEBUG_SORT_PASSES")) m->sort_passes_forced = uint32_t(std::atoi(e));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
     CREATE_TRY(hipHostMalloc(&m->h_consumed, chad_map::kMaxSlots * 64, hipHostMallocMapped));

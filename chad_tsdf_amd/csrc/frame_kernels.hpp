@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256)
 k_frame_bounds(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FramePartial* __restrict__ part, uint32_t* __restrict__ digit_total) {
     __shared__ int red[4][7];
     // the sort's digit totals, which the keys kernel adds into (saves the sort a kernel of its own for them)
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < kBaseStripes * kMaxPasses * kRadix; k += gridDim.x * blockDim.x) digit_total[k] = 0u;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < kBaseStripes * kMaxPasses * kRadixMax; k += gridDim.x * blockDim.x) digit_total[k] = 0u;
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {int(0x80000000), int(0x80000000), int(0x80000000)};
     uint32_t kept = 0;
     for_each_point(xyz, n, [&](size_t, F3 p) {
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256)
 k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, FrameHeader* __restrict__ h,
              FramePartial* __restrict__ part, uint64_t* __restrict__ keys,
              uint32_t* __restrict__ digit_total, uint32_t* __restrict__ tile_status, uint32_t status_words,
-             const uint32_t* __restrict__ live_blocks, uint32_t* __restrict__ live_blocks_host) {
+             const uint32_t* __restrict__ live_blocks, uint32_t* __restrict__ live_blocks_host, uint32_t digit_bits /* 8 or 9: what the sort passes were launched with */) {
     if (blockIdx.x == 0) frame_header_reset(h);
     if (blockIdx.x == 0) {  // host-mapped: capacity growth hint (the live-brick counter is striped, one stripe per thread)
         static_assert(kCountStripes == 256, "one stripe per thread of this workgroup");
@@ -269,8 +269,9 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
     const LocalFrame f = combine_bounds(part);
     __shared__ unsigned long long wave_mc[4];
     // digit histograms of all radix passes, taken while the key is in a register (radix_sort.hpp)
-    __shared__ uint32_t hist[kMaxPasses][kRadix];
-    const uint32_t passes = (f.bits + (f.kept < n ? 1u : 0u) + kRadixBits - 1) / kRadixBits;
+    __shared__ uint32_t hist[kMaxPasses][kRadixMax];
+    const uint32_t key_bits = f.bits + (f.kept < n ? 1u : 0u), radix = 1u << digit_bits;
+    const uint32_t passes = (key_bits + digit_bits - 1) / digit_bits;
     // clear the radix sort's look-back table for this frame (saves a memset launch): the words of the passes that will run
     // (layout [pass][tile][digit], radix_sort.hpp) and the ticket words behind the table
     {
@@ -278,7 +279,7 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
         for (size_t k = size_t(blockIdx.x) * blockDim.x + threadIdx.x; k < used; k += size_t(gridDim.x) * blockDim.x) tile_status[k] = 0u;
         if (blockIdx.x == 0 && threadIdx.x < 64) tile_status[status_words - 64 + threadIdx.x] = 0u;
     }
-    for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += blockDim.x) (&hist[0][0])[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadixMax; k += blockDim.x) (&hist[0][0])[k] = 0;
     __syncthreads();
     const uint64_t top = 1ull << f.bits;
     unsigned long long mc_min = ~0ull;
@@ -294,14 +295,15 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             mc_min = mc < mc_min ? mc : mc_min;
         }
         keys[i] = key;
-        for (uint32_t pass = 0; pass < passes; pass++) atomicAdd(&hist[pass][uint32_t(key >> (pass * kRadixBits)) & (kRadix - 1)], 1u);
+        for (uint32_t pass = 0; pass < passes; pass++) atomicAdd(&hist[pass][uint32_t(key >> (pass * digit_bits)) & (radix - 1u)], 1u);
     });
     __syncthreads();
     // digit totals of the radix passes (RadixSortBuffers::digit_base): one of kBaseStripes copies per workgroup, zero counts skipped
-    for (uint32_t p = 0; p < passes; p++) {
-        const uint32_t c = hist[p][threadIdx.x];
-        if (c) atomicAdd(&digit_total[((blockIdx.x & (kBaseStripes - 1u)) * kMaxPasses + p) * kRadix + threadIdx.x], c);
-    }
+    for (uint32_t p = 0; p < passes; p++)
+        for (uint32_t d = threadIdx.x; d < radix; d += blockDim.x) {
+            const uint32_t c = hist[p][d];
+            if (c) atomicAdd(&digit_total[((blockIdx.x & (kBaseStripes - 1u)) * kMaxPasses + p) * radix + d], c);
+        }
     mc_min = wave_min_u64(mc_min);
     if ((threadIdx.x & 63) == 0) wave_mc[threadIdx.x >> 6] = mc_min;
     __syncthreads();
@@ -314,7 +316,8 @@ k_frame_keys(const float* __restrict__ xyz, uint32_t n, F3 pos, float recip, Fra
             h->n_usable = f.kept;
             h->axis_bits = f.bits;
             h->sort_passes = passes;  // the extra top bit is only needed when some point is unusable
-            live_blocks_host[1] = passes;  // host-mapped hint: how many single-pass sort kernels the next frames should enqueue
+            live_blocks_host[1] = passes;    // host-mapped hints for the next frames: how many single-pass sort kernels this frame needed ...
+            live_blocks_host[2] = key_bits;  // ... and how wide its key was (the host picks the digit width and the launch count from it)
         }
     }
 }

@@ -22,6 +22,12 @@ namespace chadhip {
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 constexpr int kMaxPasses = 64 / kRadixBits;
+// The frame sort may also run with 9-bit digits (512 bins, two per thread of the pass kernel): a key of 17 or 18 bits -- the
+// 30 m corridor of cfg3 -- then takes two passes instead of three (25..27 bits: three instead of four).  Chosen per frame on
+// the host from the previous frame's key width (radix_digit_bits); buffers are sized for the wider digit.
+constexpr int kWideBits = 9;
+constexpr int kRadixMax = 1 << kWideBits;
+inline uint32_t radix_digit_bits(uint32_t key_bits) { return (key_bits + kWideBits - 1) / kWideBits < (key_bits + kRadixBits - 1) / kRadixBits ? kWideBits : kRadixBits; }
 constexpr uint32_t kBaseStripes = 8;  // the frame's keys kernel adds its digit counts into one of this many copies of the totals (atomics on one address serialise)
 constexpr int kSortThreads = 256;                       // 4 waves
 constexpr int kSortItems = 8;                           // keys per thread
@@ -94,7 +100,7 @@ struct RadixSortSignals {
 inline uint32_t radix_tiles(size_t n) { return uint32_t((n + kSortTile - 1) / kSortTile); }
 __host__ __device__ inline uint32_t radix_groups(uint32_t tiles) { return (tiles + kGroupTiles - 1) / kGroupTiles; }
 // look-back words of all passes ([pass][tile rows, then group rows][256]) and 64 ticket / barrier words behind them
-inline size_t radix_status_words(uint32_t tiles) { return size_t(kMaxPasses) * (tiles + radix_groups(tiles)) * kRadix + 64; }
+__host__ __device__ inline size_t radix_status_words(uint32_t tiles, uint32_t radix = kRadixMax) { return size_t(kMaxPasses) * (tiles + radix_groups(tiles)) * radix + 64; }
 
 // pass_limit (device word, may be null): passes >= *pass_limit are skipped by every kernel.
 // Also clears the look-back table of the coming passes (saves a memset launch).
@@ -140,30 +146,37 @@ k_radix_bases(const uint32_t* __restrict__ hist_part, uint32_t hist_blocks, uint
 }
 
 // One pass for the tile of this workgroup.  pay_in may be null: the payload is then made from the element's position
-// (and `first_src`, the raw points, for PointPayload) -- the first pass.
-template <class P>
+// (and `first_src`, the raw points, for PointPayload) -- the first pass.  kBits: digit width (8, or 9 with two digits per thread).
+template <class P, int kBits>
 __device__ __forceinline__ void
 radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
                     uint64_t* __restrict__ keys_out, typename P::T* __restrict__ pay_out,
                     uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
                     uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const void* __restrict__ first_src, bool use_ticket,
                     uint32_t* __restrict__ fault) {
-    // the whole input's count of digit threadIdx.x (asked for first: needed only after the tile has been ranked)
+    constexpr uint32_t kR = 1u << kBits;                  // bins
+    constexpr uint32_t kPer = kR / kSortThreads;          // digits per thread: thread t owns t, t + 256, ...
+    static_assert(kPer >= 1 && kPer * kSortThreads == kR, "whole digits per thread");
+    // the whole input's count of this thread's digits (asked for first: needed only after the tile has been ranked)
     // (all stripes loaded back to back: a loop over base_stripes waited for each load in turn, 2.5 us per pass)
-    uint32_t stripe_total[kBaseStripes];
+    uint32_t total[kPer];
 #pragma unroll
-    for (uint32_t s = 0; s < kBaseStripes; s++) stripe_total[s] = digit_base[((s < base_stripes ? s : 0u) * kMaxPasses + pass) * kRadix + threadIdx.x];
-    uint32_t total = 0;
+    for (uint32_t q = 0; q < kPer; q++) {
+        uint32_t stripe_total[kBaseStripes];
 #pragma unroll
-    for (uint32_t s = 0; s < kBaseStripes; s++) total += s < base_stripes ? stripe_total[s] : 0u;
-    __shared__ uint32_t wave_count[kSortWaves][kRadix];  // per-wave digit counts, then the wave's base inside the tile
-    __shared__ int offset[kRadix];                       // global slot of local sorted position s is offset[digit] + s
+        for (uint32_t s = 0; s < kBaseStripes; s++) stripe_total[s] = digit_base[((s < base_stripes ? s : 0u) * kMaxPasses + pass) * kR + threadIdx.x + q * kSortThreads];
+        total[q] = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kBaseStripes; s++) total[q] += s < base_stripes ? stripe_total[s] : 0u;
+    }
+    __shared__ uint32_t wave_count[kSortWaves][kR];      // per-wave digit counts, then the wave's base inside the tile
+    __shared__ int offset[kR];                           // global slot of local sorted position s is offset[digit] + s
     __shared__ uint32_t wave_total[kSortWaves], wave_total_all[kSortWaves];
     __shared__ uint32_t my_tile, tile_fault;
     __shared__ uint64_t sorted_key[kSortTile];
     __shared__ typename P::T sorted_val[P::kStaged ? kSortTile : 1];
 
-    for (uint32_t k = threadIdx.x; k < kSortWaves * kRadix; k += kSortThreads) (&wave_count[0][0])[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kSortWaves * kR; k += kSortThreads) (&wave_count[0][0])[k] = 0;
     // A tile waits for the tiles before it.  When the whole grid is certainly resident at the same time (use_ticket false:
     // the host has checked the grid against the kernel's real occupancy and against the other sorts in flight) nobody waits
     // for a workgroup that cannot start, whatever the dispatch order; otherwise tiles are handed out in start order through a
@@ -171,7 +184,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     if (threadIdx.x == 0) { tile_fault = 0u; if (use_ticket) my_tile = atomicAdd(&tile_ticket[pass], 1u); }
     __syncthreads();
     const uint32_t tile = use_ticket ? my_tile : blockIdx.x;
-    const uint32_t shift = pass * kRadixBits;
+    const uint32_t shift = pass * kBits;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 
@@ -188,10 +201,10 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 #pragma unroll
     for (uint32_t j = 0; j < kSortItems; j++) {
         const bool live = tile_index(tile, wave, j, lane) < n;
-        const uint32_t digit = uint32_t(key[j] >> shift) & (kRadix - 1);
+        const uint32_t digit = uint32_t(key[j] >> shift) & (kR - 1);
         uint64_t same = __ballot(live);  // lanes of this wave holding the same digit (one ballot per digit bit)
 #pragma unroll
-        for (uint32_t b = 0; b < kRadixBits; b++) {
+        for (uint32_t b = 0; b < uint32_t(kBits); b++) {
             const bool bit = (digit >> b) & 1u;
             const uint64_t vote = __ballot(bit);
             same &= bit ? vote : ~vote;
@@ -208,53 +221,62 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     }
     __syncthreads();
 
-    // thread d owns digit d from here on
-    const uint32_t d = threadIdx.x;
-    uint32_t count = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kSortWaves; w++) { const uint32_t c = wave_count[w][d]; wave_count[w][d] = count; count += c; }
-    // this pass's words: one row of 256 per tile (the tile's own digit counts), then one row per group of kGroupTiles tiles
+    // thread t owns digits t + q * 256 from here on
+    // this pass's words: one row of kR per tile (the tile's own digit counts), then one row per group of kGroupTiles tiles
     // (the group's digit counts)
     const uint32_t groups = radix_groups(tiles);
-    uint32_t* region = tile_status + size_t(pass) * (tiles + groups) * kRadix;
-    __hip_atomic_store(&region[size_t(tile) * kRadix + d], kStatusPublished | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    // exclusive scans over the digits: of the tile's counts (position of digit d's run in the locally sorted tile) and of
-    // the whole input's counts (first output slot of digit d; k_radix_bases left the per-digit totals)
-    uint32_t incl = count, incl_all = total;
-    {
-        const uint32_t l = d & 63;
+    uint32_t* region = tile_status + size_t(pass) * (tiles + groups) * kR;
+    uint32_t count[kPer], local_excl[kPer], first_slot[kPer];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t d = threadIdx.x + q * kSortThreads;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kSortWaves; w++) { const uint32_t v = wave_count[w][d]; wave_count[w][d] = c; c += v; }
+        count[q] = c;
+        __hip_atomic_store(&region[size_t(tile) * kR + d], kStatusPublished | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // exclusive scans over the digits (digit order: q-major, then thread): of the tile's counts (position of a digit's run in the
+    // locally sorted tile) and of the whole input's counts (first output slot of the digit; the keys kernel / k_radix_bases left the
+    // per-digit totals)
+    uint32_t carry = 0, carry_all = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+        uint32_t incl = count[q], incl_all = total[q];
+        const uint32_t l = threadIdx.x & 63;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(incl, o), u = __shfl_up(incl_all, o);
             if (int(l) >= o) { incl += t; incl_all += u; }
         }
-        if (l == 63) { wave_total[d >> 6] = incl; wave_total_all[d >> 6] = incl_all; }
+        if (q) __syncthreads();   // (the previous round's wave totals have been read)
+        if (l == 63) { wave_total[threadIdx.x >> 6] = incl; wave_total_all[threadIdx.x >> 6] = incl_all; }
+        __syncthreads();
+        local_excl[q] = carry + incl - count[q]; first_slot[q] = carry_all + incl_all - total[q];
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) { local_excl[q] += wave_total[w]; first_slot[q] += wave_total_all[w]; }
+        for (uint32_t w = 0; w < kSortWaves; w++) { carry += wave_total[w]; carry_all += wave_total_all[w]; }
     }
-    __syncthreads();
-    uint32_t local_excl = incl - count, first_slot = incl_all - total;
-    for (uint32_t w = 0; w < (d >> 6); w++) { local_excl += wave_total[w]; first_slot += wave_total_all[w]; }
 
-    // Keys of digit d in all earlier tiles, in two levels.  The tiles of a launch start together, so a chained look-back
+    // Keys of a digit in all earlier tiles, in two levels.  The tiles of a launch start together, so a chained look-back
     // finds only un-summed counts for a long way back (the nearest running total is ~4 r^2 tiles away after r round
     // trips: ~11 dependent round trips for 489 tiles, 14 us of every pass).  Instead: the last tile of every group of
     // kGroupTiles sums its group's rows and publishes the group's counts; a tile adds the counts of the lower groups and
     // of the lower tiles of its own group -- three dependent round trips whatever the number of tiles.  Every wait is for
     // a lower tile, as before.
     uint32_t polls = 0;
-    auto sum_rows = [&](const uint32_t* first_row, uint32_t rows) {   // sum of word d of `rows` consecutive rows, waiting for each to be published
+    auto sum_rows = [&](const uint32_t* first_row, uint32_t rows, uint32_t d) {   // sum of word d of `rows` consecutive rows, waiting for each to be published
         uint32_t sum = 0;
         for (uint32_t r0 = 0; r0 < rows; r0 += kLookback) {
             uint32_t word[kLookback];
 #pragma unroll
             for (uint32_t k = 0; k < kLookback; k++)
-                word[k] = r0 + k < rows ? __hip_atomic_load(first_row + size_t(r0 + k) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusPublished;
+                word[k] = r0 + k < rows ? __hip_atomic_load(first_row + size_t(r0 + k) * kR + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusPublished;
 #pragma unroll
             for (uint32_t k = 0; k < kLookback; k++) {
                 uint32_t w = word[k];
                 while ((w & kStatusPublished) == 0) {
                     if (++polls > kSpinLimit) { tile_fault = 1u; w = kStatusPublished; break; }   // give up: reported, never a hang
-                    w = __hip_atomic_load(first_row + size_t(r0 + k) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w = __hip_atomic_load(first_row + size_t(r0 + k) * kR + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 sum += w & kStatusValue;
             }
@@ -262,14 +284,23 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
         return sum;
     };
     const uint32_t group = tile / kGroupTiles, in_group = tile % kGroupTiles;
-    uint32_t earlier = sum_rows(region + size_t(group) * kGroupTiles * kRadix, in_group);          // lower tiles of this group
-    if (in_group == kGroupTiles - 1 || tile == tiles - 1)                                             // last tile of the group: its counts, for the higher groups
-        __hip_atomic_store(&region[size_t(tiles + group) * kRadix + d], kStatusPublished | (earlier + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    earlier += sum_rows(region + size_t(tiles) * kRadix, group);                                      // lower groups
-    offset[d] = int(first_slot + earlier) - int(local_excl);
-    // wave_count[w][d] becomes the local sorted position of wave w's first key of digit d
+    uint32_t earlier[kPer];
 #pragma unroll
-    for (uint32_t w = 0; w < kSortWaves; w++) wave_count[w][d] += local_excl;
+    for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t d = threadIdx.x + q * kSortThreads;
+        earlier[q] = sum_rows(region + size_t(group) * kGroupTiles * kR, in_group, d);                 // lower tiles of this group
+        if (in_group == kGroupTiles - 1 || tile == tiles - 1)                                           // last tile of the group: its counts, for the higher groups
+            __hip_atomic_store(&region[size_t(tiles + group) * kR + d], kStatusPublished | (earlier[q] + count[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t d = threadIdx.x + q * kSortThreads;
+        earlier[q] += sum_rows(region + size_t(tiles) * kR, group, d);                                  // lower groups
+        offset[d] = int(first_slot[q] + earlier[q]) - int(local_excl[q]);
+        // wave_count[w][d] becomes the local sorted position of wave w's first key of digit d
+#pragma unroll
+        for (uint32_t w = 0; w < kSortWaves; w++) wave_count[w][d] += local_excl[q];
+    }
     __syncthreads();
     if (tile_fault) {   // a predecessor never published: the slots are unknown, write nothing (the sort's output is incomplete and says so)
         if (threadIdx.x == 0 && fault) atomicOr(fault, kSortFaultStalled);
@@ -279,7 +310,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 #pragma unroll
     for (uint32_t j = 0; j < kSortItems; j++) {
         if (tile_index(tile, wave, j, lane) < n) {
-            const uint32_t digit = uint32_t(key[j] >> shift) & (kRadix - 1);
+            const uint32_t digit = uint32_t(key[j] >> shift) & (kR - 1);
             const uint32_t s = wave_count[wave][digit] + rank[j];
             sorted_key[s] = key[j];
             if (P::kStaged) sorted_val[s] = val[j];
@@ -290,7 +321,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     const uint32_t live_keys = min(uint32_t(kSortTile), n - min(n, tile * uint32_t(kSortTile)));
     for (uint32_t s = threadIdx.x; s < live_keys; s += kSortThreads) {
         const uint64_t k = sorted_key[s];
-        const uint32_t slot = uint32_t(offset[uint32_t(k >> shift) & (kRadix - 1)] + int(s));
+        const uint32_t slot = uint32_t(offset[uint32_t(k >> shift) & (kR - 1)] + int(s));
         keys_out[slot] = k;
         if (P::kStaged) pay_out[slot] = sorted_val[s];
     }
@@ -302,7 +333,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 // when a frame suddenly needs more passes than were enqueued (its extent has grown) the rest still runs, just slower --
 // instead of five surplus launches per frame that return at once.  to_limit requires every workgroup of the grid to be
 // resident at once beside everything else in flight (tiles <= RadixSortBuffers::resident; radix_sort_enqueue_as checks).
-template <class P>
+template <class P, int kBits = kRadixBits>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
                  uint32_t n, uint32_t first_pass, uint32_t to_limit, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
@@ -310,11 +341,12 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
                  uint32_t use_ticket, RadixSortSignals sig) {
     const uint32_t limit = pass_limit ? min(uint32_t(kMaxPasses), *pass_limit) : uint32_t(kMaxPasses);
     uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
+    (void)kBits;
     // this launch runs behind pass 0 (stream order): the caller's raw points have been read for the last time
     if (sig.consumed && first_pass > 0u && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig.consumed, sig.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (uint32_t pass = first_pass; pass < limit; pass++) {
         const bool odd = pass & 1u;
-        radix_onesweep_tile<P>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base, base_stripes,
+        radix_onesweep_tile<P, kBits>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base, base_stripes,
                                tile_status, tile_ticket, first_src, use_ticket != 0u, sig.fault);
         if (!to_limit || pass + 1 >= limit) break;
         // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
@@ -341,7 +373,7 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
 template <class P>
 inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
                                   uint32_t hist_blocks, uint32_t launch_passes, const void* first_src, hipEvent_t one_at_a_time = nullptr, bool wait_for_it = false,
-                                  const RadixSortSignals& sig = RadixSortSignals{}) {
+                                  const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
     const bool all_resident = b.resident != 0u && tiles <= b.resident;
@@ -361,12 +393,15 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         // each hold part of the CUs while waiting for the rest of their workgroups would wait forever): sorts running on
         // different streams take turns for this one launch.
         if (to_limit && one_at_a_time && wait_for_it) (void)hipStreamWaitEvent(stream, one_at_a_time, 0);
-        if (sig.pass_events)
-            hipExtLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, sig.pass_events[2 * p], sig.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                                  to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
-        else
-            hipLaunchKernelGGL(k_radix_onesweep<P>, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                               to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
+        auto launch = [&](auto kernel) {
+            if (sig.pass_events)
+                hipExtLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, sig.pass_events[2 * p], sig.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                                      to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
+            else
+                hipLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                                   to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
+        };
+        if (digit_bits == uint32_t(kWideBits)) launch(k_radix_onesweep<P, kWideBits>); else launch(k_radix_onesweep<P, kRadixBits>);
         if (to_limit && one_at_a_time) (void)hipEventRecord(one_at_a_time, stream);
     }
     if (sig.launches_out) *sig.launches_out = launches;
@@ -376,8 +411,9 @@ inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t p
     radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr, nullptr, false, sig);
 }
 inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                      uint32_t hist_blocks, uint32_t launch_passes, hipEvent_t one_at_a_time, bool wait_for_it, const RadixSortSignals& sig) {
-    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, one_at_a_time, wait_for_it, sig);
+                                      uint32_t hist_blocks, uint32_t launch_passes, hipEvent_t one_at_a_time, bool wait_for_it, const RadixSortSignals& sig,
+                                      uint32_t digit_bits) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, one_at_a_time, wait_for_it, sig, digit_bits);
 }
 // Workgroups of a pass kernel the device holds at once: the kernel's real occupancy (registers, LDS) x CU count, with a quarter
 // held back (the runtime's answer can exceed what the hardware admits by one per CU -- MI355X_MICROARCH.md, Residency).
@@ -385,8 +421,11 @@ template <class P>
 inline uint32_t radix_resident_workgroups() {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_radix_onesweep<P>, kSortThreads, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+    int per_cu_wide = 0;   // (the wider digit holds more LDS: the smaller of the two answers)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_radix_onesweep<P, kRadixBits>, kSortThreads, 0) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wide, k_radix_onesweep<P, kWideBits>, kSortThreads, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
         hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0u; }
+    per_cu = per_cu < per_cu_wide ? per_cu : per_cu_wide;
     return uint32_t(per_cu > 0 ? per_cu : 0) * uint32_t(prop.multiProcessorCount) * 3u / 4u;
 }
 

@@ -169,6 +169,7 @@ def test_cfg3_full_stream(chad):
             assert len(mc) == 737_935 and int(w.sum(dtype=np.uint64)) == 135_382_309
     assert closed_at == [101, 202, 303, 404]
     assert max_load <= 0.5
+    assert st["sort_passes"] == 2   # 17-18 key bits (12 000 super blocks x 8 blocks + the flag bit): two passes of 9-bit digits, not three of 8
     bounds = [0] + closed_at + [n_frames]
     per_submap = [serial.export_leaves(s) for s in range(4)] + [serial.export_leaves(-1)]
     for s, leaves in enumerate(per_submap):
