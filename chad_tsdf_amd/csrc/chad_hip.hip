@@ -162,6 +162,8 @@ struct chad_map {
 
 
     std::vector<std::array<float, 3>> positions;  // poses of the active submap (submap.hpp:110)
+    std::vector<std::vector<std::array<float, 3>>> closed_positions;   // ... and of the closed ones, in closing order (what a pose-graph back-end needs)
+    std::vector<std::array<float, 12>> closed_pose;                    // rigid correction per closed submap (rotation row-major, translation); empty = identity
     std::vector<Submap> closed;                   // tsdf.cpp:54
     Submap active_copy;                           // dense snapshot of the active submap made for the last export call
     Dag dag;                                      // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps, built lazily (chad_map_finalize)
@@ -782,6 +784,8 @@ inline bool rolls_over(const chad_map* m, const float position[3]) {
 }
 
 chad_status merge_and_close(chad_map* m, chad_comm* c);   // (further down)
+// the active submap has just been closed: its poses go with it
+inline void retire_positions(chad_map* m) { m->closed_positions.push_back(std::move(m->positions)); m->positions.clear(); }
 inline bool is_sharded(const chad_map* m) { return m->comm && m->comm->exchanges(); }
 
 chad_status note_pose(chad_map* m, const float position[3]) {
@@ -791,7 +795,7 @@ chad_status note_pose(chad_map* m, const float position[3]) {
         if (rolls_over(m, position)) {
             // every rank of a sharded map sees every pose, so all of them get here for the same frame: the merge is collective
             TRY(is_sharded(m) ? merge_and_close(m, m->comm) : close_active(m));
-            m->positions.clear();
+            retire_positions(m);
             m->positions.push_back(pose);
         } else m->positions.push_back(pose);
     }
@@ -902,6 +906,9 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         if (!times_stages(m)) record(m, T_NORM, prep);
         record(m, T_UPD, prep);
     }
+    if (count && (m->flags & CHAD_FLAG_SPACE_CARVING))   // the extension of SURVEY.md section 8 f4: free space along every ray, behind the update (frames run one at a time)
+        hipLaunchKernelGGL(k_carve, grid_for(count, 256, 4096), dim3(256), 0, prep, reinterpret_cast<const float4*>(f.sort.points[0]), reinterpret_cast<const float4*>(f.sort.points[1]),
+                           f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
     f.tail_unrecorded = true;   // (update_done is recorded when somebody waits for it: updates_done)
     f.used = true;
     HIP_TRY(hipGetLastError());
@@ -972,7 +979,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         m->own_stream = true;
     }
     if (const char* e = std::getenv("CHAD_SLOTS")) m->n_slots = std::min<uint32_t>(chad_map::kMaxSlots, std::max(1, std::atoi(e)));
-    m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr ||
+    m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE | CHAD_FLAG_SPACE_CARVING)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr ||
                 ((m->flags & CHAD_FLAG_TIME_KERNELS) && !std::getenv("CHAD_DEBUG_TIME_PIPELINED"));   // (experiment: per-kernel time stamps with three frames in flight)
 
     uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
@@ -1182,7 +1189,7 @@ chad_status chad_map_reset(chad_map* m) {
     m->dag_roots.clear();
     m->dag_generation++;
     m->mesh_submap = INT32_MIN;
-    m->positions.clear();
+    m->positions.clear(); m->closed_positions.clear(); m->closed_pose.clear();
     // Octree::clear() by rotating tables, as a roll-over does: the empty spare table becomes the active one at once, and the old
     // one is cleared on the map's stream once the updates enqueued so far have landed in it -- beside the next frames, which no
     // longer wait for them (a clear in front of the next update made every step's update wait for the two before it: 0.113 ->
@@ -1222,7 +1229,7 @@ chad_status chad_map_close_submap(chad_map* m) {
     DeviceGuard guard(m->device);
     if (m->positions.empty()) return CHAD_OK;
     TRY(is_sharded(m) ? merge_and_close(m, m->comm) : close_active(m));
-    m->positions.clear();
+    retire_positions(m);
     return CHAD_OK;
 }
 
@@ -1368,7 +1375,7 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* m, const uint64_t
         HIP_TRY(hipMemcpyAsync(s.cnt, cnt_device, blocks * 256, hipMemcpyDeviceToDevice, m->stream));
     }
     m->closed.push_back(s);
-    m->positions.clear();
+    retire_positions(m);
     TRY(clear_active(m));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return release_finalized(m);
@@ -1430,6 +1437,7 @@ void chad_comm_destroy(chad_comm* c) {
 chad_status chad_map_attach_comm(chad_map* m, chad_comm* c) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     if (c && c->device != m->device) return fail(CHAD_ERR_INVALID_ARG, "the communicator was created on another device than the map's");
+    if (c && (m->flags & CHAD_FLAG_SPACE_CARVING)) return fail(CHAD_ERR_INVALID_ARG, "space carving looks at the leaves already in the map: not defined for a map spread over ranks");
     m->comm = c;
     m->stream_frames = 0;
     return CHAD_OK;
@@ -1439,7 +1447,7 @@ chad_status chad_map_merge_and_close(chad_map* m, chad_comm* c) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     DeviceGuard guard(m->device);
     TRY(merge_and_close(m, c ? c : m->comm));
-    m->positions.clear();
+    retire_positions(m);
     return finish_closing(m, true);   // an explicit exchange is complete when the call returns
 }
 
@@ -1590,8 +1598,19 @@ chad_status chad_map_export_clusters(chad_map* m, int32_t submap, uint64_t* keys
 struct chad_iter {
     chad_map* map;
     uint64_t generation;
+    int32_t submap;
     DagCursor cursor;
 };
+
+// p <- R p + t of closed submap `submap`, if it has been given a pose
+static void apply_submap_pose(const chad_map* m, int32_t submap, float p[3]) {
+    if (submap < 0 || size_t(submap) >= m->closed_pose.size()) return;
+    const std::array<float, 12>& T = m->closed_pose[size_t(submap)];
+    const float x = p[0], y = p[1], z = p[2];
+    p[0] = T[0] * x + T[1] * y + T[2] * z + T[9];
+    p[1] = T[3] * x + T[4] * y + T[5] * z + T[10];
+    p[2] = T[6] * x + T[7] * y + T[8] * z + T[11];
+}
 
 chad_status chad_map_iter_begin(chad_map* m, int32_t submap, chad_iter** out) {
     if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
@@ -1600,7 +1619,7 @@ chad_status chad_map_iter_begin(chad_map* m, int32_t submap, chad_iter** out) {
     TRY(finalize_closed(m));
     // tsdf.cpp:106-110: "chad::TSDFMap::begin() given faulty root address"
     if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
-    chad_iter* it = new chad_iter{m, m->dag_generation, DagCursor{}};
+    chad_iter* it = new chad_iter{m, m->dag_generation, submap, DagCursor{}};
     it->cursor.open(m->dag, m->dag_roots[size_t(submap)][0], m->dag_roots[size_t(submap)][1]);
     it->cursor.first();
     *out = it;
@@ -1632,9 +1651,9 @@ static void leaf_of(const chad_iter* it, chad_leaf* out) {
     const chad_map* m = it->map;
     const uint64_t code = it->cursor.code();
     // the leaf's position: its voxel's corner, vec3(decode(mc)) * res (octree.hpp:157, lvr2.cpp:78-79)
-    out->x = float(int(dag_compact21(code) - (1u << 20))) * m->res;
-    out->y = float(int(dag_compact21(code >> 1) - (1u << 20))) * m->res;
-    out->z = float(int(dag_compact21(code >> 2) - (1u << 20))) * m->res;
+    float p[3] = {float(int(dag_compact21(code) - (1u << 20))) * m->res, float(int(dag_compact21(code >> 1) - (1u << 20))) * m->res, float(int(dag_compact21(code >> 2) - (1u << 20))) * m->res};
+    apply_submap_pose(m, it->submap, p);   // identity unless chad_map_set_submap_pose has re-posed the submap (loop closure)
+    out->x = p[0]; out->y = p[1]; out->z = p[2];
     out->signed_distance = cluster_sd_of_bits(it->cursor.sd_bits(), m->trunc);
     out->weight = it->cursor.weight_bits();
     out->reserved = 0;
@@ -1655,6 +1674,28 @@ chad_status chad_iter_read(chad_iter* it, chad_leaf* out, size_t capacity, size_
         it->cursor.next();
     }
     *count = k;
+    return CHAD_OK;
+}
+
+// ---- loop-closure support (EXTENSION; upstream roadmap README.md:59): a submap's frame poses out, a rigid correction in ---------
+chad_status chad_map_submap_positions(chad_map* m, int32_t submap, float* xyz, size_t capacity, size_t* count) {
+    if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    const std::vector<std::array<float, 3>>* poses = &m->positions;
+    if (submap >= 0) {
+        if (size_t(submap) >= m->closed_positions.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
+        poses = &m->closed_positions[size_t(submap)];
+    }
+    *count = poses->size();
+    if (xyz) for (size_t k = 0; k < std::min(capacity, poses->size()); k++) std::memcpy(xyz + 3 * k, (*poses)[k].data(), 12);
+    return CHAD_OK;
+}
+
+chad_status chad_map_set_submap_pose(chad_map* m, int32_t submap, const float rotation[9], const float translation[3]) {
+    if (!m || !rotation || !translation) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (submap < 0 || size_t(submap) >= m->closed_positions.size()) return fail(CHAD_ERR_INVALID_ARG, "only a closed submap can be re-posed");
+    if (m->closed_pose.size() <= size_t(submap)) m->closed_pose.resize(size_t(submap) + 1, std::array<float, 12>{1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0});
+    std::memcpy(m->closed_pose[size_t(submap)].data(), rotation, 36);
+    std::memcpy(m->closed_pose[size_t(submap)].data() + 9, translation, 12);
     return CHAD_OK;
 }
 
@@ -1812,7 +1853,10 @@ chad_status chad_map_mesh(chad_map* m, int32_t submap, float* vertices, size_t v
     DeviceGuard guard(m->device);
     TRY(extract_mesh(m, submap));
     *vertex_count = m->mesh_vertices.size() / 3; *triangle_count = m->mesh_triangles.size() / 3;
-    if (vertices && vertex_capacity >= *vertex_count) std::memcpy(vertices, m->mesh_vertices.data(), m->mesh_vertices.size() * 4);
+    if (vertices && vertex_capacity >= *vertex_count) {
+        std::memcpy(vertices, m->mesh_vertices.data(), m->mesh_vertices.size() * 4);
+        for (size_t v = 0; v < *vertex_count; v++) apply_submap_pose(m, submap, vertices + 3 * v);   // (loop closure: the submap's corrected pose)
+    }
     if (triangles && triangle_capacity >= *triangle_count) std::memcpy(triangles, m->mesh_triangles.data(), m->mesh_triangles.size() * 4);
     if ((vertices && vertex_capacity < *vertex_count) || (triangles && triangle_capacity < *triangle_count)) return fail(CHAD_ERR_INVALID_ARG, "mesh buffers too small");
     return CHAD_OK;
@@ -1827,7 +1871,9 @@ chad_status chad_map_save_mesh(chad_map* m, int32_t submap, const char* filename
     const size_t nv = m->mesh_vertices.size() / 3, nt = m->mesh_triangles.size() / 3;
     std::fprintf(f, "ply\nformat binary_little_endian 1.0\ncomment chad_tsdf mesh: sd = 0 surface of submap %d, res %g trunc %g\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\n"
                     "element face %zu\nproperty list uchar uint vertex_indices\nend_header\n", submap, double(m->res), double(m->trunc), nv, nt);
-    bool ok = nv == 0 || std::fwrite(m->mesh_vertices.data(), 12, nv, f) == nv;
+    std::vector<float> posed(m->mesh_vertices);
+    for (size_t v = 0; v < nv; v++) apply_submap_pose(m, submap, posed.data() + 3 * v);
+    bool ok = nv == 0 || std::fwrite(posed.data(), 12, nv, f) == nv;
     std::vector<unsigned char> faces(nt * 13);
     for (size_t t = 0; t < nt; t++) { faces[13 * t] = 3; std::memcpy(&faces[13 * t + 1], &m->mesh_triangles[3 * t], 12); }
     ok = ok && (nt == 0 || std::fwrite(faces.data(), 13, nt, f) == nt);

@@ -95,6 +95,20 @@ struct RayWalk {
         const long long span = (long long)abs(last.x - cur.x) + abs(last.y - cur.y) + abs(last.z - cur.z);
         budget = int(span < 4096 ? span : 4096);
     }
+    // the same traversal rule on an arbitrary segment from -> to with direction dir (the space-carving extension walks the
+    // free part of a ray with it: map_kernels.hpp, k_carve)
+    __device__ __forceinline__ void begin_segment(F3 from, F3 to, F3 dir, float res, float recip) {
+        const F3 inv{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+        cur = voxel_of(from, recip);
+        last = voxel_of(to, recip);
+        step = {sgn(last.x - cur.x), sgn(last.y - cur.y), sgn(last.z - cur.z)};
+        delta = {fabsf(res * inv.x), fabsf(res * inv.y), fabsf(res * inv.z)};
+        tmax.x = first_crossing(step.x, from.x, inv.x, res, recip);
+        tmax.y = first_crossing(step.y, from.y, inv.y, res, recip);
+        tmax.z = first_crossing(step.z, from.z, inv.z, res, recip);
+        const long long span = (long long)abs(last.x - cur.x) + abs(last.y - cur.y) + abs(last.z - cur.z);
+        budget = int(span < (1 << 24) ? span : (1 << 24));
+    }
     // advance to the next voxel; false when the walk is over (the stepped axis passed `last`, :130-148)
     __device__ __forceinline__ bool next() {
         const bool sx = (tmax.x < tmax.y) && (tmax.x < tmax.z);   // comparison tree of :126-150

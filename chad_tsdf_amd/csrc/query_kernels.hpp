@@ -59,6 +59,45 @@ __device__ __forceinline__ bool sample_trilinear(const MapView& m, F3 p, float r
     return true;
 }
 
+// ---- space carving: an EXTENSION (upstream's roadmap lists it as open, README.md:59-60) -------------------------
+// After a frame's regular update every ray also tells the voxels it crosses before its truncation band that they are free space:
+// the traversal rule of octree.hpp:100-152 on the segment [position, p - trunc * dir]; every voxel on it other than the segment's
+// last one (the first voxel of the regular walk) that ALREADY HOLDS A LEAF gets one observation of +trunc; no leaf, no block is
+// created.  Points closer to the sensor than trunc are not carved.  (The test oracle restates the same definition: carve_frame.)
+// Runs behind the frame's update on the same stream, frames one after the other (the set of leaves must not move under it).
+__global__ void __launch_bounds__(256)
+k_carve(const float4* __restrict__ points0, const float4* __restrict__ points1, FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m) {
+    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order (any order would do)
+    const uint32_t n = h->n_usable;
+    unsigned long long carved = 0;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const float4 q = pts[i];
+        const F3 p{q.x, q.y, q.z};
+        const F3 dir = unit3(sub3(p, pos));                                          // octree.hpp:92
+        const F3 to{p.x - dir.x * trunc, p.y - dir.y * trunc, p.z - dir.z * trunc};  // :94: where the regular walk begins
+        if (!(dot3(sub3(to, pos), dir) > 0.0f)) continue;
+        RayWalk w;
+        w.begin_segment(pos, to, dir, res, recip);
+        uint64_t cached_key = kEmptyKey;
+        uint32_t brick = kNoBrick;
+        do {
+            if (w.cur.x == w.last.x && w.cur.y == w.last.y && w.cur.z == w.last.z) continue;
+            const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
+            const uint64_t key = mc & kBlockMask;
+            if (key != cached_key) { brick = find_brick(m, key); cached_key = key; }
+            if (brick == kNoBrick) continue;
+            const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
+            if (!(m.brick_cnt[at] & ~kPoisonedCount)) continue;   // counts only grow during this kernel: "holds a leaf" cannot change
+            atomicAdd(reinterpret_cast<unsigned long long*>(&m.brick_sum[at]), (unsigned long long)(long long)kSumOne);   // +trunc in the map's units
+            atomicAdd(&m.brick_cnt[at], 1u);
+            carved++;
+        } while (w.next());
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) carved += __shfl_xor(carved, o);
+    if ((threadIdx.x & 63) == 0 && carved) atomicAdd(&h->n_updates[(blockIdx.x % kUpdateStripes) * 16u], carved);
+}
+
 enum { kQueryLeaf = 0, kQueryTrilinear = 1 };
 
 __global__ void __launch_bounds__(256)

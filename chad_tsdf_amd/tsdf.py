@@ -22,7 +22,7 @@ def _np_f32(a, shape_last=3):
 class TSDFMap:
     def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, device: int = -1, max_blocks: int = 0,
                  max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, time_update: bool = False, fixed_capacity: bool = False, update_mode: int = 0,
-                 dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False, mesh_from_dag: bool = False):
+                 dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False, mesh_from_dag: bool = False, space_carving: bool = False):
         self._lib = _lib.load()
         self._sdf_res = float(sdf_res)
         self._sdf_trunc = float(sdf_trunc)
@@ -32,7 +32,7 @@ class TSDFMap:
         opt.max_blocks = max_blocks
         opt.max_points = max_points
         opt.stream = stream or None
-        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.FLAG_MESH_FROM_DAG if mesh_from_dag else 0)
+        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.FLAG_MESH_FROM_DAG if mesh_from_dag else 0) | (_lib.FLAG_SPACE_CARVING if space_carving else 0)
         opt.update_mode = update_mode
         handle = C.c_void_p()
         _lib.check(self._lib.chad_map_create(sdf_res, sdf_trunc, C.byref(opt), C.byref(handle)), "TSDFMap")
@@ -136,6 +136,20 @@ class TSDFMap:
         t = np.empty(o.shape[0], dtype=np.float32)
         _lib.check(self._lib.chad_map_raycast(self._h, o.ctypes.data, d.ctypes.data, o.shape[0], max_range, t.ctypes.data), "TSDFMap.raycast")
         return t
+
+    def submap_positions(self, submap: int = -1) -> np.ndarray:
+        """The sensor poses of a submap's frames (Submap::positions, submap.hpp:110), float32 [frames, 3]."""
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_map_submap_positions(self._h, submap, None, 0, C.byref(n)), "TSDFMap.submap_positions")
+        out = np.empty((n.value, 3), dtype=np.float32)
+        _lib.check(self._lib.chad_map_submap_positions(self._h, submap, out.ctypes.data, n.value, C.byref(n)), "TSDFMap.submap_positions")
+        return out
+
+    def set_submap_pose(self, submap: int, rotation, translation):
+        """Loop closure: re-pose a closed submap (x' = R x + t); its iterator positions and mesh vertices come out corrected."""
+        r = np.ascontiguousarray(rotation, dtype=np.float32).reshape(9)
+        t = np.ascontiguousarray(translation, dtype=np.float32).reshape(3)
+        _lib.check(self._lib.chad_map_set_submap_pose(self._h, submap, r.ctypes.data, t.ctypes.data), "TSDFMap.set_submap_pose")
 
     def mesh(self, submap: int = 0):
         """(vertices f32 [V,3], triangles u32 [T,3]) of the sd = 0 surface of a submap (closed: >= 0; active: -1)."""

@@ -61,6 +61,10 @@ enum {
                                      records in between); frames run one after the other.  Read with chad_map_kernel_times */
     CHAD_FLAG_MESH_FROM_DAG = 128u, /* chad_map_mesh / save read a closed submap's leaves back through the DAG (8-bit signed distances), as the
                                        reference's mesh extraction does (lvr2.cpp:30-90); default: from the exact means of the dense archive */
+    CHAD_FLAG_SPACE_CARVING = 256u, /* EXTENSION (upstream roadmap, README.md:59-60, not built there): after a frame's update every ray also gives
+                                       the voxels it crosses before its truncation band -- the traversal of octree.hpp:100-152 on
+                                       [position, p - trunc * dir], without that segment's last voxel -- one observation of +sdf_trunc, where they
+                                       already hold a leaf; nothing is created.  Frames then run one after the other; not with chad_map_attach_comm */
     CHAD_FLAG_DAG_ONLY = 32u /* a closed submap is folded into the DAG as soon as its archive is complete and its dense brick copy
                                 is released: device memory then holds the active submap only (long trajectories), as the reference
                                 keeps nothing but the DAG of a closed submap (tsdf.cpp:53-54).  Closed submaps are then read back with
@@ -268,6 +272,14 @@ chad_status chad_map_raycast(chad_map* map, const float* origins, const float* d
 chad_status chad_map_mesh(chad_map* map, int32_t submap, float* vertices, size_t vertex_capacity, uint32_t* triangles, size_t triangle_capacity,
                           size_t* vertex_count, size_t* triangle_count);
 chad_status chad_map_save_mesh(chad_map* map, int32_t submap, const char* filename);   /* binary little-endian PLY */
+
+/* ---- Loop-closure support (upstream's roadmap lists "Loop closure" as open, README.md:59, and keeps what it would
+ * need: the poses of a submap's frames, Submap::positions, submap.hpp:110).  EXTENSION, nothing upstream to compare with.
+ * chad_map_submap_positions: those poses, 3 floats per frame, in insertion order (submap < 0: the active submap) -- what a pose-graph
+ * back-end matches.  chad_map_set_submap_pose: its answer, a rigid correction x' = R x + t (R row-major) of a CLOSED submap; the
+ * iterator's leaf positions and the mesh's vertices of that submap come out corrected (the stored voxels do not move). */
+chad_status chad_map_submap_positions(chad_map* map, int32_t submap, float* xyz, size_t capacity, size_t* count);
+chad_status chad_map_set_submap_pose(chad_map* map, int32_t submap, const float rotation[9], const float translation[3]);
 
 /* Stage read-back for parity tests: intermediates of the LAST insert, copied to host.
  * order[i]: input index of the i-th point in processing order; mc[i]: its Morton code; normals: 3 floats per point.

@@ -226,6 +226,41 @@ inline void walk_ray(V3 p, V3 pos, float res, float res_recip, float trunc, Emit
     }
 }
 
+// The same traversal rule (octree.hpp:100-152) on the segment from `from` to `to`, direction `dir` (= normalize(to - from) up to
+// rounding; passed in so that it is bit for bit the ray's).  Used by the space-carving EXTENSION below: upstream has no such code
+// (README.md:59-60 lists it as not done).
+template <class Emit>
+inline void walk_segment(V3 from, V3 to, V3 dir, float res, float res_recip, Emit&& emit) {
+    const V3 dir_recip{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    const I3 v0{int32_t(std::floor(from.x * res_recip)), int32_t(std::floor(from.y * res_recip)), int32_t(std::floor(from.z * res_recip))};
+    const I3 v1{int32_t(std::floor(to.x * res_recip)), int32_t(std::floor(to.y * res_recip)), int32_t(std::floor(to.z * res_recip))};
+    const I3 step{isign(v1.x - v0.x), isign(v1.y - v0.y), isign(v1.z - v0.z)};
+    const V3 delta{std::fabs(res * dir_recip.x), std::fabs(res * dir_recip.y), std::fabs(res * dir_recip.z)};
+    V3 tmax;
+    auto boundary = [&](int32_t s, float st) {
+        if (s < 0) return res * std::floor(st * res_recip);
+        if (s > 0) return res * std::ceil(st * res_recip);
+        return std::numeric_limits<float>::max();
+    };
+    tmax.x = boundary(step.x, from.x); tmax.y = boundary(step.y, from.y); tmax.z = boundary(step.z, from.z);
+    tmax = tmax - from;
+    tmax = {std::fabs(tmax.x * dir_recip.x), std::fabs(tmax.y * dir_recip.y), std::fabs(tmax.z * dir_recip.z)};
+    I3 cur = v0;
+    int64_t budget = int64_t(std::abs(int64_t(v1.x) - v0.x)) + std::abs(int64_t(v1.y) - v0.y) + std::abs(int64_t(v1.z) - v0.z);
+    emit(cur);
+    for (;;) {
+        if (tmax.x < tmax.y) {
+            if (tmax.x < tmax.z) { cur.x += step.x; tmax.x += delta.x; if (cur.x == v1.x + step.x) break; }
+            else                 { cur.z += step.z; tmax.z += delta.z; if (cur.z == v1.z + step.z) break; }
+        } else {
+            if (tmax.y < tmax.z) { cur.y += step.y; tmax.y += delta.y; if (cur.y == v1.y + step.y) break; }
+            else                 { cur.z += step.z; tmax.z += delta.z; if (cur.z == v1.z + step.z) break; }
+        }
+        if (--budget < 0) break;   // (every step moves one axis towards v1)
+        emit(cur);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // octree.hpp:12-78 -- pointer octree of depth 20 + leaves, with a hash shortcut at 4x4x4-voxel granularity.
 struct Leaf { float sd; uint32_t w; };
@@ -304,6 +339,16 @@ struct Octree {
             nodes[node].child[li] = leaf;
         }
         return leaves[leaf];
+    }
+    // read-only: the leaf of `mc`, or null (a walk from the root, nothing created)
+    Leaf* find(uint64_t mc) {
+        uint32_t node = 0;
+        for (uint32_t depth = 0; depth < 20; depth++) {
+            node = nodes[node].child[uint32_t(mc >> (uint64_t(20 - depth) * 3)) & 7u];
+            if (node == 0) return nullptr;
+        }
+        const uint32_t leaf = nodes[node].child[uint32_t(mc) & 7u];
+        return leaf ? &leaves[leaf] : nullptr;
     }
 };
 
@@ -421,6 +466,7 @@ struct Map {
     NodeLevels levels;                // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps
     std::vector<std::array<uint32_t, 2>> roots;  // submap.hpp:108-109 per closed submap
     bool saturate_weights = false;
+    bool carve = false;               // EXTENSION (space carving, README.md:60 "not done" upstream): see carve_frame
     double ms_finalize = 0;
     // scratch reused across frames
     std::vector<PointMc> pmc; std::vector<V3> sorted, normals; std::vector<uint64_t> walked;
@@ -468,6 +514,34 @@ void octree_insert(Map& m, V3 pos) {
     m.updates = updates;
 }
 
+// EXTENSION, not in the reference (its roadmap lists space carving as open, README.md:59-60): after a frame's regular update, every
+// ray also tells the voxels it crosses BEFORE its truncation band that they are free space.  Definition (the HIP library
+// implements the same, CHAD_FLAG_SPACE_CARVING): for every usable point p, the traversal rule of octree.hpp:100-152 on the segment
+// [position, p - trunc * dir]; every voxel on it other than the segment's last one (which is the first voxel of the regular walk)
+// that ALREADY HOLDS A LEAF gets one observation of +trunc (sd = (sd * w + trunc) / (w + 1), w++); no leaf is created.  Points
+// closer to the sensor than trunc are not carved.
+void carve_frame(Map& m, V3 pos) {
+    const float res = m.res, trunc = m.trunc, res_recip = float(1.0 / double(res));
+    uint64_t carved = 0;
+    for (size_t i = 0; i < m.sorted.size(); i++) {
+        const V3 p = m.sorted[i];
+        const V3 dir = normalize(p - pos);
+        const V3 to = p - dir * trunc;
+        if (!(dot(to - pos, dir) > 0.0f)) continue;
+        const I3 last{int32_t(std::floor(to.x * res_recip)), int32_t(std::floor(to.y * res_recip)), int32_t(std::floor(to.z * res_recip))};
+        walk_segment(pos, to, dir, res, res_recip, [&](I3 v) {
+            if (v.x == last.x && v.y == last.y && v.z == last.z) return;
+            Leaf* leaf = m.oct.find(morton_encode(v.x, v.y, v.z));
+            if (!leaf || leaf->w == 0) return;
+            leaf->sd = (leaf->sd * float(leaf->w) + trunc) / float(leaf->w + 1);
+            leaf->w++;
+            m.oct.leaf_sum[size_t(leaf - m.oct.leaves.data())] += double(trunc);
+            carved++;
+        });
+    }
+    m.updates += carved;
+}
+
 // tsdf.cpp:53-54 / :78-81: Submap::finalize into the shared DAG, then archive (the sorted leaf list is kept beside the
 // DAG for the leaf-level parity tests)
 void close_submap(Map& m) {
@@ -502,6 +576,7 @@ void map_insert(Map& m, const float* xyz, size_t n, const float position[3]) {
     estimate_normals(m.pmc, pos, m.normals, nullptr);    // :67
     m.ms_norm = ms_since(t0); t0 = std::chrono::steady_clock::now();
     octree_insert(m, pos);                               // :70
+    if (m.carve) carve_frame(m, pos);                    // (extension, off by default)
     m.ms_upd = ms_since(t0);
     m.ms_total = ms_since(t_total);
     m.frames++;
@@ -557,6 +632,7 @@ void oracle_map_stats(void* h, double* out) {
 
 // ---- Submap::finalize / NodeLevels (submap.hpp, levels.hpp) ----
 void oracle_map_set_saturate_weights(void* h, int on) { static_cast<Map*>(h)->saturate_weights = on != 0; }
+void oracle_map_set_carving(void* h, int on) { static_cast<Map*>(h)->carve = on != 0; }
 // TSDFMap::save's hand-over (tsdf.cpp:78-81): finalize and archive the active submap if it holds a pose
 void oracle_map_close_submap(void* h) {
     Map* m = static_cast<Map*>(h);

@@ -56,6 +56,7 @@ def lib():
         L.oracle_walk_ray.argtypes = [vp, vp, f32, f32, vp, sz]
         L.oracle_walk_rays.argtypes = [vp, sz, vp, f32, f32, vp, vp, sz]
         L.oracle_map_set_saturate_weights.argtypes = [vp, C.c_int]
+        L.oracle_map_set_carving.argtypes = [vp, C.c_int]
         L.oracle_map_close_submap.argtypes = [vp]
         L.oracle_dag_level_words.restype = sz
         L.oracle_dag_level_words.argtypes = [vp, C.c_uint32]
@@ -117,6 +118,10 @@ class OracleMap:
     # ---- Submap::finalize / NodeLevels (submap.hpp:10-106, levels.hpp) ----
     def set_saturate_weights(self, on: bool):
         lib().oracle_map_set_saturate_weights(self._h, int(on))
+
+    def set_carving(self, on: bool):
+        """The space-carving extension (not in the reference): see carve_frame in chad_oracle.cpp."""
+        lib().oracle_map_set_carving(self._h, int(on))
 
     def close_submap(self):
         """TSDFMap::save's hand-over (tsdf.cpp:78-81): finalize + archive the active submap if it holds a pose."""

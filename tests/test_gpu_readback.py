@@ -284,3 +284,64 @@ def test_mesh_and_iterator_when_only_the_dag_is_kept(chad):
         a.export_leaves(0)            # the dense copy is gone ...
     assert len(np.concatenate(list(a.iter_leaves(0)))) == len(b.export_leaves(0)[0])   # ... the DAG is not
     a.close(); b.close()
+
+
+def test_space_carving_extension_matches_its_oracle(chad, oracle):
+    """SURVEY.md section 8 f4 (upstream roadmap, never built there: README.md:59-60).  The definition -- every ray gives the voxels
+    it crosses before its truncation band one observation of +trunc where they already hold a leaf, nothing is created -- is stated
+    twice, in the oracle (carve_frame) and in the HIP library (k_carve): leaf sets and weights must agree exactly, signed distances
+    within 1e-4.  Scene: a room scanned from one pose, then from a pose from which many rays cross the first scan's band."""
+    res, trunc = 0.05, 0.10
+    m = chad.TSDFMap(res, trunc, space_carving=True)
+    plain = chad.TSDFMap(res, trunc)
+    o = oracle.OracleMap(res, trunc)
+    o.set_carving(True)
+    total = 0
+    for k, sensor in enumerate([(0.3, -0.2, 0.1), (2.5, 1.0, -0.4), (-3.0, -2.0, 0.6)]):
+        pts, pos = synth.cfg2_frame(120_000, seed=80 + k, sensor=sensor)
+        if k == 2:   # an obstacle that was there in the first two scans' free space: rays of later frames pass through its band
+            pts = np.concatenate([pts, synth.box_scan(30_000, (-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), (0.0, 0.0, 0.0), 99) + np.float32(0.0)]).astype(np.float32)
+        m.insert(pts, pos); plain.insert(pts, pos); o.insert(pts, pos)
+        total += m.stats()["updates"]
+    got, want, base = m.export_leaves(), o.export_leaves(), plain.export_leaves()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    assert np.array_equal(got[0], base[0])                       # carving creates nothing ...
+    carved = got[2] > base[2]
+    assert 1_000 < carved.sum() and np.all(got[2] >= base[2])    # ... it adds observations to leaves that rays pass through
+    assert int(got[2].sum()) == total                             # (they count as updates)
+    assert np.all(got[1][carved] >= base[1][carved] - 1e-6)      # towards +trunc: free space
+    err = np.abs(got[1] - want[1]) / np.maximum(np.abs(want[1]), trunc)
+    assert err.max() <= SD_TOL
+    m.close(); plain.close()
+
+
+def test_submap_positions_and_re_posing(chad):
+    """Loop-closure support (SURVEY.md section 8 f4): the poses of a submap's frames come back (Submap::positions, submap.hpp:110),
+    and a rigid correction of a closed submap moves its leaves and its mesh -- and nothing else."""
+    m = chad.TSDFMap(0.05, 0.10)
+    poses = []
+    for k in range(0, 130, 10):      # 0.5 m per frame: the submap closes when frame 110 arrives
+        pts, pos = synth.cfg3_frame(k, 30_000)
+        m.insert(pts, pos)
+        poses.append(pos)
+    m.sync()
+    assert m.closed_submaps == 1
+    assert np.array_equal(m.submap_positions(0), np.stack(poses[:11])) and np.array_equal(m.submap_positions(-1), np.stack(poses[11:]))
+    before = np.concatenate(list(m.iter_leaves(0)))
+    v0, t0 = m.mesh(0)
+    c, s_ = np.float32(np.cos(0.3)), np.float32(np.sin(0.3))
+    R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+    t = np.array([0.5, -1.25, 0.125], np.float32)
+    with pytest.raises(chad._lib.ChadError):
+        m.set_submap_pose(-1, R, t)              # only closed submaps
+    m.set_submap_pose(0, R, t)
+    after = np.concatenate(list(m.iter_leaves(0)))
+    p0 = np.stack([before["x"], before["y"], before["z"]], 1)
+    p1 = np.stack([after["x"], after["y"], after["z"]], 1)
+    assert np.allclose(p1, p0 @ R.T + t, atol=1e-5) and np.array_equal(after["signed_distance"], before["signed_distance"])
+    v1, t1 = m.mesh(0)
+    assert np.array_equal(t1, t0) and np.allclose(v1, v0 @ R.T + t, atol=1e-5)
+    assert np.array_equal(m.export_leaves(0)[0], m.export_leaves(0)[0])   # the stored voxels do not move
+    m.reset()
+    assert len(m.submap_positions(-1)) == 0
+    m.close()
