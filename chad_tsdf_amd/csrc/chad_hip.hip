@@ -123,6 +123,7 @@ struct FrameSlot {
     uint32_t* d_seg = nullptr;
 };
 
+struct chad_iter;
 struct chad_map {
     float res = 0, trunc = 0, recip = 0;
     int device = 0;
@@ -170,6 +171,7 @@ struct chad_map {
     std::vector<std::array<uint32_t, 2>> dag_roots;  // submap.hpp:108-109 of the closed submaps folded so far (a prefix of `closed`)
     float dag_ms_device = 0, dag_ms_host = 0;
     uint64_t dag_generation = 0;                  // bumped when the DAG is thrown away (chad_map_reset): iterators of an older generation are dead
+    std::vector<chad_iter*> iterators;            // the iterators handed out and not yet destroyed: chad_map_destroy cuts them loose
     // the last mesh extracted (chad_map_mesh is called twice: sizes, then data)
     int32_t mesh_submap = INT32_MIN;
     std::vector<float> mesh_vertices;
@@ -189,6 +191,7 @@ struct chad_map {
     uint64_t frames_empty_tail = 0;               // empty inserts since the last one with points (they use no slot)
     // Frame-sharded multi-GPU map (chad_map_attach_comm): insert k of the stream is integrated by rank k % world only, and a
     // submap is closed by merging the ranks' partial bricks (merge_and_close) instead of archiving the local ones.
+    bool copy_pool_failed = false;
     std::unique_ptr<CopyPool> copy_pool;          // helper threads of chad_map_insert's staging copy (made by the first large host frame)
     chad_comm* comm = nullptr;
     uint64_t stream_frames = 0;                   // inserts seen since the communicator was attached
@@ -1035,8 +1038,11 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     return CHAD_OK;
 }
 
+static void orphan_iterators(chad_map* m);   // (chad_iter is defined with the read-back API below)
+
 void chad_map_destroy(chad_map* m) {
     if (!m) return;
+    orphan_iterators(m);   // iterators that outlive the map report invalid instead of dangling
     DeviceGuard guard(m->device);
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
@@ -1142,9 +1148,12 @@ chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float
         hipError_t dma = hipSuccess;
         auto start_dma = [&](size_t at, size_t len) { if (dma == hipSuccess) dma = hipMemcpyAsync(device + at, pinned + at, len, hipMemcpyHostToDevice, f.prep); };
         if (helpers > 0 && n * 12 >= 3 * chunk) {   // a helper thread shares the copy (one thread: ~25 GB/s; the DMA: ~30-50)
-            if (!m->copy_pool) m->copy_pool.reset(new CopyPool(helpers));
-            m->copy_pool->copy(src, pinned, n * 12, chunk, start_dma);
-        } else
+            if (!m->copy_pool && !m->copy_pool_failed) {
+                try { m->copy_pool.reset(new CopyPool(helpers)); } catch (...) { m->copy_pool_failed = true; }   // (no thread to be had: the caller copies alone)
+            }
+        }
+        if (m->copy_pool && n * 12 >= 3 * chunk) m->copy_pool->copy(src, pinned, n * 12, chunk, start_dma);
+        else
             for (size_t at = 0; at < n * 12; at += chunk) {
                 const size_t len = std::min(chunk, n * 12 - at);
                 std::memcpy(pinned + at, src + at, len);
@@ -1622,12 +1631,24 @@ chad_status chad_map_iter_begin(chad_map* m, int32_t submap, chad_iter** out) {
     chad_iter* it = new chad_iter{m, m->dag_generation, submap, DagCursor{}};
     it->cursor.open(m->dag, m->dag_roots[size_t(submap)][0], m->dag_roots[size_t(submap)][1]);
     it->cursor.first();
+    m->iterators.push_back(it);
     *out = it;
     return CHAD_OK;
 }
 
-void chad_iter_destroy(chad_iter* it) { delete it; }
+void chad_iter_destroy(chad_iter* it) {
+    if (!it) return;
+    if (it->map) {
+        auto& list = it->map->iterators;
+        list.erase(std::remove(list.begin(), list.end(), it), list.end());
+    }
+    delete it;
+}
 
+static void orphan_iterators(chad_map* m) {
+    for (chad_iter* it : m->iterators) it->map = nullptr;
+    m->iterators.clear();
+}
 static bool iter_alive(const chad_iter* it) { return it && it->map && it->generation == it->map->dag_generation; }
 
 int32_t chad_iter_valid(const chad_iter* it) { return iter_alive(it) && it->cursor.valid ? 1 : 0; }

@@ -122,7 +122,13 @@ def test_iterator_walks_a_closed_submap(chad, oracle):
     assert not keep.valid
     with pytest.raises(chad._lib.ChadError):
         keep.advance(1)
-    m.close()
+    m.insert(pts, pos)
+    m.close_submap()
+    orphan = LeafIterator(m, 0)
+    assert orphan.valid
+    m.close()                                                   # ... and an iterator that outlives its map is cut loose by the destroy
+    assert not orphan.valid
+    orphan.close()
 
 
 def test_queries_of_the_active_submap_match_the_oracles_octree(chad, oracle):
