@@ -365,9 +365,12 @@ def main():
         dev = [torch.from_numpy(outdoor_frames[k][0]).cuda() for k in range(args.outdoor_frames)]
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
-        m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"])
+        # the map at the size this trajectory needs (2^22 blocks: no table doubling inside the timed region) and its spare table made
+        # by a roll-over in the warm-up: multi-GB hipMalloc / hipFree calls take anything from 2 to 200 ms depending on the box
+        m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22)
         m5.insert(dev[0], outdoor_frames[0][1], ready=True)
         v5 = len(m5.export_leaves()[0])   # distinct voxels one frame touches (into an empty map)
+        m5.close_submap(); m5.sync()
         m5.reset(); m5.sync(); m5.stats()
         t1 = time.perf_counter()
         for k in range(args.outdoor_frames):
@@ -378,7 +381,7 @@ def main():
         held = free0 - torch.cuda.mem_get_info()[0]
         b5 = 24 * c5["n"] + 16 * v5
         u5 = float(s5["ms_oct_upd"])
-        out["cfg5"] = {"workload": f"{args.outdoor_frames} frames x {c5['n']} points, 40x40x11.5 m box sliding with the sensor (0.5 m per frame, roll-over every 11 frames), voxel 0.02 m, trunc 0.06 m",
+        out["cfg5"] = {"workload": f"{args.outdoor_frames} frames x {c5['n']} points, 40x40x11.5 m box sliding with the sensor (0.5 m per frame, roll-over every 11 frames), voxel 0.02 m, trunc 0.06 m; table pre-sized to 2^22 blocks",
                        "ms_per_frame": round(t5 / args.outdoor_frames * 1e3, 4), "points_per_s": round(args.outdoor_frames * c5["n"] / t5),
                        "update_kernel_ms": round(u5, 4), "update_algorithmic_bytes": b5, "update_GBps": round(b5 / u5 / 1e6, 1) if u5 > 0 else None,
                        "update_frac": round(b5 / u5 / 1e6 / HBM_PEAK_GBS, 5) if u5 > 0 else None, "voxels_per_frame": v5,
