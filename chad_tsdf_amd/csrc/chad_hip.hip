@@ -864,7 +864,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 20;
         LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(256 * normal_waves_per_cu / kNormalWaves), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                     reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, big_groups);
+                     reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, big_groups, item_start);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -966,7 +966,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
     m->fixed_capacity = (o.flags & CHAD_FLAG_FIXED_CAPACITY) != 0;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
-    if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)hipMalloc(&m->d_stamps, 8192 * 8 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 8 * 8); }
+    if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)hipMalloc(&m->d_stamps, 8192 * 16 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 16 * 8); }
     auto bail = [&](chad_status s) { chad_map_destroy(m); return s; };
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
@@ -1047,18 +1047,27 @@ void chad_map_destroy(chad_map* m) {
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->d_stamps) {  // diagnostic: mean cycles per phase over the waves of the last update launch
-        std::vector<unsigned long long> st(8192 * 8);
+        std::vector<unsigned long long> st(8192 * 16);
         (void)hipMemcpy(st.data(), m->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
-        std::vector<unsigned long long> life, start, items;
-        for (int w = 0; w < 8192; w++) { if (!st[w * 8 + 5]) continue; life.push_back(st[w * 8 + 5]); start.push_back(st[w * 8 + 1]); items.push_back(st[w * 8 + 2]); }
+        std::vector<unsigned long long> life, barriers, items, entry, loop, done, zeroed, lists;
+        for (int w = 0; w < 8192; w++) {
+            if (!st[w * 16 + 5]) continue;
+            life.push_back(st[w * 16 + 5]); barriers.push_back(st[w * 16 + 1]); items.push_back(st[w * 16 + 2]);
+            entry.push_back(st[w * 16 + 8]); loop.push_back(st[w * 16 + 9]); done.push_back(st[w * 16 + 10]); zeroed.push_back(st[w * 16 + 11]); lists.push_back(st[w * 16 + 12]);
+        }
         if (!life.empty()) {
             auto pct = [](std::vector<unsigned long long> v, double p) { std::sort(v.begin(), v.end()); return v[size_t(p * (v.size() - 1))]; };
-            const unsigned long long s0 = pct(start, 0.0);
-            std::fprintf(stderr, "stamps: waves %zu  life p10 %llu p50 %llu p90 %llu max %llu | start p50 +%llu p90 +%llu max +%llu | items p10 %llu p50 %llu p90 %llu max %llu\n", life.size(),
-                         pct(life, 0.1), pct(life, 0.5), pct(life, 0.9), pct(life, 1.0), pct(start, 0.5) - s0, pct(start, 0.9) - s0, pct(start, 1.0) - s0,
+            std::fprintf(stderr, "stamps: waves %zu  life p10 %llu p50 %llu p90 %llu max %llu cycles | barriers p50 %llu p90 %llu max %llu | items p10 %llu p50 %llu p90 %llu max %llu\n", life.size(),
+                         pct(life, 0.1), pct(life, 0.5), pct(life, 0.9), pct(life, 1.0), pct(barriers, 0.5), pct(barriers, 0.9), pct(barriers, 1.0),
                          pct(items, 0.1), pct(items, 0.5), pct(items, 0.9), pct(items, 1.0));
+            // the constant clock (10 ns ticks), relative to the first wave's entry: when the waves were started, reached their first item and finished
+            const unsigned long long e0 = pct(entry, 0.0);
+            auto rel = [&](std::vector<unsigned long long> v, double p) { return 0.01 * double(pct(v, p) - e0); };
+            std::fprintf(stderr, "stamps: us after the first wave's entry: entry p50 %.2f p90 %.2f max %.2f | first item p10 %.2f p50 %.2f p90 %.2f max %.2f | done p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+                         rel(entry, 0.5), rel(entry, 0.9), rel(entry, 1.0), rel(loop, 0.1), rel(loop, 0.5), rel(loop, 0.9), rel(loop, 1.0), rel(done, 0.1), rel(done, 0.5), rel(done, 0.9), rel(done, 1.0));
+            std::fprintf(stderr, "stamps: us after the first wave's entry: tile zeroed p50 %.2f p90 %.2f | lists in LDS p50 %.2f p90 %.2f max %.2f\n", rel(zeroed, 0.5), rel(zeroed, 0.9), rel(lists, 0.5), rel(lists, 0.9), rel(lists, 1.0));
             double sum[8] = {};
-            for (int w = 0; w < 8192; w++) if (st[w * 8 + 5]) for (int k = 0; k < 8; k++) sum[k] += double(st[w * 8 + k]);
+            for (int w = 0; w < 8192; w++) if (st[w * 16 + 5]) for (int k = 0; k < 8; k++) sum[k] += double(st[w * 16 + k]);
             std::fprintf(stderr, "stamps: mean cycles per wave: fetch %.0f walk %.0f readback %.0f hash %.0f flush %.0f life %.0f\n", sum[0] / life.size(), sum[3] / life.size(),
                          sum[6] / life.size(), sum[7] / life.size(), sum[4] / life.size(), sum[5] / life.size());
         }
@@ -1169,7 +1178,7 @@ chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float
 chad_status read_back_header(chad_map* m, uint32_t* overflow) {
     TRY(flush_pending_clear(m));
     TRY(join_streams(m));
-    HIP_TRY(hipMemcpy(m->h_hdr, m->slot[m->last_slot].d_hdr, sizeof(FrameHeader), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(m->h_hdr, m->slot[m->last_slot].d_hdr, offsetof(FrameHeader, first_item), hipMemcpyDeviceToHost));   // (the scalars and counters; not the update kernel's item table)
     HIP_TRY(hipMemcpy(overflow, m->d_overflow, 4, hipMemcpyDeviceToHost));
     return CHAD_OK;
 }

@@ -29,6 +29,7 @@ constexpr uint32_t kBigItem = 384;     // items longer than this are handed out 
 constexpr uint32_t kWorkGroups = 256; // update waves pull items from one of this many counters (blockIdx % kWorkGroups)
 constexpr uint32_t kListStripes = 16; // stripes of the frame's block / work-item lists (FrameHeader::list_count)
 constexpr uint32_t kSparsePointsPerBlock = 6;  // frames with fewer points per block than this take the scatter form of the update
+constexpr uint32_t kFirstItems = 2048; // workgroups of the update kernel whose first work item k_frame_normals looks up for them (FrameHeader::first_item)
 constexpr uint32_t kBigBlock = 256;   // point blocks with more points than this get a workgroup of four waves in k_frame_normals (a wave works a
                                       // block off in a chain proportional to its size: with one wave each, the few blocks next to the sensor -- a
                                       // thousand points and more -- set the kernel's duration: 45 us, 25 us without them)
@@ -52,7 +53,16 @@ struct FrameHeader {
     // ~25 ns each, half of that kernel's 26 us.  Stripe s of a list owns entries [s * stride, (s + 1) * stride) of its array,
     // stride = capacity / kListStripes + kGatherChunk; long items fill a stripe's range from the front, short ones from the back.
     uint32_t list_count[4][kListStripes * 16];
+    // For the update kernel, written by the last workgroup of k_frame_normals (the lists are complete by then): where each stripe's
+    // long / short work items begin when counted through the stripes in order ([list][kListStripes] = the list's total), whether the
+    // frame is sparse, and the record of work item v for the first kFirstItems items -- workgroup b of the update kernel starts on
+    // item b.  Looked up by every workgroup for itself these were three dependent round trips (stripe counts -> item record ->
+    // points) in front of the first ray, 4.9 us of the kernel's 31 (in-kernel stamps); now it is two.
+    uint32_t item_first[2][kListStripes + 1];
+    uint32_t frame_sparse, reserved4;
+    uint4 first_item[kFirstItems];
 };
+static_assert(offsetof(FrameHeader, first_item) % 16 == 0, "first_item[] is read with 16-byte loads");
 // (the large point blocks -- more than kBigBlock points -- are listed a second time, from the back of the block list's stripes:
 // k_frame_normals gives each of them a whole workgroup)
 enum { kListBlocks = 0, kListLongItems = 1, kListShortItems = 2, kListBigBlocks = 3 };
@@ -821,6 +831,34 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
     sync();
 }
 
+// The update kernel's view of the work-item lists (FrameHeader::item_first / frame_sparse / first_item), by one workgroup.
+__device__ __forceinline__ void publish_item_summary(FrameHeader* __restrict__ h, const uint4* __restrict__ items, uint32_t list_stride, bool sparse) {
+    __shared__ uint32_t first[2][kListStripes + 1];
+    if (threadIdx.x < 2 * kListStripes) {   // lanes 0..15: long items, 16..31: short items; a 16-lane inclusive scan each
+        const uint32_t list = threadIdx.x / kListStripes, stripe = threadIdx.x % kListStripes;
+        uint32_t incl = h->list_count[list ? kListShortItems : kListLongItems][stripe * 16];
+#pragma unroll
+        for (int o = 1; o < int(kListStripes); o <<= 1) { const uint32_t t = __shfl_up(incl, o, kListStripes); if (int(stripe) >= o) incl += t; }
+        first[list][stripe + 1] = incl;
+        if (stripe == 0) first[list][0] = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * (kListStripes + 1)) (&h->item_first[0][0])[threadIdx.x] = (&first[0][0])[threadIdx.x];
+    if (threadIdx.x == 0) h->frame_sparse = sparse ? 1u : 0u;
+    const uint32_t n_long = first[0][kListStripes], nitems = n_long + first[1][kListStripes];
+    for (uint32_t v = threadIdx.x; v < min(nitems, kFirstItems); v += blockDim.x) {
+        // long items fill a stripe's range of items[] from the front, short ones from the back (k_frame_gather)
+        const bool is_long = v < n_long;
+        const uint32_t* f = first[is_long ? 0 : 1];
+        const uint32_t i = is_long ? v : v - n_long;
+        uint32_t stripe = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < kListStripes; k++) stripe = i >= f[k] ? k : stripe;
+        const uint32_t index = i - f[stripe];
+        h->first_item[v] = items[is_long ? stripe * list_stride + index : (stripe + 1u) * list_stride - 1u - index];
+    }
+}
+
 // Workgroups of four waves.  In a dense frame the first kNormalBigGroups workgroups take the large point blocks (more than
 // kBigBlock points: k_frame_gather lists them), one block at a time with all four waves; every other wave takes small blocks, one
 // wave per block, the waves of a workgroup sharing nothing.  (The large workgroups have the lowest indices, so they start first:
@@ -828,7 +866,8 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
 __global__ void __launch_bounds__(64 * kNormalWaves, 5)  // <= 96 VGPRs: 20 waves per CU (7.2 KiB of LDS per wave)
 k_frame_normals(float4* __restrict__ points0, float4* __restrict__ points1, float recip,
                 const uint2* __restrict__ segments, uint32_t list_stride,
-                FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate, uint32_t big_block, uint32_t max_big_groups) {
+                FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate, uint32_t big_block, uint32_t max_big_groups,
+                const uint4* __restrict__ items) {
     __shared__ NormalScratch scratch[kNormalWaves];
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points: by block, input order inside
     float4* __restrict__ ordered = (h->sort_passes & 1u) ? points0 : points1;     // the sort's other buffer: the same blocks, each in the reference's order
@@ -859,6 +898,7 @@ k_frame_normals(float4* __restrict__ points0, float4* __restrict__ points1, floa
         return segments[stripe * list_stride + index];
     };
     const bool sparse = n < kSparsePointsPerBlock * nseg;   // frame_is_sparse
+    if (blockIdx.x == gridDim.x - 1u) publish_item_summary(h, items, list_stride, sparse);   // (never one of the large blocks' workgroups)
     // the large blocks' workgroups (none in a sparse frame or when there is no large block)
     uint32_t big_groups = 0;
     if (!sparse && !(ablate & 128u)) {

@@ -94,37 +94,37 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
                FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t items_capacity /* entries per stripe of items[] */,
                unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+    unsigned long long wall_entry = 0, wall_loop = 0, wall_zeroed = 0, wall_lists = 0;   // kStamps: constant-clock (10 ns) times of the wave's entry and of its first item
+    if (kStamps) wall_entry = wall_clock64();
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order: k_frame_normals' output (the sort's other buffer)
-    if (adaptive && frame_is_sparse(h)) {  // about one point per block: staging tiles is pure overhead, take the general form
-        scatter_update(pts, normals, h, pos, res, recip, trunc, m);
-        return;
-    }
     const int R = int(reach), D = 8 + 2 * R;
     const uint32_t cells = uint32_t(D * D * D);
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-    // cells + 1 words: the last one is never added to and stands in for cells outside the tile; then the next item's record
+    // cells + 2 words: the last two are never added to -- cell `cells` stands in for cells outside the tile, and the pair is what
+    // the read-back of step 2 looks at for rows outside the tile; then the next item's record
     unsigned long long* tile = reinterpret_cast<unsigned long long*>(tile_raw);
-    uint4* next_record = reinterpret_cast<uint4*>(tile + ((cells + 2u) & ~1u));
+    uint4* next_record = reinterpret_cast<uint4*>(tile + ((cells + 3u) & ~1u));
     const uint32_t tile_base = uint32_t(uintptr_t(tile));  // LDS byte address (low half of the flat address)
     const float to_fixed = kFixedOne / trunc;
-    // (the stripe counts of the work lists are loaded here so that their latency overlaps the zeroing of the tile)
-    uint32_t stripe_count = 0;
-    if (threadIdx.x < 2 * kListStripes) stripe_count = h->list_count[threadIdx.x / kListStripes ? kListShortItems : kListLongItems][(threadIdx.x % kListStripes) * 16];
-    for (uint32_t k = threadIdx.x; k <= cells; k += kTileThreads) tile[k] = 0ull;
-    // the work list: the long items of all stripes first, then the short ones (k_frame_gather; FrameHeader::list_count)
-    // Where each stripe's entries begin, in LDS (registers are scarce here): first_long[s], first_short[s], s = 0 .. kListStripes.
+    // Everything the workgroup needs to know about the frame's work lists comes ready-made from k_frame_normals (FrameHeader::
+    // item_first, frame_sparse, first_item): ONE round trip, in flight while the tile is zeroed -- the long items of all stripes
+    // first, then the short ones (k_frame_gather); where each stripe's entries begin goes to LDS (registers are scarce here):
+    // first_long[s], first_short[s], s = 0 .. kListStripes.
     uint32_t* first_long = reinterpret_cast<uint32_t*>(next_record + 1);
     uint32_t* first_short = first_long + kListStripes + 1;
-    if (threadIdx.x < 2 * kListStripes) {   // lanes 0..15: long items, 16..31: short items; a 16-lane inclusive scan each
-        const uint32_t list = threadIdx.x / kListStripes, stripe = threadIdx.x % kListStripes;
-        uint32_t incl = stripe_count;
-#pragma unroll
-        for (int o = 1; o < int(kListStripes); o <<= 1) { const uint32_t t = __shfl_up(incl, o, kListStripes); if (int(stripe) >= o) incl += t; }
-        uint32_t* first = list ? first_short : first_long;
-        first[stripe + 1] = incl;
-        if (stripe == 0) first[0] = 0u;
+    uint32_t summary_word = 0;
+    if (threadIdx.x < 2 * (kListStripes + 1)) summary_word = (&h->item_first[0][0])[threadIdx.x];
+    const uint32_t sparse = adaptive ? h->frame_sparse : 0u;
+    uint4 record = h->first_item[blockIdx.x];   // (meaningless beyond the frame's last item: masked below)
+    for (uint32_t k = threadIdx.x; k <= cells + 1u; k += kTileThreads) tile[k] = 0ull;
+    if (kStamps) wall_zeroed = wall_clock64();
+    if (threadIdx.x < 2 * (kListStripes + 1)) first_long[threadIdx.x] = summary_word;
+    if (sparse) {  // about one point per block: staging tiles is pure overhead, take the general form
+        scatter_update(pts, normals, h, pos, res, recip, trunc, m);
+        return;
     }
     tile_barrier();
+    if (kStamps) wall_lists = wall_clock64();
     const uint32_t n_long = first_long[kListStripes], nitems = n_long + first_short[kListStripes];
     auto item_record = [&](uint32_t v) {
         const bool is_long = v < n_long;
@@ -154,10 +154,10 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
 
     const uint32_t group = blockIdx.x % kWorkGroups;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t_begin = 0, items_done = 0;
-    if (kStamps) t_begin = stamp_now();
+    if (kStamps) { t_begin = stamp_now(); }
 
     // everything a wave holds about an item before it starts on it
-    uint4 record = blockIdx.x < nitems ? item_record(blockIdx.x) : make_uint4(0u, 0u, 0u, 0u);   // length 0: no more work
+    if (blockIdx.x >= nitems) record = make_uint4(0u, 0u, 0u, 0u);   // length 0: no more work
     float4 q_first = make_float4(0, 0, 0, 0), n_first = make_float4(0, 0, 0, 0);            // its first chunk's point and normal for this lane
     uint64_t my_key = kEmptyKey, early = kEmptyKey;                                         // lanes 0..15: key of their brick, what its home slot held
     uint32_t my_slot = 0;
@@ -186,6 +186,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     prefetch(record);
     uint32_t turn = 0;  // first lane of the last wave: ticket of the item after the current one (in flight during the walk)
     tile_barrier();     // the tile is zeroed
+    if (kStamps) wall_loop = wall_clock64();
 
     while (__builtin_amdgcn_readfirstlane(int(record.y)) != 0) {
         if (kStamps) { t0 = stamp_now(); items_done++; }
@@ -274,15 +275,32 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
         // step 2: which of this wave's 16 bricks received observations (four reads in flight at a time)
         const uint64_t this_key = my_key;
         const uint32_t this_slot = my_slot;
+        // Only "does any cell of the brick hold something" is asked here, so the lanes need not sit on their voxels: 16 lanes per
+        // brick, one per (y, z) row of four cells along x, four bricks (bx = 0..3 of one by) per pass -- 4 passes instead of 16, no
+        // branches, all reads in flight together (the voxel-per-lane form compiled to sixteen dependent LDS round trips under
+        // exec masks: 3 300 cycles per item).  A row outside the tile reads the two spare zero cells; a brick cut by the tile's
+        // rim along x reads its cells inside (two at least, for reach >= 2), some of them twice.
         uint32_t touched = 0;
-#pragma unroll 1
-        for (int by = 0; by < 4; by++) {   // four bricks at a time: one address register, the four reads in flight together
-            const unsigned long long* row = tile + cell_of(4 * by);
-            const uint32_t valid4 = lane_valid >> (4 * by);
-            uint32_t t4 = 0;
+        {
+            const int rx = 4 * int(lane >> 4) + R - 4, ry = int(lane & 3u) + R - 4, rz = 4 * int(wave) + int((lane >> 2) & 3u) + R - 4;
+            const int lo = max(rx, 0), hi = min(rx + 3, D - 1);
+            const uint32_t zero_at = tile_base + 8u * cells;
+            const uint32_t row_a = tile_base + 8u * uint32_t(lo + D * ry + D * D * rz), delta_b = 8u * uint32_t(max(hi - 1 - lo, 0));
+            const bool z_ok = uint32_t(rz) < uint32_t(D);
+            unsigned long long any[4];
 #pragma unroll
-            for (int bx = 0; bx < 4; bx++) t4 |= __ballot(((valid4 >> bx) & 1u) && row[4 * bx] != 0ull) ? (1u << bx) : 0u;
-            touched |= t4 << (4 * by);
+            for (int by = 0; by < 4; by++) {
+                const bool ok = z_ok && uint32_t(ry + 4 * by) < uint32_t(D);
+                const uint32_t a = ok ? row_a + uint32_t(by) * uint32_t(32 * D) : zero_at;
+                const uint32_t b = ok ? a + delta_b : zero_at;
+                any[by] = lds_cell(a)[0] | lds_cell(a)[1] | lds_cell(b)[0] | lds_cell(b)[1];
+            }
+#pragma unroll
+            for (int by = 0; by < 4; by++) {
+                const uint64_t rows = __ballot(any[by] != 0ull);
+                const uint32_t t4 = ((rows & 0xffffull) ? 1u : 0u) | ((rows & 0xffff0000ull) ? 2u : 0u) | ((rows & 0xffff00000000ull) ? 4u : 0u) | ((rows >> 48) ? 8u : 0u);
+                touched |= t4 << (4 * by);
+            }
         }
         if (kStamps) { asm volatile("" :: "s"(touched)); const unsigned long long t1 = stamp_now(); ph[6] += t1 - t0; t0 = t1; }
         // touched bricks whose key the speculative look-up did not show: one CAS claims or finds the home slot.  It is
@@ -335,7 +353,9 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
         ph[5] = stamp_now() - t_begin;
         ph[1] += ph[2];         // both barriers
         ph[2] = items_done;
-        for (int k = 0; k < 8; k++) stamps[size_t(wave_global) * 8 + k] = ph[k];
+        for (int k = 0; k < 8; k++) stamps[size_t(wave_global) * 16 + k] = ph[k];
+        stamps[size_t(wave_global) * 16 + 8] = wall_entry; stamps[size_t(wave_global) * 16 + 9] = wall_loop; stamps[size_t(wave_global) * 16 + 10] = wall_clock64();
+        stamps[size_t(wave_global) * 16 + 11] = wall_zeroed; stamps[size_t(wave_global) * 16 + 12] = wall_lists;
     }
     unsigned long long total = applied;
 #pragma unroll
@@ -345,7 +365,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
 
 inline uint32_t tile_reach(float res, float trunc) {
     const float r = std::ceil(trunc / res) + 1.0f;
-    return r < 1.0f ? 1u : (r > float(kMaxReach) ? kMaxReach : uint32_t(r));
+    return r < 2.0f ? 2u : (r > float(kMaxReach) ? kMaxReach : uint32_t(r));   // (at least 2: the read-back of step 2 wants two cells of every brick inside the tile along x)
 }
 
 inline void tile_update_enqueue(const float4* points0, const float4* points1, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
@@ -353,7 +373,7 @@ inline void tile_update_enqueue(const float4* points0, const float4* points1, co
                                 hipEvent_t started = nullptr, hipEvent_t stopped = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
     const uint32_t d = 8 + 2 * reach;
-    const size_t lds = ((size_t(d) * d * d + 2) & ~size_t(1)) * 8 + 16 + 2 * (kListStripes + 1) * 4 + 8;   // tile + spare zero cell (padded to 16 bytes) + next item's record + list index
+    const size_t lds = ((size_t(d) * d * d + 3) & ~size_t(1)) * 8 + 16 + 2 * (kListStripes + 1) * 4 + 8;   // tile + two spare zero cells (padded to 16 bytes) + next item's record + list index
     // persistent workgroups: as many as are resident at once (registers and LDS decide), on every CU
     static int resident[2] = {0, 0};
     static size_t resident_lds = 0;
@@ -364,7 +384,8 @@ inline void tile_update_enqueue(const float4* points0, const float4* points1, co
         resident_lds = lds;
     }
     uint32_t per_cu = uint32_t(std::max(1, std::min(8, resident[stamps ? 1 : 0])));
-    if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::atoi(e));
+    if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::max(1, std::min(8, std::atoi(e))));
+    static_assert(256 * 8 <= kFirstItems, "every workgroup finds its first item in FrameHeader::first_item");
     // 5 waves per SIMD (<= 96 VGPRs): a 6-wave build (80 VGPRs) spills and measured slower
     if (stamps)
         hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
