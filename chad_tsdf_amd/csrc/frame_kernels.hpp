@@ -17,6 +17,8 @@
 // position of its 2x2x2-block "super block" (8x8x8 voxels, the unit the update kernel stages in LDS) and three bits
 // for the block inside it, so that the points of a super block are contiguous as well.
 #pragma once
+#include <type_traits>
+
 #include "device_math.hpp"
 #include "radix_sort.hpp"
 
@@ -369,6 +371,8 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
     __shared__ uint32_t word_rank[2][kWords], word_next[2][kWords];
     __shared__ uint32_t base_heads, n_big, n_small, base_big, base_small, trail_extra;
     __shared__ unsigned long long wave_mc[4], block_mc_min;
+    const uint32_t n = h->n_usable;            // (loaded beside the partials below: one round trip, not two)
+    const bool odd = h->sort_passes & 1u;
     // frame-wide smallest code from the keys kernel's partials
     {
         unsigned long long m = ~0ull;
@@ -385,8 +389,6 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
         __syncthreads();
     }
     const unsigned long long mc_min = block_mc_min;
-    const uint32_t n = h->n_usable;
-    const bool odd = h->sort_passes & 1u;
     const uint64_t* keys = odd ? keys1 : keys0;
     const float4* pts = odd ? points1 : points0;   // the sort carries the points along: its last pass left them in processing order
     const uint32_t chunks = (n + kGatherChunk - 1) / kGatherChunk;
@@ -491,26 +493,30 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
 }
 
 // ---- Stage 4: normals (normals.hpp:10-148) -------------------------------------------------------------------
-// One wave per point block.  The block's <= 64 voxel runs are counted into LDS, the greedy neighbourhood walk
-// runs over those 64 counters (not over the points), then the neighbourhoods are fitted with the reference's
-// two-pass f64 "plane from points" -- small ones by one lane each in the reference's summation order, large ones
-// by 16-lane teams or the whole wave -- and every point picks up its neighbourhood's normal (or the per-point fallback when the
-// neighbourhood has < 8 points).
+// One wave per point block (four for the large ones).  The block's <= 64 voxel runs are counted into LDS, the greedy neighbourhood
+// walk runs over those 64 counters (not over the points), then the neighbourhoods are fitted with the reference's two-pass f64
+// "plane from points" -- teams of 8 or 16 lanes per neighbourhood, the whole wave for the largest -- and every point picks up its
+// neighbourhood's normal (or the per-point fallback when the neighbourhood has < 8 points).
 
 constexpr uint32_t kMinPoints = 8;    // normals.hpp:88
 constexpr int kMaxNormalWaves = 4;    // waves that may share a point block (k_frame_normals' workgroup)
 constexpr uint32_t kStagePoints = 256;  // points of a block kept in LDS for the fits (4 KiB)
-constexpr uint32_t kTeamPoints = 16;    // neighbourhoods of 16..255 points are fitted by a 16-lane team (4 at a time); from 8 on: no faster, and the one-lane fits keep the reference's summation order
+constexpr uint32_t kTeamPoints = 32;    // neighbourhoods of 32..255 points are fitted by a 16-lane team (4 at a time), those of 8..31 points by an 8-lane team (8 at a time)
 constexpr uint32_t kCoopPoints = 256;   // neighbourhoods at least this large are fitted by the whole wave
 
+constexpr uint32_t kCovSlots = 21;       // neighbourhoods whose covariance terms fit into the counting sort's 1 KiB (a wave on its own; a team of waves uses a neighbour's scratch)
 struct NormalScratch {         // per wave, in LDS
     uint32_t group_of[64];     // neighbourhood of voxel v
     uint32_t g_first[64];      // first point (offset in the segment) of neighbourhood g
     uint32_t g_size[64];
     float g_normal[64][4];     // fitted normal; [3] != 0 marks "fit" (else per-point fallback)
-    uint32_t team_list[64];    // neighbourhoods fitted by 16-lane teams
-    uint32_t run[kMaxNormalWaves][64];   // counting sort by voxel: wave w's points per voxel, then the next free position of voxel v for wave w
-    float4 stage[kStagePoints];  // the block's first points IN VOXEL ORDER (x, y, z, input index)
+    uint32_t team_list[64];    // neighbourhoods fitted by teams: the 8-lane ones from the front, the 16-lane ones from the back
+    union {
+        uint32_t run[kMaxNormalWaves][64];   // counting sort by voxel: wave w's points per voxel, then the next free position of voxel v for wave w
+        double cov[kCovSlots][6];            // afterwards: covariance terms of fitted neighbourhoods waiting for their plane (estimate_block)
+    };
+    uint32_t cov_group[kCovSlots + 3];       // whose they are
+    float4 stage[kStagePoints];  // the block's first points IN VOXEL ORDER (x, y, z, voxel inside the block as an integer)
 };
 
 // normals.hpp:39-79 -- normal from the covariance terms: three determinant-weighted axis directions, each aligned
@@ -537,23 +543,6 @@ __device__ __forceinline__ F3 plane_from_covariance(double xx, double xy, double
     }
     const double inv = 1.0 / sqrt(wx * wx + wy * wy + wz * wz);  // :79
     return {float(wx * inv), float(wy * inv), float(wz * inv)};
-}
-
-// One lane fits one neighbourhood, summing in the reference's order (normals.hpp:12-36): bit-identical moments.
-// `pts` may point into LDS (staged block) or HBM.
-template <class Ptr>
-__device__ __forceinline__ F3 fit_plane(Ptr pts, uint32_t count) {
-    double cx = 0, cy = 0, cz = 0;
-    for (uint32_t k = 0; k < count; k++) { const float4 q = pts[k]; cx += double(q.x); cy += double(q.y); cz += double(q.z); }
-    const double recip = 1.0 / double(count);
-    cx *= recip; cy *= recip; cz *= recip;
-    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-    for (uint32_t k = 0; k < count; k++) {
-        const float4 q = pts[k];
-        const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
-        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
-    }
-    return plane_from_covariance(xx * recip, xy * recip, xz * recip, yy * recip, yz * recip, zz * recip);
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -598,6 +587,16 @@ __device__ __forceinline__ double team_sum_f64(double v) {
     v += dpp_move_f64<0x121>(v);  // row_ror:1
     return v;
 }
+
+// The same over the 8 lanes of a half row: mirror the half, then swap neighbours, then pairs.  Every lane of the eight ends up with
+// the same bits (each step adds the same two partial sums in one or the other order).
+__device__ __forceinline__ double team8_sum_f64(double v) {
+    v += dpp_move_f64<0x141>(v);  // row_half_mirror
+    v += dpp_move_f64<0xB1>(v);   // quad_perm:[1,0,3,2]
+    v += dpp_move_f64<0x4E>(v);   // quad_perm:[2,3,0,1]
+    return v;
+}
+template <uint32_t kWidth> __device__ __forceinline__ double team_sum(double v) { return kWidth == 8u ? team8_sum_f64(v) : team_sum_f64(v); }
 
 constexpr int kNormalWaves = 4;            // waves per workgroup of k_frame_normals
 constexpr uint32_t kNormalBigGroups = 512;  // its first workgroups (at most): one large point block each at a time, all four waves on it (scripts/sweep_big_blocks.sh)
@@ -657,10 +656,11 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
         for (uint32_t j = 0; j < kKeep; j++) { const uint32_t k = begin + 64u * j + lane; q[j] = k < end ? pts[first + k] : make_float4(0, 0, 0, 0); }
 #pragma unroll
         for (uint32_t j = 0; j < kKeep; j++) {
+            vr[j] = 0u;
+            if (begin + 64u * j >= end) continue;   // (wave-uniform) a step without points: the average block of a room scan has two of these
             const bool live = begin + 64u * j + lane < end;
             const uint32_t v = live ? voxel_in_block(q[j], recip) : 0u;
             const uint64_t same = same_voxel(v, live);
-            vr[j] = 0u;
             if (live) {
                 const uint32_t leader = uint32_t(__ffsll((unsigned long long)same)) - 1u;
                 uint32_t base = 0;
@@ -692,7 +692,7 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
             if (begin + 64u * j + lane < end) {
                 const uint32_t at = s.run[wave][vr[j] & 63u] + (vr[j] >> 8);
                 ordered[first + at] = q[j];
-                if (at < kStagePoints) s.stage[at] = q[j];
+                if (at < kStagePoints) s.stage[at] = make_float4(q[j].x, q[j].y, q[j].z, __uint_as_float(vr[j] & 63u));   // (the staged copy keeps the voxel, not the input index)
             }
     } else
         for (uint32_t k0 = begin; k0 < end; k0 += 64u) {
@@ -707,7 +707,7 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
                 if (lane == leader) { base = s.run[wave][v]; s.run[wave][v] = base + uint32_t(__popcll(same)); }
                 const uint32_t at = uint32_t(__shfl(base, int(leader))) + uint32_t(__popcll(same & lanes_below));
                 ordered[first + at] = p;
-                if (at < kStagePoints) s.stage[at] = p;
+                if (at < kStagePoints) s.stage[at] = make_float4(p.x, p.y, p.z, __uint_as_float(v));
             }
             wave_lds_fence();
         }
@@ -724,7 +724,7 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(cupto, o); if (int(lane) >= o) cupto += t; }
     const uint32_t cbefore = cupto - cnt;     // (== before everywhere: the missing point is the very last one)
     uint64_t rest = (ablate & 64u) ? 0ull : __ballot(cnt != 0);  // voxel runs not yet in a neighbourhood
-    uint32_t ngroups = 0, my_group = 0, nteams = 0, ncoop = 0;
+    uint32_t ngroups = 0, my_group = 0, nnarrow = 0, nwide = 0, ncoop = 0;
     while (rest) {
         const uint32_t l = uint32_t(__ffsll((unsigned long long)rest)) - 1u;  // highest remaining voxel
         const uint32_t start = read_lane(cbefore, l);
@@ -738,11 +738,14 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
                 size = read_lane(cupto, 63u) - start;
             }
         }
+        const bool narrow = size >= kMinPoints && size < kTeamPoints, wide = size >= kTeamPoints && size < kCoopPoints;
         if (lane == 0 && wave == 0) {
             s.g_first[ngroups] = start; s.g_size[ngroups] = size;
-            if (size >= kTeamPoints && size < kCoopPoints) s.team_list[nteams] = ngroups;
+            if (narrow) s.team_list[nnarrow] = ngroups;
+            if (wide) s.team_list[63u - nwide] = ngroups;
         }
-        if (size >= kTeamPoints && size < kCoopPoints) nteams++;
+        if (narrow) nnarrow++;
+        if (wide) nwide++;
         if (size >= kCoopPoints) ncoop++;
         if (lane >= l && lane <= l_end) my_group = ngroups;
         ngroups++;
@@ -768,66 +771,85 @@ __device__ __forceinline__ void estimate_block(NormalScratch& s, const uint2 rec
             }
         }
     }
-    // medium neighbourhoods: 16-lane teams, four per wave at a time; a team strides over its points (first from the
-    // staged LDS copy, the rest from HBM) and combines the moments with DPP row reductions
-    {
-        const uint32_t team = lane >> 4, tl = lane & 15u;
-        for (uint32_t r = 0; r * 4u * waves < ((ablate & 8u) ? 0u : nteams); r++) {
-            const uint32_t tg = (r * waves + wave) * 4u + team;
-            const bool on = tg < nteams;
-            const uint32_t g = on ? s.team_list[tg] : 0u;
+    // Every other neighbourhood of at least kMinPoints points: teams of lanes -- eight lanes for 8..31 points (eight neighbourhoods per
+    // wave at a time), sixteen for 32..255 (four at a time).  A team strides over its points (from the staged LDS copy, beyond it from
+    // HBM) and combines the moments of the reference's two passes (normals.hpp:12-36) with DPP reductions; the covariance terms are
+    // parked in LDS -- where the counting sort's counters were -- and the planes (normals.hpp:39-79) are worked out for all parked
+    // neighbourhoods at once, one lane each: per round of teams that part cost as much again as the moments.  (Round 1 fitted the
+    // neighbourhoods below 16 points with one lane each, in the reference's summation order: a handful of lanes busy for 700
+    // instructions in three blocks out of four.)
+    double (*cov)[6] = kTeam ? reinterpret_cast<double (*)[6]>(&(&s)[1]) : s.cov;   // a team of waves: the next wave's scratch is idle
+    uint32_t* cov_group = kTeam ? reinterpret_cast<uint32_t*>(&(&s)[2]) : s.cov_group;
+    const uint32_t cov_slots = kTeam ? 64u : kCovSlots;
+    uint32_t pending = 0;   // parked neighbourhoods (uniform over the workgroup)
+    auto planes = [&]() {
+        sync();
+        if (tid < pending && !(ablate & 16u)) {
+            const uint32_t g = cov_group[tid], g0 = s.g_first[g];
+            F3 nrm = plane_from_covariance(cov[tid][0], cov[tid][1], cov[tid][2], cov[tid][3], cov[tid][4], cov[tid][5]);
+            const float4 q = g0 < kStagePoints ? s.stage[g0] : sorted[g0];
+            const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
+            if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
+            s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
+        }
+        sync();
+        pending = 0;
+    };
+    auto team_rounds = [&](auto width, uint32_t count, auto entry) {
+        constexpr uint32_t kWidth = decltype(width)::value, kTeams = 64u / kWidth;
+        const uint32_t team = lane / kWidth, tl = lane % kWidth;
+        for (uint32_t done = 0; done < count; done += kTeams * waves) {
+            const uint32_t round = min(kTeams * waves, count - done);   // neighbourhoods of this round, over all waves
+            if (pending + round > cov_slots) planes();
+            const uint32_t slot = wave * kTeams + team;
+            const bool on = slot < round;
+            const uint32_t g = on ? entry(done + slot) : 0u;
             const uint32_t g0 = s.g_first[g], gn = on ? s.g_size[g] : 0u;
             auto point = [&](uint32_t k) { const uint32_t at = g0 + k; return at < kStagePoints ? s.stage[at] : sorted[at]; };
             double cx = 0, cy = 0, cz = 0;
-            for (uint32_t k = tl; k < gn; k += 16) { const float4 q = point(k); cx += double(q.x); cy += double(q.y); cz += double(q.z); }
+            for (uint32_t k = tl; k < gn; k += kWidth) { const float4 q = point(k); cx += double(q.x); cy += double(q.y); cz += double(q.z); }
             const double rcp = 1.0 / double(gn);
-            cx = team_sum_f64(cx) * rcp; cy = team_sum_f64(cy) * rcp; cz = team_sum_f64(cz) * rcp;
+            cx = team_sum<kWidth>(cx) * rcp; cy = team_sum<kWidth>(cy) * rcp; cz = team_sum<kWidth>(cz) * rcp;
             double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-            for (uint32_t k = tl; k < gn; k += 16) {
+            for (uint32_t k = tl; k < gn; k += kWidth) {
                 const float4 q = point(k);
                 const double rx = double(q.x) - cx, ry = double(q.y) - cy, rz = double(q.z) - cz;
                 xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
             }
-            xx = team_sum_f64(xx); xy = team_sum_f64(xy); xz = team_sum_f64(xz);
-            yy = team_sum_f64(yy); yz = team_sum_f64(yz); zz = team_sum_f64(zz);
+            xx = team_sum<kWidth>(xx); xy = team_sum<kWidth>(xy); xz = team_sum<kWidth>(xz);
+            yy = team_sum<kWidth>(yy); yz = team_sum<kWidth>(yz); zz = team_sum<kWidth>(zz);
             if (on && tl == 0) {
-                F3 nrm = plane_from_covariance(xx * rcp, xy * rcp, xz * rcp, yy * rcp, yz * rcp, zz * rcp);
-                const float4 q = point(0);
-                const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
-                if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
-                s.g_normal[g][0] = nrm.x; s.g_normal[g][1] = nrm.y; s.g_normal[g][2] = nrm.z; s.g_normal[g][3] = 1.0f;
+                double* c = cov[pending + slot];
+                c[0] = xx * rcp; c[1] = xy * rcp; c[2] = xz * rcp; c[3] = yy * rcp; c[4] = yz * rcp; c[5] = zz * rcp;
+                cov_group[pending + slot] = g;
             }
+            pending += round;
         }
+    };
+    if (!(ablate & 8u)) {
+        team_rounds(std::integral_constant<uint32_t, 8>{}, nnarrow, [&](uint32_t i) { return s.team_list[i]; });
+        team_rounds(std::integral_constant<uint32_t, 16>{}, nwide, [&](uint32_t i) { return s.team_list[63u - i]; });
+        if (pending) planes();
     }
-    // small neighbourhoods (8..15 points): one lane each, in the reference's summation order; and the
-    // neighbourhoods below 8 points, which only get their "no fit" mark here
-    if (tid < ngroups && s.g_size[tid] < kTeamPoints) {
-        const uint32_t g0 = s.g_first[tid], gn = s.g_size[tid];
-        float fit = 0.0f;
-        F3 nrm{0, 0, 0};
-        if (gn >= kMinPoints && !(ablate & 16u)) {
-            const bool staged = g0 + gn <= kStagePoints;
-            nrm = staged ? fit_plane(&s.stage[g0], gn) : fit_plane(sorted + g0, gn);
-            const float4 q = staged ? s.stage[g0] : sorted[g0];
-            const F3 to_sensor = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:117
-            if (dot3(nrm, to_sensor) < 0.0f) nrm = {-nrm.x, -nrm.y, -nrm.z};
-            fit = 1.0f;
-        }
-        s.g_normal[tid][0] = nrm.x; s.g_normal[tid][1] = nrm.y; s.g_normal[tid][2] = nrm.z; s.g_normal[tid][3] = fit;
-    }
+    // neighbourhoods below kMinPoints points: every point its own fallback normal (normals.hpp:127-134)
+    if (tid < ngroups && s.g_size[tid] < kMinPoints) s.g_normal[tid][3] = 0.0f;
     sync();
-    for (uint32_t k = tid; k < ((ablate & 32u) ? 0u : len); k += stride) {
-        const float4 q = k < kStagePoints ? s.stage[k] : sorted[k];
+    // every point picks up its neighbourhood's normal.  Two loops, so that the common one -- the staged points, whose LDS copy
+    // carries the voxel -- does not pay for the other's floor / convert / interleave
+    auto emit = [&](uint32_t k, float4 q, uint32_t voxel) {
         F3 nrm;
         bool fitted = false;
         if (k < grouped) {
-            const uint32_t g = s.group_of[voxel_in_block(q, recip)];
+            const uint32_t g = s.group_of[voxel];
             fitted = s.g_normal[g][3] != 0.0f;
             nrm = {s.g_normal[g][0], s.g_normal[g][1], s.g_normal[g][2]};
         }
         if (!fitted) nrm = unit3(sub3(pos, F3{q.x, q.y, q.z}));  // normals.hpp:130
         normals[first + k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
-    }
+    };
+    const uint32_t out_len = (ablate & 32u) ? 0u : len;
+    for (uint32_t k = tid; k < min(out_len, kStagePoints); k += stride) { const float4 q = s.stage[k]; emit(k, q, __float_as_uint(q.w)); }
+    for (uint32_t k = kStagePoints + tid; k < out_len; k += stride) { const float4 q = sorted[k]; emit(k, q, voxel_in_block(q, recip)); }
     sync();
 }
 
@@ -915,8 +937,10 @@ k_frame_normals(float4* __restrict__ points0, float4* __restrict__ points1, floa
     NormalScratch& s = scratch[wave];
     const uint32_t my_wave = (blockIdx.x - big_groups) * kNormalWaves + wave, all_waves = (gridDim.x - big_groups) * kNormalWaves;
     if (!sparse) {  // dense frame: one wave per (small) point block
+        uint2 next = my_wave < nseg ? segment(my_wave) : make_uint2(0u, 0u);
         for (uint32_t seg = my_wave; seg < nseg; seg += all_waves) {
-            const uint2 record = segment(seg);
+            const uint2 record = next;
+            if (seg + all_waves < nseg) next = segment(seg + all_waves);   // the next block's record: in flight while this one is worked off
             if (big_groups && (record.y & 0x7fffffffu) > big_block) continue;   // a large block: the workgroups above
             estimate_block<false>(s, record, pts, ordered, recip, pos, normals, ablate);
         }
