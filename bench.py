@@ -386,7 +386,7 @@ def main():
                        "update_kernel_ms": round(u5, 4), "update_algorithmic_bytes": b5, "update_GBps": round(b5 / u5 / 1e6, 1) if u5 > 0 else None,
                        "update_frac": round(b5 / u5 / 1e6 / HBM_PEAK_GBS, 5) if u5 > 0 else None, "voxels_per_frame": v5,
                        "live_blocks": int(s5["blocks"]), "block_capacity": int(s5["block_capacity"]), "closed_submaps": int(s5["closed_submaps"]),
-                       "hash_load": round(s5["blocks"] / s5["hash_capacity"], 5), "table_bytes": int(s5["hash_capacity"]) * (8 + 512 + 256) + int(s5["hash_capacity"]) // 8,
+                       "hash_load": round(s5["blocks"] / s5["hash_capacity"], 5), "table_bytes": int(s5["hash_capacity"]) * (8 + 512 + 256 + 512) + int(s5["hash_capacity"]) // 8,
                        "hbm_held_bytes": int(held), "overflow": int(s5["overflow"])}
         m5.close()
         del dev

@@ -156,7 +156,13 @@ struct chad_map {
     MapView view{};
     uint32_t hash_capacity = 0, brick_capacity = 0;
     FrameHeader* h_hdr = nullptr;  // pinned
-    uint32_t* d_overflow = nullptr;  // MapView::overflow
+    uint32_t* d_overflow = nullptr;  // MapView::overflow (word 0; word 8: launches that have used the scatter form's staging words)
+    static constexpr uint32_t kRecentFrames = 2 * 8;   // two per frame slot at most (fold_if_due)
+    size_t recent_points[kRecentFrames] = {};
+    uint32_t recent_at = 0;
+    uint64_t pack_points = 0;        // points inserted since the last fold of the staging words was considered
+    uint32_t pack_seen_folded = 0;   // what the device's "staging words in use" counter showed then
+    uint64_t folds = 0;
     volatile uint32_t* h_live_blocks = nullptr;  // host-mapped word the device mirrors the live block count into each frame
     uint32_t* d_live_blocks = nullptr;           // (its device address): lets the host grow the pools without a round trip
     bool fixed_capacity = false;
@@ -342,7 +348,7 @@ chad_status ensure_aux_sort(chad_map* m, size_t n) {
 
 void free_map_storage(MapView& v) {
     (void)hipFree(v.hash_keys); (void)hipFree(v.live_bits);
-    (void)hipFree(v.brick_sum); (void)hipFree(v.brick_cnt); (void)hipFree(v.brick_count);
+    (void)hipFree(v.brick_sum); (void)hipFree(v.brick_cnt); (void)hipFree(v.brick_pack); (void)hipFree(v.brick_count);
     v = MapView{};  // (v.overflow belongs to the chad_map)
 }
 
@@ -356,6 +362,7 @@ chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream, u
     HIP_TRY(hipMalloc(&v.live_bits, hcap / 8));
     HIP_TRY(hipMalloc(&v.brick_sum, hcap * 512));   // a brick lives at its hash slot; 64-bit sums (map_kernels.hpp)
     HIP_TRY(hipMalloc(&v.brick_cnt, hcap * 256));
+    HIP_TRY(hipMalloc(&v.brick_pack, hcap * 512));  // staging words of the scatter form (map_kernels.hpp, kPackCountShift)
     HIP_TRY(hipMalloc(&v.brick_count, kCountStripes * 64));
     v.hash_mask = uint32_t(hcap - 1);
     v.brick_capacity = uint32_t(blocks);
@@ -363,6 +370,7 @@ chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream, u
     HIP_TRY(hipMemsetAsync(v.live_bits, 0, hcap / 8, stream));
     HIP_TRY(hipMemsetAsync(v.brick_sum, 0, hcap * 512, stream));
     HIP_TRY(hipMemsetAsync(v.brick_cnt, 0, hcap * 256, stream));
+    HIP_TRY(hipMemsetAsync(v.brick_pack, 0, hcap * 512, stream));
     HIP_TRY(hipMemsetAsync(v.brick_count, 0, kCountStripes * 64, stream));
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
@@ -461,6 +469,8 @@ chad_status finish_closing(chad_map* m, bool block) {
     return release_finalized(m);
 }
 
+inline void staging_restart(chad_map* m);   // (defined with fold_if_due's bookkeeping below)
+
 // Submap roll-over (tsdf.cpp:52-57): archive the active submap's bricks and start an empty one -- by swapping tables, so
 // that the frames behind the roll-over do not wait for the archive (a synchronous roll-over drained the three frames in
 // flight, sized the archive on the host and compacted: ~1 ms per roll-over, 13 % of the cfg3 stream).
@@ -488,6 +498,7 @@ chad_status close_active(chad_map* m) {
     m->closing_view = m->view; m->closing = true;
     m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
     *m->h_live_blocks = 0;
+    staging_restart(m);
     return exclusive_end(m, m->stream);    // ... and later updates (into the new table) wait for this point: the spare is ready
 }
 
@@ -519,6 +530,7 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
     m->closing_view = m->view; m->closing = true; m->closing_comm = c; m->merge_stage = 0;
     m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
     *m->h_live_blocks = 0;
+    staging_restart(m);
     return exclusive_end(m, m->stream);    // ... and later updates (into the new table) wait for this point only
 }
 
@@ -787,6 +799,9 @@ inline bool rolls_over(const chad_map* m, const float position[3]) {
 }
 
 chad_status merge_and_close(chad_map* m, chad_comm* c);   // (further down)
+// the active table has just been swapped for an empty one: nothing is staged in it yet (fold_if_due)
+inline void staging_restart(chad_map* m) { m->pack_points = 0; for (auto& p : m->recent_points) p = 0; }
+
 // the active submap has just been closed: its poses go with it
 inline void retire_positions(chad_map* m) { m->closed_positions.push_back(std::move(m->positions)); m->positions.clear(); }
 inline bool is_sharded(const chad_map* m) { return m->comm && m->comm->exchanges(); }
@@ -813,6 +828,27 @@ chad_status insert_nothing(chad_map* m, const float position[3]) {
     m->frames_empty_tail++;
     m->last_points_in = 0;
     return CHAD_OK;
+}
+
+// The scatter form of the update stages its observations in one packed word per voxel whose count field holds 2^23 of them
+// (map_kernels.hpp, kPackCountShift); k_fold_packed moves the staged part into the exact sums.  It is due when kPackFoldPoints points
+// have been inserted since the last one -- a voxel receives at most one observation per point -- and only if some launch has used
+// the staging words since (the device says so through a host-mapped word: a map fed dense frames never folds).  The frames that
+// may not have run yet when the fold does are carried over: up to two per frame slot (a slot is reused once its previous frame's
+// first sort pass has run, which says nothing about that frame's update).  The kernel runs on the inserting frame's stream, in
+// front of its update, beside whatever the other streams are doing.
+void fold_if_due(chad_map* m, hipStream_t stream, size_t n) {
+    m->recent_points[m->recent_at++ % chad_map::kRecentFrames] = n;
+    m->pack_points += n;
+    if (m->pack_points < kPackFoldPoints) return;
+    const uint32_t seen = m->h_live_blocks[3];
+    if (seen != m->pack_seen_folded) {
+        hipLaunchKernelGGL(k_fold_packed, dim3(512), dim3(256), 0, stream, m->view);
+        m->pack_seen_folded = seen;
+        m->folds++;
+    }
+    m->pack_points = 0;
+    for (uint32_t k = 0; k < std::min<uint32_t>(2u * m->n_slots, chad_map::kRecentFrames); k++) m->pack_points += m->recent_points[(m->recent_at - 1u - k) % chad_map::kRecentFrames];
 }
 
 // tsdf.cpp:39-75 with the points already on the device (n > 0)
@@ -890,6 +926,8 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         const bool adaptive = m->update_mode == CHAD_UPDATE_AUTO;
+        uint32_t* pack_counter = m->d_overflow + 8, *pack_seen = m->d_live_blocks + 3;   // (the scatter form's "staging words in use" signal)
+        if (m->update_mode != CHAD_UPDATE_TILED) fold_if_due(m, prep, n);
         // CHAD_FLAG_TIME_UPDATE times the update kernel alone, with the dispatch's own begin / end time stamps (hipExtLaunchKernel)
         const bool time_kernel = (!times_stages(m) && (m->flags & CHAD_FLAG_TIME_UPDATE)) || times_kernels(m);
         hipEvent_t* ev = m->ev[m->timed_end % chad_map::kTimingRing];
@@ -898,11 +936,11 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         if (m->update_mode == CHAD_UPDATE_SCATTER) {
             const dim3 grid = grid_for(count);
             if (time_kernel)
-                hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, prep, upd_pair[0], upd_pair[1], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
+                hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, prep, upd_pair[0], upd_pair[1], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
             else
-                hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
+                hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
         } else  // the tiled kernel; in automatic mode it takes the scatter form itself when the frame is sparse (decided on the device)
-            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, list_stride, m->d_stamps,
+            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, list_stride, pack_counter, pack_seen, m->d_stamps,
                                 time_kernel ? upd_pair[0] : nullptr, time_kernel ? upd_pair[1] : nullptr);
         if (times_stages(m)) record(m, T_UPD, prep);
     } else {
@@ -1011,6 +1049,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->h_live_blocks[0] = 0;
     m->h_live_blocks[1] = kMaxPasses;  // sort pass hint: all passes as single launches until the first frame has reported
     m->h_live_blocks[2] = 0;           // key width hint: none yet (8-bit digits)
+    m->h_live_blocks[3] = 0;           // launches that have used the scatter form's staging words (fold_if_due)
     if (const char* e = std::getenv("CHAD_DEBUG_SORT_PASSES")) m->sort_passes_forced = uint32_t(std::atoi(e));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
     CREATE_TRY(hipHostMalloc(&m->h_consumed, chad_map::kMaxSlots * 64, hipHostMallocMapped));
@@ -1226,6 +1265,7 @@ chad_status chad_map_reset(chad_map* m) {
             HIP_TRY(hipGetLastError());
             std::swap(m->view, m->spare);
             *m->h_live_blocks = 0;
+            staging_restart(m);
             return CHAD_OK;
         }
     }

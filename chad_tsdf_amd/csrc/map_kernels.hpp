@@ -12,11 +12,14 @@
 //   brick_sum[H*64]  i64  sum of the clamped signed distances observed by each voxel of the brick in slot s, in units of
 //                         trunc / 2^30 (exact, order-independent; see kSumOne below)
 //   brick_cnt[H*64]  u32  number of observations (the reference's Leaf::_weight)
+//   brick_pack[H*64] u64  staging word of the scatter form: count << 40 + sum in units of trunc / 2^16, added with ONE atomic per
+//                         observation; every reader adds it to (brick_sum, brick_cnt) on the fly (voxel_totals), k_fold_packed moves
+//                         it over before the count field could run out (see kPack... below)
 //   live_bits[H/32]  u32  bit s set: slot s holds a brick (set fire-and-forget by the claiming lane); clearing,
 //                         export and growth walk this bitmap -- O(H/32 + bricks), not O(table)
 //   brick_count[kCountStripes*16] u32  number of bricks, striped over kCountStripes = 256 cache lines (no same-address atomics)
 // H = 2 * capacity rounded up to a power of two, i.e. the table -- and with it the brick storage, 768 B per slot --
-// is at most half full at the nominal capacity; 288 GB of HBM make that trade (2 x 776 B per block) a cheap one.
+// is at most half full at the nominal capacity; 288 GB of HBM make that trade (2 x 1288 B per block) a cheap one.
 // Slots that hold no brick keep all-zero rows (zeroed at allocation and again whenever a brick is released).
 // The reference keeps a running mean sd and a count w per leaf, with unit weight per observation
 // (octree.hpp:161-163); (sum, cnt) is the same information with sd = sum / cnt, and it is what makes the update a
@@ -44,10 +47,27 @@ constexpr float kSumOne = 1073741824.0f;        // 2^30 units per truncation dis
 constexpr uint32_t kPoisonedCount = 0x80000000u;
 __device__ __forceinline__ long long sum_units(float d, float units_per_metre) { return (long long)rintf(d * units_per_metre); }
 
+// The scatter form of the update (sparse frames: about one observation per voxel and frame) is bound by the number of memory-side
+// atomic requests -- on this chip every device-scope atomic travels to the memory side, 64 bytes per request whatever it carries:
+// 222 us per cfg5 frame with two atomics per observation (sum, count), 147 us with one, 62 us with none (scripts/cfg5_costs.py).
+// So an observation of the scatter form is ONE 64-bit add into a staging word per voxel: (1 << 40) + round(d * 2^16 / trunc) --
+// count in the top 24 bits, the signed sum below it (a negative sum borrows from the count; decoding undoes that).  2^16 units per
+// truncation distance: 7.6e-6 of it per observation at worst, against the 1e-4 bar, and still an exact, order-independent integer.
+// The sum field holds 2^23 observations of +-trunc: the host folds the staging words into (brick_sum, brick_cnt) before a voxel
+// could have received that many (chad_hip.hip, fold_if_due), and only frames of at most kPackMaxPoints points use them: between two
+// folds a voxel gets at most kPackFoldPoints observations + those of the frame that made the fold due and of the (at most eight)
+// frames that overtake the fold on other streams: 2^22 + 9 * 2^18 < 2^23.
+constexpr uint32_t kPackCountShift = 40;
+constexpr float kPackOne = 65536.0f;                         // 2^16 units per truncation distance
+constexpr long long kPackToSum = 1ll << (30 - 16);           // one staging unit in units of the exact sum (kSumOne = 2^30)
+constexpr uint32_t kPackMaxPoints = 1u << 18;                // larger frames take two exact atomics per observation in the scatter form
+constexpr uint64_t kPackFoldPoints = 1ull << 22;             // points inserted since the last fold that make the next one due
+
 struct MapView {
     uint64_t* hash_keys;
     long long* brick_sum;
     uint32_t* brick_cnt;
+    unsigned long long* brick_pack;
     uint32_t* live_bits;
     uint32_t* brick_count;   // striped device counter of live bricks
     uint32_t* overflow;      // sticky: set when a block found no slot (its updates are dropped)
@@ -60,6 +80,31 @@ __device__ __forceinline__ void add_observation(const MapView& m, size_t at, flo
     if (d == d) atomicAdd(reinterpret_cast<unsigned long long*>(&m.brick_sum[at]), (unsigned long long)sum_units(d, units_per_metre));
     else atomicOr(&m.brick_cnt[at], kPoisonedCount);   // NaN (Q4): the voxel's mean is NaN from here on, as in the reference
     atomicAdd(&m.brick_cnt[at], 1u);
+}
+
+// The scatter form's observation: one atomic (see kPackCountShift).  A NaN distance (Q4) counts and poisons as above.
+__device__ __forceinline__ void add_observation_packed(const MapView& m, size_t at, float d, float pack_units_per_metre) {
+    unsigned long long word = 1ull << kPackCountShift;
+    if (d == d) word += (unsigned long long)(long long)rintf(d * pack_units_per_metre);
+    else atomicOr(&m.brick_cnt[at], kPoisonedCount);
+    atomicAdd(&m.brick_pack[at], word);
+}
+__device__ __forceinline__ void unpack_staged(unsigned long long word, long long* sum_units_out, uint32_t* count_out) {
+    const long long staged = (long long)(word << (64 - kPackCountShift)) >> (64 - kPackCountShift);   // the low 40 bits, sign-extended
+    *count_out = uint32_t((word - (unsigned long long)staged) >> kPackCountShift);
+    *sum_units_out = staged * kPackToSum;
+}
+// What voxel `at` holds: the exact sums plus whatever is still staged.  count keeps the poison flag in its top bit.
+__device__ __forceinline__ void voxel_totals(const MapView& m, size_t at, long long* sum, uint32_t* count) {
+    long long s = m.brick_sum[at];
+    uint32_t c = m.brick_cnt[at];
+    const unsigned long long word = m.brick_pack[at];
+    if (word) {
+        long long staged_sum; uint32_t staged_count;
+        unpack_staged(word, &staged_sum, &staged_count);
+        s += staged_sum; c += staged_count;   // (the count never reaches the flag bit: 2^31 observations)
+    }
+    *sum = s; *count = c;
 }
 
 __device__ __forceinline__ uint32_t hash_block(uint64_t key, uint32_t mask) {
@@ -96,9 +141,15 @@ __device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint6
 // ---- update, general form: one lane per point, global atomics per observation (octree.hpp:86-164) -----------
 // The body is shared: k_update_scatter runs it alone; k_update_tiled (tile_update.hpp) runs it instead of its own loop when
 // the frame turns out to be sparse, so that the automatic mode needs one launch, not two.
+// `pack_signal`: two words -- a device counter of the launches that have used the staging words, and its mirror in host-mapped
+// memory, by which the host learns that there is something to fold (chad_hip.hip, fold_if_due).
 __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
-                                               F3 pos, float res, float recip, float trunc, const MapView& m) {
+                                               F3 pos, float res, float recip, float trunc, const MapView& m, uint32_t* pack_counter, uint32_t* pack_seen_host) {
     const uint32_t n = h->n_usable;
+    const bool packed = n <= kPackMaxPoints;
+    if (packed && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(pack_seen_host, atomicAdd(pack_counter, 1u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const float pack_units = kPackOne / trunc, sum_units_per_metre = kSumOne / trunc;
     unsigned long long applied = 0;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const float4 q = pts[i], nq = normals[i];
@@ -110,10 +161,18 @@ __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, c
         do {
             const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
             const uint64_t key = mc & kBlockMask;
-            if (key != cached_key) { brick = find_or_create_brick(m, key); cached_key = key; }
+            if (key != cached_key) {
+                // most blocks of a frame are there already (the sensor moves a fraction of its range per frame): a plain load finds
+                // them, and only a miss pays for the compare-and-swap (a memory-side atomic like the adds below)
+                const uint32_t home = hash_block(key, m.hash_mask);
+                brick = __hip_atomic_load(&m.hash_keys[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key ? home : find_or_create_brick(m, key, home);
+                cached_key = key;
+            }
             if (brick != kNoBrick) {
                 const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
-                add_observation(m, at, observe(w.cur, p, nrm, res, trunc), kSumOne / trunc);
+                const float d = observe(w.cur, p, nrm, res, trunc);
+                if (packed) add_observation_packed(m, at, d, pack_units);
+                else add_observation(m, at, d, sum_units_per_metre);
                 applied++;
             }
         } while (w.next());
@@ -125,9 +184,9 @@ __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, c
 
 __global__ void __launch_bounds__(256)
 k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
-                 F3 pos, float res, float recip, float trunc, MapView m) {
+                 F3 pos, float res, float recip, float trunc, MapView m, uint32_t* pack_counter, uint32_t* pack_seen_host) {
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order: k_frame_normals' output (the sort's other buffer)
-    scatter_update(pts, normals, h, pos, res, recip, trunc, m);
+    scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host);
 }
 
 // ---- stage entries for parity tests ----------------------------------------------------------------------------
@@ -273,8 +332,9 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
             for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u, k++) {
                 if (k >= capacity) continue;
                 const uint32_t slot = (w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u;
-                const uint32_t count = m.brick_cnt[size_t(slot) * 64 + lane];
-                const float sum = float(double(m.brick_sum[size_t(slot) * 64 + lane]) * metres_per_unit);   // exact integer -> one rounding
+                long long units; uint32_t count;
+                voxel_totals(m, size_t(slot) * 64 + lane, &units, &count);
+                const float sum = float(double(units) * metres_per_unit);   // exact integer -> one rounding
                 out_sum[size_t(k) * 64 + lane] = (count & kPoisonedCount) ? __int_as_float(0x7fc00000) : sum;
                 out_cnt[size_t(k) * 64 + lane] = count & ~kPoisonedCount;
                 if (lane == 0) out_key[k] = m.hash_keys[slot];
@@ -284,7 +344,7 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
 }
 
 // Octree::clear() (octree.hpp:22-29) in O(H/32 + bricks) and without a host round trip: every live brick's key is
-// released and its two 256-byte rows are zeroed; then the bitmap words and the counter stripes.
+// released and its rows are zeroed; then the bitmap words and the counter stripes.
 __global__ void __launch_bounds__(256)
 k_clear_bricks(MapView m, uint32_t clear_overflow) {
     const uint32_t lane = threadIdx.x & 63;
@@ -292,6 +352,7 @@ k_clear_bricks(MapView m, uint32_t clear_overflow) {
         if (lane == 0) m.hash_keys[slot] = kEmptyKey;
         m.brick_sum[size_t(slot) * 64 + lane] = 0ll;
         m.brick_cnt[size_t(slot) * 64 + lane] = 0u;
+        m.brick_pack[size_t(slot) * 64 + lane] = 0ull;
     });
     // each wave clears exactly the words it has just read
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -314,6 +375,25 @@ k_rehash_bricks(MapView from, MapView to) {
         if (dst == kNoBrick) return;
         to.brick_sum[size_t(dst) * 64 + lane] = from.brick_sum[size_t(slot) * 64 + lane];
         to.brick_cnt[size_t(dst) * 64 + lane] = from.brick_cnt[size_t(slot) * 64 + lane];
+        to.brick_pack[size_t(dst) * 64 + lane] = from.brick_pack[size_t(slot) * 64 + lane];
+    });
+}
+
+// Move what the scatter form has staged into the exact sums (before the staging word's count field could run out).  Safe beside
+// updates in flight: the word is taken with an exchange and added with atomics, so nothing is lost or counted twice, and every
+// reader adds the two parts anyway.
+__global__ void __launch_bounds__(256)
+k_fold_packed(MapView m) {
+    const uint32_t lane = threadIdx.x & 63;
+    for_each_live_brick(m, [&](uint32_t slot) {
+        const size_t at = size_t(slot) * 64 + lane;
+        if (m.brick_pack[at] == 0ull) return;
+        const unsigned long long word = atomicExch(&m.brick_pack[at], 0ull);
+        if (!word) return;
+        long long units; uint32_t count;
+        unpack_staged(word, &units, &count);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&m.brick_sum[at]), (unsigned long long)units);
+        atomicAdd(&m.brick_cnt[at], count);
     });
 }
 

@@ -41,8 +41,9 @@ k_compact_bricks_raw(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity
             for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u, k++) {
                 if (k >= capacity) continue;
                 const uint32_t slot = (w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u;
-                const uint32_t count = m.brick_cnt[size_t(slot) * 64 + lane];
-                out_sum[size_t(k) * 64 + lane] = m.brick_sum[size_t(slot) * 64 + lane];
+                long long units; uint32_t count;
+                voxel_totals(m, size_t(slot) * 64 + lane, &units, &count);
+                out_sum[size_t(k) * 64 + lane] = units;
                 out_cnt[size_t(k) * 64 + lane] = (count & kWireCountMask) | ((count & kPoisonedCount) ? (1u << 28) : 0u);
                 if (lane == 0) out_key[k] = m.hash_keys[slot];
             }

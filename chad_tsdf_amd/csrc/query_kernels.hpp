@@ -31,9 +31,10 @@ __device__ __forceinline__ bool read_leaf(const MapView& m, I3 v, double metres_
     const uint32_t slot = find_brick(m, mc & kBlockMask);
     if (slot == kNoBrick) return false;
     const size_t at = size_t(slot) * 64 + (uint32_t(mc) & 63u);
-    const uint32_t count = m.brick_cnt[at];
+    long long units; uint32_t count;
+    voxel_totals(m, at, &units, &count);
     if (!(count & ~kPoisonedCount)) return false;
-    const float sum = float(double(m.brick_sum[at]) * metres_per_unit);
+    const float sum = float(double(units) * metres_per_unit);
     *sd = (count & kPoisonedCount) ? __int_as_float(0x7fc00000) : sum / float(count & ~kPoisonedCount);
     *w = count & ~kPoisonedCount;
     return true;
@@ -87,7 +88,7 @@ k_carve(const float4* __restrict__ points0, const float4* __restrict__ points1, 
             if (key != cached_key) { brick = find_brick(m, key); cached_key = key; }
             if (brick == kNoBrick) continue;
             const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
-            if (!(m.brick_cnt[at] & ~kPoisonedCount)) continue;   // counts only grow during this kernel: "holds a leaf" cannot change
+            if (!(m.brick_cnt[at] & ~kPoisonedCount) && !m.brick_pack[at]) continue;   // counts only grow during this kernel: "holds a leaf" cannot change
             atomicAdd(reinterpret_cast<unsigned long long*>(&m.brick_sum[at]), (unsigned long long)(long long)kSumOne);   // +trunc in the map's units
             atomicAdd(&m.brick_cnt[at], 1u);
             carved++;

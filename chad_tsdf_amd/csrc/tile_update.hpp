@@ -92,7 +92,7 @@ template <bool kStamps, int kMinWaves>
 __global__ void __launch_bounds__(kTileThreads, kMinWaves)
 k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, const uint4* __restrict__ items,
                FrameHeader* __restrict__ h, F3 pos, float res, float recip, float trunc, MapView m, uint32_t reach, uint32_t adaptive, uint32_t items_capacity /* entries per stripe of items[] */,
-               unsigned long long* stamps) {
+               unsigned long long* stamps, uint32_t* pack_counter, uint32_t* pack_seen_host) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
     unsigned long long wall_entry = 0, wall_loop = 0, wall_zeroed = 0, wall_lists = 0;   // kStamps: constant-clock (10 ns) times of the wave's entry and of its first item
     if (kStamps) wall_entry = wall_clock64();
@@ -120,7 +120,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     if (kStamps) wall_zeroed = wall_clock64();
     if (threadIdx.x < 2 * (kListStripes + 1)) first_long[threadIdx.x] = summary_word;
     if (sparse) {  // about one point per block: staging tiles is pure overhead, take the general form
-        scatter_update(pts, normals, h, pos, res, recip, trunc, m);
+        scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host);
         return;
     }
     tile_barrier();
@@ -369,8 +369,8 @@ inline uint32_t tile_reach(float res, float trunc) {
 }
 
 inline void tile_update_enqueue(const float4* points0, const float4* points1, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
-                                const MapView& m, hipStream_t stream, bool adaptive, uint32_t items_capacity, unsigned long long* stamps = nullptr,
-                                hipEvent_t started = nullptr, hipEvent_t stopped = nullptr) {
+                                const MapView& m, hipStream_t stream, bool adaptive, uint32_t items_capacity, uint32_t* pack_counter, uint32_t* pack_seen_host,
+                                unsigned long long* stamps = nullptr, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr) {
     const uint32_t reach = tile_reach(res, trunc);
     const uint32_t d = 8 + 2 * reach;
     const size_t lds = ((size_t(d) * d * d + 3) & ~size_t(1)) * 8 + 16 + 2 * (kListStripes + 1) * 4 + 8;   // tile + two spare zero cells (padded to 16 bytes) + next item's record + list index
@@ -388,12 +388,12 @@ inline void tile_update_enqueue(const float4* points0, const float4* points1, co
     static_assert(256 * 8 <= kFirstItems, "every workgroup finds its first item in FrameHeader::first_item");
     // 5 waves per SIMD (<= 96 VGPRs): a 6-wave build (80 VGPRs) spills and measured slower
     if (stamps)
-        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
+        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
     else if (started && stopped)  // the events take the dispatch's own begin and end time stamps: the kernel's execution, without marker packets around it
         hipExtLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), uint32_t(lds), stream, started, stopped, 0u, points0, points1, normals, items, h, pos,
-                              res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
+                              res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
     else
-        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps);
+        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
 }
 
 }  // namespace chadhip

@@ -87,7 +87,10 @@ def test_dag_against_the_oracles_own_inserts(chad, oracle):
         got = m.export_clusters(k, weights=False)[1]
         step = (got.view(np.uint8).astype(np.int16) - want.view(np.uint8).astype(np.int16))
         assert np.abs(step).max() <= 1                                   # a byte off by one step at most ...
-        assert (step != 0).mean() < 1e-3                                 # ... and rarely
+        # ... and rarely.  (3e-3: these 30 k-point frames take the scatter form of the update, whose staging words carry the signed
+        # distance in units of trunc / 2^16 -- a byte's step is trunc / 127, so about one mean in a thousand lands on the other
+        # side of a step for that alone; with exact sums throughout it was below 1e-3)
+        assert (step != 0).mean() < 3e-3
         trees_equal += int(np.array_equal(got, want))
         assert np.abs(sd - osd).max() <= 0.10 / 127 + 1e-5              # cluster.hpp:13-26 truncates: one step
     if trees_equal == 2:                                                # no byte on a step boundary: then everything matches
