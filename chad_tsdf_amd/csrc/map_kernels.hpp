@@ -141,41 +141,75 @@ __device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint6
 // ---- update, general form: one lane per point, global atomics per observation (octree.hpp:86-164) -----------
 // The body is shared: k_update_scatter runs it alone; k_update_tiled (tile_update.hpp) runs it instead of its own loop when
 // the frame turns out to be sparse, so that the automatic mode needs one launch, not two.
-// `pack_signal`: two words -- a device counter of the launches that have used the staging words, and its mirror in host-mapped
-// memory, by which the host learns that there is something to fold (chad_hip.hip, fold_if_due).
+// `pack_counter` / `pack_seen_host`: a device counter of the launches that have used the staging words, and its mirror in
+// host-mapped memory, by which the host learns that there is something to fold (chad_hip.hip, fold_if_due).
+//
+// What bounds this form is the number of memory-side atomic REQUESTS, and a request is a 64-byte segment touched by one
+// instruction of one wave -- the eight staging words of a 2x2x2 octant of a brick.  With a lane per ray, the lanes of an
+// instruction are sixty-four different rays at the same step: sixty-four requests.  So the walk only NOTES its observations, in
+// LDS (`stage`: this wave's rows of kStageRow entries, one row per step), and a second phase issues them transposed: sixteen
+// lanes are the steps of ONE ray, four neighbouring rays per instruction -- the two or three voxels a ray visits in an octant,
+// and what the neighbouring rays of a sorted frame add to the same octants, travel as one request.  Steps beyond the staged rows
+// (stage_rows, whatever LDS the caller has) and frames too large for the staging words go straight to memory as before.
+constexpr uint32_t kStageRow = 65;   // entries of a row: one per lane, and one of padding (the transposed reads stride over rows)
 __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
-                                               F3 pos, float res, float recip, float trunc, const MapView& m, uint32_t* pack_counter, uint32_t* pack_seen_host) {
+                                               F3 pos, float res, float recip, float trunc, const MapView& m, uint32_t* pack_counter, uint32_t* pack_seen_host,
+                                               unsigned long long* stage, uint32_t stage_rows) {
     const uint32_t n = h->n_usable;
     const bool packed = n <= kPackMaxPoints;
     if (packed && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(pack_seen_host, atomicAdd(pack_counter, 1u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float pack_units = kPackOne / trunc, sum_units_per_metre = kSumOne / trunc;
+    const uint32_t lane = threadIdx.x & 63u, rows = packed ? min(stage_rows, 16u) : 0u;
+    constexpr unsigned long long kNothing = ~0ull;
     unsigned long long applied = 0;
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
-        const float4 q = pts[i], nq = normals[i];
-        const F3 p{q.x, q.y, q.z}, nrm{nq.x, nq.y, nq.z};
-        RayWalk w;
-        w.begin(p, pos, res, recip, trunc);
-        uint64_t cached_key = kEmptyKey;
-        uint32_t brick = kNoBrick;
-        do {
-            const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
-            const uint64_t key = mc & kBlockMask;
-            if (key != cached_key) {
-                // most blocks of a frame are there already (the sensor moves a fraction of its range per frame): a plain load finds
-                // them, and only a miss pays for the compare-and-swap (a memory-side atomic like the adds below)
-                const uint32_t home = hash_block(key, m.hash_mask);
-                brick = __hip_atomic_load(&m.hash_keys[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key ? home : find_or_create_brick(m, key, home);
-                cached_key = key;
-            }
-            if (brick != kNoBrick) {
-                const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
-                const float d = observe(w.cur, p, nrm, res, trunc);
-                if (packed) add_observation_packed(m, at, d, pack_units);
-                else add_observation(m, at, d, sum_units_per_metre);
-                applied++;
-            }
-        } while (w.next());
+    for (size_t base = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) & ~size_t(63); base < n; base += size_t(gridDim.x) * blockDim.x) {
+        const size_t i = base + lane;
+        uint32_t k = 0;   // steps of this lane's ray so far
+        if (i < n) {
+            const float4 q = pts[i], nq = normals[i];
+            const F3 p{q.x, q.y, q.z}, nrm{nq.x, nq.y, nq.z};
+            RayWalk w;
+            w.begin(p, pos, res, recip, trunc);
+            uint64_t cached_key = kEmptyKey;
+            uint32_t brick = kNoBrick;
+            do {
+                const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
+                const uint64_t key = mc & kBlockMask;
+                if (key != cached_key) {
+                    // most blocks of a frame are there already (the sensor moves a fraction of its range per frame): a plain load finds
+                    // them, and only a miss pays for the compare-and-swap (a memory-side atomic like the adds below)
+                    const uint32_t home = hash_block(key, m.hash_mask);
+                    brick = __hip_atomic_load(&m.hash_keys[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key ? home : find_or_create_brick(m, key, home);
+                    cached_key = key;
+                }
+                unsigned long long note = kNothing;
+                if (brick != kNoBrick) {
+                    const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
+                    const float d = observe(w.cur, p, nrm, res, trunc);
+                    if (k < rows) {   // noted: [cell : 40 | distance in staging units : 24, two's complement]
+                        if (!(d == d)) atomicOr(&m.brick_cnt[at], kPoisonedCount);   // NaN (Q4): counted, adds nothing, poisons
+                        note = (uint64_t(at) << 24) | (uint32_t(d == d ? int(rintf(d * pack_units)) : 0) & 0xffffffu);
+                    } else if (packed) add_observation_packed(m, at, d, pack_units);
+                    else add_observation(m, at, d, sum_units_per_metre);
+                    applied++;
+                }
+                if (k < rows) stage[k * kStageRow + lane] = note;
+                k++;
+            } while (w.next());
+        }
+        if (rows) {
+            for (; k < rows; k++) stage[k * kStageRow + lane] = kNothing;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a wave's LDS operations complete in order: its own notes are there)
+            const uint32_t step = lane & 15u, ray = lane >> 4;
+            if (step < rows)
+                for (uint32_t j = 0; j < 16u; j++) {
+                    const unsigned long long note = stage[step * kStageRow + 4u * j + ray];
+                    if (note != kNothing)
+                        atomicAdd(&m.brick_pack[note >> 24], (1ull << kPackCountShift) + (unsigned long long)(long long)(int(uint32_t(note) << 8) >> 8));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next batch's notes overwrite them
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) applied += __shfl_xor(applied, o);
@@ -186,7 +220,8 @@ __global__ void __launch_bounds__(256)
 k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
                  F3 pos, float res, float recip, float trunc, MapView m, uint32_t* pack_counter, uint32_t* pack_seen_host) {
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order: k_frame_normals' output (the sort's other buffer)
-    scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host);
+    __shared__ unsigned long long stage[4][16 * kStageRow];
+    scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host, stage[threadIdx.x >> 6], 16u);
 }
 
 // ---- stage entries for parity tests ----------------------------------------------------------------------------

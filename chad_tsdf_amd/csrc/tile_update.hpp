@@ -119,11 +119,14 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     for (uint32_t k = threadIdx.x; k <= cells + 1u; k += kTileThreads) tile[k] = 0ull;
     if (kStamps) wall_zeroed = wall_clock64();
     if (threadIdx.x < 2 * (kListStripes + 1)) first_long[threadIdx.x] = summary_word;
+    tile_barrier();   // the tile is zeroed, the lists are in LDS
     if (sparse) {  // about one point per block: staging tiles is pure overhead, take the general form
-        scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host);
+        // (its notes go where the tile would be: as many rows of kStageRow entries per wave as that leaves room for -- ten for a
+        // reach of 3 voxels, fifteen for 4: a ray's steps grow with the reach as the tile does)
+        const uint32_t stage_rows = ((cells + 2u) / kTileWaves) / kStageRow;
+        scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host, tile + wave * (stage_rows * kStageRow), stage_rows);
         return;
     }
-    tile_barrier();
     if (kStamps) wall_lists = wall_clock64();
     const uint32_t n_long = first_long[kListStripes], nitems = n_long + first_short[kListStripes];
     auto item_record = [&](uint32_t v) {
