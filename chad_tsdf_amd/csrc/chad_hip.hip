@@ -163,6 +163,8 @@ struct chad_map {
     uint64_t pack_points = 0;        // points inserted since the last fold of the staging words was considered
     uint32_t pack_seen_folded = 0;   // what the device's "staging words in use" counter showed then
     uint64_t folds = 0;
+    uint64_t fold_due = kPackFoldPoints;   // (CHAD_DEBUG_FOLD_POINTS: tests fold often)
+    bool report_folds = false;
     volatile uint32_t* h_live_blocks = nullptr;  // host-mapped word the device mirrors the live block count into each frame
     uint32_t* d_live_blocks = nullptr;           // (its device address): lets the host grow the pools without a round trip
     bool fixed_capacity = false;
@@ -840,7 +842,7 @@ chad_status insert_nothing(chad_map* m, const float position[3]) {
 void fold_if_due(chad_map* m, hipStream_t stream, size_t n) {
     m->recent_points[m->recent_at++ % chad_map::kRecentFrames] = n;
     m->pack_points += n;
-    if (m->pack_points < kPackFoldPoints) return;
+    if (m->pack_points < m->fold_due) return;
     const uint32_t seen = m->h_live_blocks[3];
     if (seen != m->pack_seen_folded) {
         hipLaunchKernelGGL(k_fold_packed, dim3(512), dim3(256), 0, stream, m->view);
@@ -1004,6 +1006,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
     m->fixed_capacity = (o.flags & CHAD_FLAG_FIXED_CAPACITY) != 0;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
+    if (const char* a = std::getenv("CHAD_DEBUG_FOLD_POINTS")) { m->fold_due = uint64_t(std::atoll(a)); m->report_folds = true; }
     if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)hipMalloc(&m->d_stamps, 8192 * 16 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 16 * 8); }
     auto bail = [&](chad_status s) { chad_map_destroy(m); return s; };
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
@@ -1085,6 +1088,7 @@ void chad_map_destroy(chad_map* m) {
     DeviceGuard guard(m->device);
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->report_folds) std::fprintf(stderr, "chad: staging folds %llu\n", (unsigned long long)m->folds);
     if (m->d_stamps) {  // diagnostic: mean cycles per phase over the waves of the last update launch
         std::vector<unsigned long long> st(8192 * 16);
         (void)hipMemcpy(st.data(), m->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);

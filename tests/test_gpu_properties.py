@@ -329,3 +329,33 @@ def test_maps_are_bit_reproducible(chad, mode):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
     assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))        # the means: identical bits
     assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+
+
+def test_scatter_staging_is_folded_and_read_through(chad, oracle, monkeypatch, capfd):
+    """The scatter form stages its observations in packed words (map_kernels.hpp, kPackCountShift): whatever the state of the
+    staging -- nothing folded yet, folded in part beside frames in flight, carried across a table growth -- the map read back is
+    the oracle's: leaf sets and weights exact, sd within the bar; the device's leaf look-up reads through the staging as well."""
+    monkeypatch.setenv("CHAD_DEBUG_FOLD_POINTS", "90000")    # a fold is due every third of these frames
+    res, trunc = 0.05, 0.10
+    m = chad.TSDFMap(res, trunc, update_mode=1, max_blocks=12_000)   # scatter form throughout; the table grows on the way (7 k blocks after the first frame)
+    o = oracle.OracleMap(res, trunc)
+    for k in range(9):
+        pts, pos = synth.cfg2_frame(40_000, seed=50 + k, sensor=(0.3 + 0.01 * k, -0.2, 0.1))
+        m.insert(pts, pos)
+        o.insert(pts, pos)
+        if k in (0, 4):                                       # read through the staging words, in the middle of the stream
+            assert_leaves_match(m.export_leaves(), o.export_leaves(), trunc)
+    m.sync()
+    mc, sd, w = m.export_leaves()
+    assert_leaves_match((mc, sd, w), o.export_leaves(), trunc)
+    st = m.stats()
+    assert st["blocks"] == int(o.stats()["blocks"]) and st["overflow"] == 0 and st["block_capacity"] > 12_000
+    # leaf queries at the corners' own voxels: bit for bit what the export reports
+    pick = np.random.default_rng(3).integers(0, len(mc), 5000)
+    centres = ((oracle.morton_decode_ivec(mc[pick]).astype(np.float32) + np.float32(0.5)) * np.float32(res)).astype(np.float32)
+    qsd, qw = m.query_sd(centres, trilinear=False)
+    assert np.array_equal(qw, w[pick]) and np.array_equal(qsd.view(np.uint32), sd[pick].view(np.uint32))
+    m.close()
+    err = capfd.readouterr().err
+    folds = [int(line.split()[-1]) for line in err.splitlines() if line.startswith("chad: staging folds")]
+    assert folds and folds[-1] >= 2, err
