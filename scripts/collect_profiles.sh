@@ -18,4 +18,11 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" --
 echo "write done"
 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/tcc" -- python3 bench.py --steps 6 --warmup 2 $B > "$out/bench_tcc.log" 2>&1
 echo "tcc done"
+# cfg5 (outdoor shape, the scatter form of the update): kernel trace and the same counters for 40 frames of scripts/outdoor_bench.py
+O="scripts/outdoor_bench.py --frames 40"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cfg5_trace" -- python3 $O > "$out/cfg5_trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/cfg5_fetch" -- python3 $O > "$out/cfg5_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/cfg5_write" -- python3 $O > "$out/cfg5_write.log" 2>&1
+rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/cfg5_tcc" -- python3 $O > "$out/cfg5_tcc.log" 2>&1
+echo "cfg5 done"
 python3 scripts/summarise_profiles.py "$out" "$tag"

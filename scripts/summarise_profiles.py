@@ -54,3 +54,25 @@ json.dump({
 print(open(os.path.join(prof, "pmc_update_kernel.json")).read())
 for k, v in sorted(durations.items(), key=lambda kv: -kv[1])[:8]:
     print(f"{k:32s} {v / 1e3:8.2f} us")
+
+# cfg5 (scripts/outdoor_bench.py): the same two summaries, if collect_profiles.sh has taken them
+if glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursive=True):
+    stats5 = sorted(glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursive=True))[-1]
+    shutil.copy(stats5, os.path.join(prof, f"{tag}_cfg5_kernel_stats.csv"))
+    per5 = collections.defaultdict(dict)
+    for group in ("cfg5_fetch", "cfg5_write", "cfg5_tcc"):
+        f = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))[-1]
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("chadhip::", "").replace("void ", "")
+            acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for name, counters in acc.items():
+            for c, vals in counters.items():
+                per5[name][c] = sum(vals) / len(vals)
+                per5[name]["launches_sampled"] = len(vals)
+    json.dump(per5, open(os.path.join(prof, f"{tag}_cfg5_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
+    print("cfg5:")
+    for r in csv.DictReader(open(stats5)):
+        print(f'{r["Name"].split("(")[0][:60]:60s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"]) / 1e3:8.2f} us  {r["Percentage"]:>6s}%')
+    u5 = [k for k in per5 if k.startswith("k_update_tiled<false")]
+    if u5: print("cfg5 update kernel counters per launch:", json.dumps(per5[u5[0]]))
