@@ -17,21 +17,23 @@
 //      the voxel lists are bit-identical) with the bookkeeping folded into three registers: the LDS address and the
 //      per-axis remaining step counts share one word that a step updates with a single add, and the signed
 //      distance -- for which the bar is 1e-4, not bit equality -- is carried incrementally in fixed-point scale.
-//      ~26 VALU instructions per voxel step (the first version: ~110).
+//      ~20 VALU instructions per voxel step (the first version: ~110).
 //      Rays that leave the tile (float rounding at the rim, trunc > 3*res) or whose normal is not finite (Q4) take
 //      the global path of k_update_scatter instead, outside the hot loop;
-//   2. workgroup barrier; wave w owns the 16 bricks of slab z = w from here on.  It reads them back (lane = voxel
-//      of the brick, all 16 reads in flight together) to learn which received observations; lanes 0..15 whose brick
-//      was touched and whose speculative look-up (below) did not already show the key claim or find the slot with
-//      one CAS (map_kernels.hpp);
+//   2. workgroup barrier; wave w owns the 16 bricks of slab z = w from here on.  It reads them back -- sixteen lanes per brick,
+//      a row of four cells each, four bricks per pass, all reads in flight together -- to learn which received observations;
+//      lanes 0..15 whose brick was touched and whose speculative look-up (below) did not already show the key claim or find the
+//      slot with one CAS (map_kernels.hpp);
 //   3. every touched brick is flushed with two wave-wide atomic adds (512 B of 64-bit sums, 256 B of counts), the full-rate shape for
 //      memory-side atomics, and its part of the tile is zeroed for the next item; workgroup barrier.
 // Memory operations of a wave complete in issue order, so a load issued behind the flush's atomics waits ~3000
 // cycles for them.  The loop is therefore software-pipelined: right after the first barrier -- before the flush --
 // every wave loads the NEXT item's first chunk of points and the home hash slots of its 16 bricks (speculative,
 // nothing is created), and the next item's record itself was fetched by wave 0 during the walk.
-// Work items: the first one is static (workgroup index), the rest are pulled from 256 separate counters (a
-// returning atomic on ONE shared address serialises at ~25 ns per dequeue).  Sparse frames (few points per block): in
+// Work items: the first one is static (workgroup index; its record and the lists' stripe sums come ready-made from
+// k_frame_normals' last workgroup, FrameHeader::first_item / item_first: one round trip in front of the first ray instead of
+// three), the rest are pulled from 256 separate counters (a returning atomic on ONE shared address serialises at ~25 ns per
+// dequeue).  Sparse frames (few points per block): in
 // automatic mode the kernel notices (device memory) and runs the scatter form (map_kernels.hpp, scatter_update) on its
 // own grid instead -- with one point per block the staging is pure overhead.
 #pragma once
