@@ -211,3 +211,34 @@ def test_cfg5_stream_with_roll_overs_and_table_growth(chad, oracle):
     for s in (0, 1, 2, -1):
         assert_leaves_match(m.export_leaves(s), o.export_leaves(s), 0.06)
     m.close()
+
+
+def test_cfg5_long_trajectory_keeps_only_the_dag(chad, oracle):
+    """BASELINE config 5 is a 5 000-frame trajectory; what bounds its length is what a closed submap leaves behind.  221 frames of
+    its shape (20 roll-overs) under CHAD_FLAG_DAG_ONLY -- the reference's own policy: a closed submap is its DAG and nothing else --:
+    the device holds the active submap only, however many have been closed, and a submap read back through the DAG at the start,
+    in the middle and at the end of the trajectory is the oracle's (leaf sets exact, signed distances within one byte step)."""
+    import torch
+
+    n_frames = 221
+    m = chad.TSDFMap(0.02, 0.06, max_blocks=1 << 22, dag_only=True)
+    free = {}
+    for k in range(n_frames):
+        pts, pos = synth.cfg5_frame(k)
+        m.insert(pts, pos)
+        if k in (60, 220):
+            m.sync()
+            free[k] = torch.cuda.mem_get_info()[0]
+    m.sync()
+    st = m.stats()
+    assert m.closed_submaps == 20 and st["overflow"] == 0 and st["blocks"] / st["hash_capacity"] <= 0.5
+    assert free[60] - free[220] < (1 << 30), "device memory grows with the number of closed submaps"
+    for s in (0, 9, 19):
+        o = oracle.OracleMap(0.02, 0.06)
+        for k in range(11 * s, 11 * s + 11):      # frame 11 s arrives more than 5 m from submap s - 1's first pose and opens submap s
+            o.insert(*synth.cfg5_frame(k))
+        omc, osd, _ = o.export_leaves(-1)
+        mc, sd = m.dag_leaves(s)
+        assert np.array_equal(mc, omc), f"submap {s}"
+        assert np.abs(sd - osd).max() <= 0.06 / 127 + 1e-5
+    m.close()
