@@ -147,8 +147,10 @@ k_radix_bases(const uint32_t* __restrict__ hist_part, uint32_t hist_blocks, uint
 
 // One pass for the tile of this workgroup.  pay_in may be null: the payload is then made from the element's position
 // (and `first_src`, the raw points, for PointPayload) -- the first pass.  kBits: digit width (8, or 9 with two digits per thread).
+// Returns false -- having done nothing -- when the ticket it drew lies beyond the last tile (a workgroup of the catch-all launch
+// that goes round for more, k_radix_onesweep_rest).
 template <class P, int kBits>
-__device__ __forceinline__ void
+__device__ __forceinline__ bool
 radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
                     uint64_t* __restrict__ keys_out, typename P::T* __restrict__ pay_out,
                     uint32_t n, uint32_t pass, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
@@ -184,6 +186,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     if (threadIdx.x == 0) { tile_fault = 0u; if (use_ticket) my_tile = atomicAdd(&tile_ticket[pass], 1u); }
     __syncthreads();
     const uint32_t tile = use_ticket ? my_tile : blockIdx.x;
+    if (tile >= tiles) return false;   // (only a ticket can say so: grids that take their tile from blockIdx have exactly `tiles` workgroups)
     const uint32_t shift = pass * kBits;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -304,7 +307,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     __syncthreads();
     if (tile_fault) {   // a predecessor never published: the slots are unknown, write nothing (the sort's output is incomplete and says so)
         if (threadIdx.x == 0 && fault) atomicOr(fault, kSortFaultStalled);
-        return;
+        return true;
     }
 
 #pragma unroll
@@ -325,6 +328,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
         keys_out[slot] = k;
         if (P::kStaged) pay_out[slot] = sorted_val[s];
     }
+    return true;
 }
 
 // One launch = pass `first_pass`, and -- when `to_limit` is set -- every further pass up to *pass_limit as well, separated
@@ -366,6 +370,44 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
     }
 }
 
+// The catch-all behind the hinted launches of a sort whose grid is too large to be resident at once (a 1 M-point frame with three
+// frames in flight: 489 tiles against a share of 320 workgroups): passes first_pass .. *pass_limit - 1 -- normally none, and the
+// launch returns at once -- by as many workgroups as ARE resident at once, each drawing tiles by ticket until the pass has none
+// left, with a grid barrier between passes.  (Without it such a frame got a launch per possible pass, eight: six surplus launches
+// of 4.5 us each on the frame's stream and 15 us of host time, every frame of the headline benchmark -- seen in the kernel trace
+// of round 3.)
+template <class P, int kBits = kRadixBits>
+__global__ void __launch_bounds__(kSortThreads)
+k_radix_onesweep_rest(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
+                      uint32_t n, uint32_t first_pass, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
+                      uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src,
+                      RadixSortSignals sig) {
+    const uint32_t limit = min(uint32_t(kMaxPasses), *pass_limit);
+    if (first_pass >= limit) return;
+    uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
+    for (uint32_t pass = first_pass; pass < limit; pass++) {
+        const bool odd = pass & 1u;
+        while (radix_onesweep_tile<P, kBits>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base,
+                                             base_stripes, tile_status, tile_ticket, first_src, true, sig.fault))
+            __syncthreads();   // the tile's LDS is read to the end before the next one overwrites it
+        if (pass + 1 >= limit) break;
+        // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicAdd(arrived, 1u);
+            const uint32_t target = gridDim.x * (pass - first_pass + 1u);
+            uint32_t polls = 0;
+            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++polls > kSpinLimit) { if (sig.fault) atomicOr(sig.fault, kSortFaultStalled); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __threadfence();
+        }
+        __syncthreads();
+    }
+}
+
 // launch_passes (0 = all `passes`): launches to enqueue; the last of them covers whatever passes remain (k_radix_onesweep,
 // to_limit) when the grid is small enough to be resident at once -- otherwise every pass gets its launch.
 // P = IndexPayload: pairs (key, input position) in b.keys / b.idx.  P = PointPayload: (key, point) in b.keys / b.points,
@@ -386,7 +428,9 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     const uint32_t base_stripes = hist_blocks ? kBaseStripes : 1u;
     if (!hist_blocks) hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
     const bool hinted = pass_limit && launch_passes && launch_passes < passes && all_resident;
-    const uint32_t launches = hinted ? launch_passes : passes;
+    // a grid too large to be resident at once: the hinted launches, then one catch-all for whatever the frame needs beyond them
+    const bool with_rest = pass_limit && launch_passes && launch_passes < passes && !all_resident && b.resident != 0u;
+    const uint32_t launches = hinted || with_rest ? launch_passes : passes;
     for (uint32_t p = 0; p < launches; p++) {
         const bool to_limit = hinted && p + 1 == launches;
         // A launch that may end up behind grid barriers must not share the chip with another one like it (two grids that
@@ -403,6 +447,15 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         };
         if (digit_bits == uint32_t(kWideBits)) launch(k_radix_onesweep<P, kWideBits>); else launch(k_radix_onesweep<P, kRadixBits>);
         if (to_limit && one_at_a_time) (void)hipEventRecord(one_at_a_time, stream);
+    }
+    if (with_rest) {
+        const uint32_t grid = tiles < b.resident ? tiles : b.resident;
+        if (digit_bits == uint32_t(kWideBits))
+            hipLaunchKernelGGL((k_radix_onesweep_rest<P, kWideBits>), dim3(grid), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
+                               base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
+        else
+            hipLaunchKernelGGL((k_radix_onesweep_rest<P, kRadixBits>), dim3(grid), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
+                               base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
     }
     if (sig.launches_out) *sig.launches_out = launches;
 }
