@@ -686,8 +686,22 @@ inline hipEvent_t* kernel_events(chad_map* m, int id) {
 }
 // sums of the kernel durations of the inserts not read yet (the streams must be idle)
 void collect_kernel_times(chad_map* m) {
+    // CHAD_DEBUG_TIMELINE: every timed kernel's begin and end, in microseconds after the first timed frame's first kernel (stderr;
+    // scripts/timeline.py turns it into the frames-in-flight picture: concurrency, gaps on each frame's stream)
+    static const bool timeline = std::getenv("CHAD_DEBUG_TIMELINE") != nullptr;
     for (uint64_t f = m->ktimed_begin; f < m->ktimed_end; f++) {
         const int at = int(f % chad_map::kKernelRing);
+        if (timeline) {
+            static hipEvent_t base = nullptr;
+            if (!base) base = m->kev[at][2 * CHAD_KERNEL_BOUNDS];
+            for (int id = 0; id < CHAD_KERNEL_COUNT; id++) {
+                if (!((m->kev_launched[at] >> id) & 1u)) continue;
+                float b = 0, e = 0;
+                if (hipEventElapsedTime(&b, base, m->kev[at][2 * id]) == hipSuccess && hipEventElapsedTime(&e, base, m->kev[at][2 * id + 1]) == hipSuccess)
+                    std::fprintf(stderr, "timeline frame %llu kernel %d begin %.2f end %.2f\n", (unsigned long long)f, id, b * 1e3, e * 1e3);
+                else (void)hipGetLastError();
+            }
+        }
         for (int id = 0; id < CHAD_KERNEL_COUNT; id++) {
             if (!((m->kev_launched[at] >> id) & 1u)) continue;
             float t = 0;

@@ -433,10 +433,13 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     const uint32_t launches = hinted || with_rest ? launch_passes : passes;
     for (uint32_t p = 0; p < launches; p++) {
         const bool to_limit = hinted && p + 1 == launches;
-        // A launch that may end up behind grid barriers must not share the chip with another one like it (two grids that
-        // each hold part of the CUs while waiting for the rest of their workgroups would wait forever): sorts running on
-        // different streams take turns for this one launch.
-        if (to_limit && one_at_a_time && wait_for_it) (void)hipStreamWaitEvent(stream, one_at_a_time, 0);
+        // A launch that may end up behind grid barriers shares the chip with the like launches of the other frames in flight: each
+        // of them is at most RadixSortBuffers::resident workgroups -- the host's SHARE of what the device holds at once -- so all of
+        // them fit together, and whatever else occupies the CUs meanwhile finishes without waiting for a sort.  (Rounds 1-2 made
+        // these launches take turns through an event: with four or more frames in flight every frame's last pass then queued
+        // behind the previous frame's -- 36-57 us of waiting per 200 k-point frame, scripts/timeline.py -- for a barrier that a
+        // frame reaches only when its key has outgrown the hint.)
+        (void)one_at_a_time; (void)wait_for_it;
         auto launch = [&](auto kernel) {
             if (sig.pass_events)
                 hipExtLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, sig.pass_events[2 * p], sig.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
@@ -446,7 +449,6 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
                                    to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
         };
         if (digit_bits == uint32_t(kWideBits)) launch(k_radix_onesweep<P, kWideBits>); else launch(k_radix_onesweep<P, kRadixBits>);
-        if (to_limit && one_at_a_time) (void)hipEventRecord(one_at_a_time, stream);
     }
     if (with_rest) {
         const uint32_t grid = tiles < b.resident ? tiles : b.resident;
