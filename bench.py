@@ -300,7 +300,7 @@ def main():
 
         # PCIe-inclusive: the reference's own signature (host pointer; tsdf.hpp:50), staged through pinned memory by the library
         mp_ = TSDFMap(res, trunc, update_mode=args.update_mode, max_points=args.points)
-        for i in range(2):
+        for i in range(8):   # every frame slot has its pinned staging buffer (made by its first host frame) before the clock starts
             mp_.reset(); mp_.insert(scans[i % len(scans)][2], scans[i % len(scans)][1])
         mp_.sync()
         k_pcie = max(8, args.steps * fps // 4)
