@@ -212,9 +212,10 @@ def test_thousands_of_observations_of_one_voxel_in_one_frame(chad, oracle):
 
 
 def test_three_frames_in_flight_all_outgrow_the_enqueued_sort_passes(chad):
-    """Three consecutive large frames whose extent needs more sort passes than the previous frames' hint: each is finished
-    by its last pass launch running on behind grid barriers, and those launches take turns (three such grids at once
-    would not fit the chip together).  Device-resident, back to back, no synchronisation in between."""
+    """Three consecutive large frames whose extent needs more sort passes than the previous frames' hint: their grids (489 tiles)
+    are too large to be resident beside each other, so each is finished by its catch-all launch (k_radix_onesweep_rest: a
+    resident-sized grid drawing tiles by ticket, grid barriers between the passes), all three in flight at once.
+    Device-resident, back to back, no synchronisation in between."""
     import torch
 
     small = [torch.from_numpy((synth.cfg2_frame(400_000, seed=31 + k)[0] * np.float32(0.1))).cuda() for k in range(3)]
