@@ -712,6 +712,34 @@ void collect_kernel_times(chad_map* m) {
     }
     m->ktimed_begin = m->ktimed_end;
 }
+// CHAD_DEBUG_HOST_PROFILE: where the host's time per insert goes (microseconds per call and section, printed when a map is destroyed)
+struct HostProfile {
+    bool on = std::getenv("CHAD_DEBUG_HOST_PROFILE") != nullptr;
+    double us[12] = {};
+    uint64_t calls = 0;
+    std::chrono::steady_clock::time_point last;
+    void begin() { if (on) { last = std::chrono::steady_clock::now(); calls++; } }
+    void mark(int section) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        us[section] += std::chrono::duration<double, std::micro>(now - last).count();
+        last = now;
+    }
+    void report() const {
+        if (!on || !calls) return;
+        static const char* const names[12] = {"pose/closing/growth", "bounds+keys", "sort", "gather+normals", "waits/clear", "update", "tail", "reset", "prepare_slot", "", "", ""};
+        std::fprintf(stderr, "chad host profile, us per insert (%llu inserts):", (unsigned long long)calls);
+        for (int k = 0; k < 9; k++) std::fprintf(stderr, " %s %.1f", names[k], us[k] / double(calls));
+        std::fprintf(stderr, "\n");
+    }
+};
+static HostProfile g_host_profile;
+struct HostProfileScope {   // a whole call's time into one section
+    int section; std::chrono::steady_clock::time_point t0;
+    explicit HostProfileScope(int s) : section(s), t0(std::chrono::steady_clock::now()) {}
+    ~HostProfileScope() { if (g_host_profile.on) g_host_profile.us[section] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 #define LAUNCH_TIMED(m_, id_, kernel_, grid_, block_, lds_, stream_, ...)                                                   \
     do {                                                                                                                    \
         if (hipEvent_t* ke_ = kernel_events(m_, id_)) hipExtLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, ke_[0], ke_[1], 0u, __VA_ARGS__); \
@@ -870,6 +898,7 @@ void fold_if_due(chad_map* m, hipStream_t stream, size_t n) {
 // tsdf.cpp:39-75 with the points already on the device (n > 0)
 chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t n, const float position[3]) {
     if (n >= (1ull << 30)) return fail(CHAD_ERR_INVALID_ARG, "more than 2^30 points in one frame");
+    g_host_profile.mark(8);
     TRY(note_pose(m, position));
     TRY(finish_closing(m, false));   // a roll-over's archive, once its size is known (never waits)
     m->frames_empty_tail = 0;
@@ -880,6 +909,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     // preparation on the slot's own stream (it has already waited for the slot's previous update: prepare_slot) ...
     hipStream_t prep = f.prep;
     record(m, T_BEGIN, prep);
+    g_host_profile.mark(0);
     const uint32_t list_stride = uint32_t(f.cap_points / kListStripes + kGatherChunk);
     uint4* item_start = reinterpret_cast<uint4*>(f.d_seg + 2 * size_t(list_stride) * kListStripes);
     if (!count) hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(256), 0, prep, f.d_hdr);
@@ -894,6 +924,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         LAUNCH_TIMED(m, CHAD_KERNEL_KEYS, k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
                      f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks, digit_bits);
         record(m, T_CALC, prep);
+        g_host_profile.mark(1);
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
         // last of them covering whatever else the frame turns out to need (radix_sort.hpp, k_radix_onesweep to_limit)
         // launches: what a key of the reported width needs at this frame's digit width (all eight until a frame has reported)
@@ -905,6 +936,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         uint32_t pass_launches = 0;
         if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
         radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used, sig, digit_bits);
+        g_host_profile.mark(2);
         static const uint32_t big_block = std::getenv("CHAD_DEBUG_BIG_BLOCK") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_BLOCK"))) : kBigBlock;
         static const uint32_t big_groups = std::getenv("CHAD_DEBUG_BIG_GROUPS") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_GROUPS"))) : kNormalBigGroups;
         m->sort_turn_used = true;   // (recorded by the hinted path only; an unrecorded event makes the wait a no-op)
@@ -921,6 +953,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
     }
+    g_host_profile.mark(3);
     // ... then the update, on the same stream.  It has to wait for whatever has needed the map to itself since this
     // stream last looked (a roll-over, growth ...), and a deferred reset is carried out here: behind the updates of the
     // other streams enqueued so far, in front of this one and -- through the epoch -- of every later one.
@@ -938,6 +971,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         TRY(exclusive_end(m, prep));
         f.seen_epoch = m->excl_epoch;
     }
+    g_host_profile.mark(4);
     if (count) {
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
@@ -963,6 +997,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         if (!times_stages(m)) record(m, T_NORM, prep);
         record(m, T_UPD, prep);
     }
+    g_host_profile.mark(5);
     if (count && (m->flags & CHAD_FLAG_SPACE_CARVING))   // the extension of SURVEY.md section 8 f4: free space along every ray, behind the update (frames run one at a time)
         hipLaunchKernelGGL(k_carve, grid_for(count, 256, 4096), dim3(256), 0, prep, reinterpret_cast<const float4*>(f.sort.points[0]), reinterpret_cast<const float4*>(f.sort.points[1]),
                            f.d_hdr, pos, m->res, m->recip, m->trunc, m->view);
@@ -981,6 +1016,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             std::printf("mc  calc %.2f\nmc  sort %.2f\nnorm est %.2f\noct  upd %.2f\ntotal    %.2f\n", m->ms[T_CALC], m->ms[T_SORT], m->ms[T_NORM], m->ms[T_UPD], m->ms[T_BEGIN]);
         }
     }
+    g_host_profile.mark(6);
     return CHAD_OK;
 }
 
@@ -1102,6 +1138,7 @@ void chad_map_destroy(chad_map* m) {
     DeviceGuard guard(m->device);
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    g_host_profile.report();
     if (m->report_folds) std::fprintf(stderr, "chad: staging folds %llu\n", (unsigned long long)m->folds);
     if (m->d_stamps) {  // diagnostic: mean cycles per phase over the waves of the last update launch
         std::vector<unsigned long long> st(8192 * 16);
@@ -1166,6 +1203,7 @@ void chad_map_destroy(chad_map* m) {
 static bool owns_next_frame(chad_map* m) { return int32_t(m->stream_frames++ % uint64_t(m->comm->world)) == m->comm->rank; }
 
 chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t n, const float position[3]) {
+    g_host_profile.begin();
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
     if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
@@ -1176,6 +1214,7 @@ chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t 
 }
 
 chad_status chad_map_insert_device_stream(chad_map* m, const float* xyz_device, size_t n, const float position[3], void* producer_stream) {
+    g_host_profile.begin();
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
     if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
@@ -1253,6 +1292,7 @@ chad_status chad_map_sync(chad_map* m) {
 
 chad_status chad_map_reset(chad_map* m) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
+    HostProfileScope profiled(7);
     DeviceGuard guard(m->device);
     TRY(finish_closing(m, true));
     if (!m->closed.empty()) {
