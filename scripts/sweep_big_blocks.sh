@@ -1,5 +1,5 @@
 #!/bin/bash
-# k_frame_normals: which point blocks get a whole workgroup (size threshold) and how many workgroups serve them
-for bb in 128 256 384 512 1024; do for bg in 128 256 512 768; do
-  echo "big_block=$bb big_groups=$bg $(CHAD_DEBUG_BIG_BLOCK=$bb CHAD_DEBUG_BIG_GROUPS=$bg python bench.py --steps 30 --warmup 3 --cpu-seconds 0 --no-extras 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.readline()); k={x["kernel"]:x["ms"] for x in d["roofline"]["kernels"]}; print("normals", k["k_frame_normals"], "gather", k["k_frame_gather"], "ms_per_step", round(d["ms_per_step"],4))')"
-done; done | tee gpurun_out/sweep_big_blocks.log
+# normals kernel (alone) against the size above which a block gets a whole workgroup and the number of such workgroups
+for bb in 192 256 384; do for g in 384 512 640; do
+  echo "big_block=$bb big_groups=$g $(CHAD_DEBUG_BIG_BLOCK=$bb CHAD_DEBUG_BIG_GROUPS=$g python bench.py --steps 20 --cpu-seconds 0 --no-extras 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.readline()); print("normals alone", d["stage_ms"]["ms_norm_est"], "ms/frame", round(d["ms_per_frame"],4))')"
+done; done 2>&1 | tee gpurun_out/sweep_big_blocks.log
