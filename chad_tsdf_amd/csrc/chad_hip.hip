@@ -163,7 +163,7 @@ struct chad_map {
     uint64_t pack_points = 0;        // points inserted since the last fold of the staging words was considered
     uint32_t pack_seen_folded = 0;   // what the device's "staging words in use" counter showed then
     uint64_t folds = 0;
-    uint64_t fold_due = kPackFoldPoints;   // (CHAD_DEBUG_FOLD_POINTS: tests fold often)
+    uint64_t fold_due = pack_fold_points(3);   // points since the last fold that make the next one due (set for the map's slots at creation; CHAD_DEBUG_FOLD_POINTS: tests fold often)
     bool report_folds = false;
     volatile uint32_t* h_live_blocks = nullptr;  // host-mapped word the device mirrors the live block count into each frame
     uint32_t* d_live_blocks = nullptr;           // (its device address): lets the host grow the pools without a round trip
@@ -875,7 +875,7 @@ chad_status insert_nothing(chad_map* m, const float position[3]) {
 }
 
 // The scatter form of the update stages its observations in one packed word per voxel whose count field holds 2^23 of them
-// (map_kernels.hpp, kPackCountShift); k_fold_packed moves the staged part into the exact sums.  It is due when kPackFoldPoints points
+// (map_kernels.hpp, kPackCountShift); k_fold_packed moves the staged part into the exact sums.  It is due when pack_fold_points(slots) points
 // have been inserted since the last one -- a voxel receives at most one observation per point -- and only if some launch has used
 // the staging words since (the device says so through a host-mapped word: a map fed dense frames never folds).  The frames that
 // may not have run yet when the fold does are carried over: up to two per frame slot (a slot is reused once its previous frame's
@@ -1073,6 +1073,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         m->own_stream = true;
     }
     if (const char* e = std::getenv("CHAD_SLOTS")) m->n_slots = std::min<uint32_t>(chad_map::kMaxSlots, std::max(1, std::atoi(e)));
+    if (!m->report_folds) m->fold_due = pack_fold_points(m->n_slots);   // (unless CHAD_DEBUG_FOLD_POINTS has set it)
     m->serial = (m->flags & (CHAD_FLAG_TIMING | CHAD_FLAG_VERBOSE | CHAD_FLAG_SPACE_CARVING)) != 0 || std::getenv("CHAD_DEBUG_SERIAL") != nullptr ||
                 ((m->flags & CHAD_FLAG_TIME_KERNELS) && !std::getenv("CHAD_DEBUG_TIME_PIPELINED"));   // (experiment: per-kernel time stamps with three frames in flight)
 

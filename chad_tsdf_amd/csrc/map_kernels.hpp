@@ -53,15 +53,18 @@ __device__ __forceinline__ long long sum_units(float d, float units_per_metre) {
 // So an observation of the scatter form is ONE 64-bit add into a staging word per voxel: (1 << 40) + round(d * 2^16 / trunc) --
 // count in the top 24 bits, the signed sum below it (a negative sum borrows from the count; decoding undoes that).  2^16 units per
 // truncation distance: 7.6e-6 of it per observation at worst, against the 1e-4 bar, and still an exact, order-independent integer.
-// The sum field holds 2^23 observations of +-trunc: the host folds the staging words into (brick_sum, brick_cnt) before a voxel
-// could have received that many (chad_hip.hip, fold_if_due), and only frames of at most kPackMaxPoints points use them: between two
-// folds a voxel gets at most kPackFoldPoints observations + those of the frame that made the fold due and of the (at most eight)
-// frames that overtake the fold on other streams: 2^22 + 9 * 2^18 < 2^23.
+// The sum field holds 2^23 observations of +-trunc (kPackCapacity): the host folds the staging words into (brick_sum, brick_cnt)
+// before a voxel could have received that many (chad_hip.hip, fold_if_due), and only frames of at most kPackMaxPoints points use
+// them.  Between the executions of two folds a voxel gets at most one observation per point of: the frames counted towards the
+// second fold, the frame that made it due, the frames that overtake it on other streams (fewer than the frame slots), and the
+// frames enqueued before the first fold that ran behind it (two per slot at most) -- so a fold is due after
+// pack_fold_points(slots) points.
 constexpr uint32_t kPackCountShift = 40;
 constexpr float kPackOne = 65536.0f;                         // 2^16 units per truncation distance
 constexpr long long kPackToSum = 1ll << (30 - 16);           // one staging unit in units of the exact sum (kSumOne = 2^30)
 constexpr uint32_t kPackMaxPoints = 1u << 18;                // larger frames take two exact atomics per observation in the scatter form
-constexpr uint64_t kPackFoldPoints = 1ull << 22;             // points inserted since the last fold that make the next one due
+constexpr uint64_t kPackCapacity = 1ull << 23;               // observations of +-trunc the staging word's sum field holds
+inline uint64_t pack_fold_points(uint32_t slots) { return kPackCapacity - uint64_t(3u * slots + 2u) * kPackMaxPoints; }   // 5.5 M at three slots, 1.6 M at eight
 
 struct MapView {
     uint64_t* hash_keys;

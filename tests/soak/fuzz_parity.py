@@ -15,6 +15,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"   # frames of 1-4 M points (the oracle needs 0.15-0.6 s for each)
 t_end = time.time() + budget
 cases = 0
+last_report = time.time()
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     res = float(np.float32(rng.choice([0.02, 0.035, 0.05, 0.0731, 0.1, 0.2])))
@@ -67,5 +68,8 @@ while time.time() < t_end:
         sys.exit(1)
     cases += 1
     seed += 1
+    if time.time() - last_report > 60.0:   # (a run that writes nothing for minutes is taken to be hung by the GPU box's watchdog)
+        print(f"... {cases} cases so far, next seed {seed}", flush=True)
+        last_report = time.time()
     m.close()
 print(f"fuzz ok: {cases} cases, seeds up to {seed - 1}")

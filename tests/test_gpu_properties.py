@@ -360,3 +360,26 @@ def test_scatter_staging_is_folded_and_read_through(chad, oracle, monkeypatch, c
     err = capfd.readouterr().err
     folds = [int(line.split()[-1]) for line in err.splitlines() if line.startswith("chad: staging folds")]
     assert folds and folds[-1] >= 2, err
+
+
+def test_scatter_staging_folds_at_the_default_threshold(chad, oracle, monkeypatch, capfd):
+    """29 sparse frames (200 k points at 2 cm voxels, automatic mode) from one pose, no roll-over: 5.8 M points pass the default fold
+    threshold of a three-slot map (5 505 024 = 2^23 less what the frames in flight around a fold can add) once; the map is the
+    oracle's whether a voxel's observations sit in the staging word, in the exact sums or in both."""
+    monkeypatch.setenv("CHAD_DEBUG_FOLD_POINTS", "5505024")   # the default, spelt out so that the library reports its folds
+    res, trunc = 0.02, 0.06
+    c5 = synth.CFG5
+    m = chad.TSDFMap(res, trunc, max_blocks=1 << 21)
+    o = oracle.OracleMap(res, trunc)
+    sensor = np.float32([0.0, 0.0, 0.0])
+    for k in range(29):
+        pts = synth.box_scan(200_000, np.array(c5["lo"]), np.array(c5["hi"]), sensor, 9000 + k)
+        m.insert(pts, sensor)
+        o.insert(pts, sensor)
+    m.sync()
+    assert_leaves_match(m.export_leaves(), o.export_leaves(), trunc)
+    st = m.stats()
+    assert st["overflow"] == 0 and st["blocks"] == int(o.stats()["blocks"])
+    m.close()
+    folds = [int(line.split()[-1]) for line in capfd.readouterr().err.splitlines() if line.startswith("chad: staging folds")]
+    assert folds and folds[-1] >= 1
