@@ -129,8 +129,6 @@ struct chad_map {
     int device = 0;
     hipStream_t stream = nullptr;       // the map's stream: every operation that needs the map to itself
     hipEvent_t excl_done = nullptr;     // recorded behind the last such operation
-    hipEvent_t sort_turn = nullptr;     // behind the last sort launch that may run on behind grid barriers: those take turns (radix_sort.hpp)
-    bool sort_turn_used = false;
     uint64_t excl_epoch = 0;            // ... and counted
     bool pending_clear = false;         // chad_map_reset is lazy: the clear runs on the next insert's stream, right before its update
     bool pending_clear_overflow = false;
@@ -935,11 +933,10 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         sig.fault = m->d_overflow; sig.consumed = m->d_consumed + m->last_slot * 16u; sig.seq = ++f.input_seq;
         uint32_t pass_launches = 0;
         if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
-        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, m->sort_turn, m->sort_turn_used, sig, digit_bits);
+        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits);
         g_host_profile.mark(2);
         static const uint32_t big_block = std::getenv("CHAD_DEBUG_BIG_BLOCK") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_BLOCK"))) : kBigBlock;
         static const uint32_t big_groups = std::getenv("CHAD_DEBUG_BIG_GROUPS") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_GROUPS"))) : kNormalBigGroups;
-        m->sort_turn_used = true;   // (recorded by the hinted path only; an unrecorded event makes the wait a no-op)
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         if (times_kernels(m)) m->kev_launched[m->ktimed_end % chad_map::kKernelRing] |= ((1u << pass_launches) - 1u) << CHAD_KERNEL_SORT_PASS0;
@@ -1094,7 +1091,6 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         CREATE_TRY(hipMalloc(&f.d_part, sizeof(FramePartial) * kFrameBlocks));
     }
     CREATE_TRY(hipEventCreateWithFlags(&m->excl_done, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&m->sort_turn, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->closing_counted, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->closing_count, kCountStripes * 64));
     if (!m->own_stream) CREATE_TRY(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming));
@@ -1183,7 +1179,6 @@ void chad_map_destroy(chad_map* m) {
     if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
     free_sort_buffers(m->aux_sort);
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
-    if (m->sort_turn) (void)hipEventDestroy(m->sort_turn);
     if (m->closing_counted) (void)hipEventDestroy(m->closing_counted);
     if (m->closing_count) (void)hipHostFree(m->closing_count);
     if (m->closing) free_map_storage(m->closing_view);

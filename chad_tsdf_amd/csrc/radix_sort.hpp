@@ -414,7 +414,7 @@ k_radix_onesweep_rest(uint64_t* __restrict__ keys0, typename P::T* __restrict__ 
 // the first pass reading the raw points `first_src` (float xyz[n][3]) in input order.
 template <class P>
 inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                  uint32_t hist_blocks, uint32_t launch_passes, const void* first_src, hipEvent_t one_at_a_time = nullptr, bool wait_for_it = false,
+                                  uint32_t hist_blocks, uint32_t launch_passes, const void* first_src,
                                   const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits) {
     if (n == 0) return;
     const uint32_t tiles = radix_tiles(n);
@@ -439,7 +439,6 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         // these launches take turns through an event: with four or more frames in flight every frame's last pass then queued
         // behind the previous frame's -- 36-57 us of waiting per 200 k-point frame, scripts/timeline.py -- for a barrier that a
         // frame reaches only when its key has outgrown the hint.)
-        (void)one_at_a_time; (void)wait_for_it;
         auto launch = [&](auto kernel) {
             if (sig.pass_events)
                 hipExtLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, sig.pass_events[2 * p], sig.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
@@ -463,12 +462,11 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
 }
 inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
                                uint32_t launch_passes = 0, const RadixSortSignals& sig = RadixSortSignals{}) {
-    radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr, nullptr, false, sig);
+    radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr, sig);
 }
 inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                      uint32_t hist_blocks, uint32_t launch_passes, hipEvent_t one_at_a_time, bool wait_for_it, const RadixSortSignals& sig,
-                                      uint32_t digit_bits) {
-    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, one_at_a_time, wait_for_it, sig, digit_bits);
+                                      uint32_t hist_blocks, uint32_t launch_passes, const RadixSortSignals& sig, uint32_t digit_bits) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, sig, digit_bits);
 }
 // Workgroups of a pass kernel the device holds at once: the kernel's real occupancy (registers, LDS) x CU count, with a quarter
 // held back (the runtime's answer can exceed what the hardware admits by one per CU -- MI355X_MICROARCH.md, Residency).
