@@ -139,6 +139,8 @@ struct chad_map {
     uint32_t* d_consumed = nullptr;           // (its device address)
     RadixSortBuffers aux_sort{};        // block-key sorter of exports and of Submap::finalize (never a frame slot's: those belong to frames in flight)
     size_t aux_cap = 0;
+    uint32_t cu_count = 256;            // compute units of the map's device (hipDeviceProp_t::multiProcessorCount): every grid that is sized "per CU" uses it
+    TileLaunch tile{};                  // launch shape of the update kernel on this device for this map's resolution / truncation (tile_update.hpp)
     uint32_t sort_resident = 0;         // workgroups of the frame sort's pass kernel the device certainly holds at once (radix_resident_workgroups)
     uint32_t aux_resident = 0;
     static constexpr uint32_t kMaxSlots = 8;
@@ -154,7 +156,10 @@ struct chad_map {
     MapView view{};
     uint32_t hash_capacity = 0, brick_capacity = 0;
     FrameHeader* h_hdr = nullptr;  // pinned
-    uint32_t* d_overflow = nullptr;  // MapView::overflow (word 0; word 8: launches that have used the scatter form's staging words)
+    uint32_t* d_overflow = nullptr;  // 16 words.  Word 0: sticky fault bits of the frame sorts (kSortFaultStalled); words 1..7: MapView::overflow of the tables
+                                     // alive (active, spare, closing: each table has a word of its own, so that clearing one table -- ordered behind ITS updates --
+                                     // cannot wipe what a frame in flight reports about another); word 8: launches that have used the scatter form's staging words
+    uint32_t overflow_words_used = 0;   // bit w: word w belongs to a table
     static constexpr uint32_t kRecentFrames = 2 * 8;   // two per frame slot at most (fold_if_due)
     size_t recent_points[kRecentFrames] = {};
     uint32_t recent_at = 0;
@@ -197,6 +202,8 @@ struct chad_map {
     uint64_t frames_empty_tail = 0;               // empty inserts since the last one with points (they use no slot)
     // Frame-sharded multi-GPU map (chad_map_attach_comm): insert k of the stream is integrated by rank k % world only, and a
     // submap is closed by merging the ranks' partial bricks (merge_and_close) instead of archiving the local ones.
+    int stage_mode = 0;                           // chad_map_insert (host points): 0 = direct copy for frames of stage_direct_from bytes and more, staged below; 1 = always staged; 2 = always direct
+    size_t stage_direct_from = size_t(512) << 10; // (CHAD_STAGE_MODE = staged | direct, CHAD_STAGE_DIRECT_KB: read when the map is created)
     bool copy_pool_failed = false;
     std::unique_ptr<CopyPool> copy_pool;          // helper threads of chad_map_insert's staging copy (made by the first large host frame)
     chad_comm* comm = nullptr;
@@ -205,6 +212,7 @@ struct chad_map {
     // enqueued on the map's stream when the previous one's numbers have reached the host (merge_advance): polled by every insert,
     // waited for by whatever needs the closed submap.
     chad_comm* closing_comm = nullptr;            // non-null: the closing table is being merged over this communicator
+    bool in_exchange = false;                     // join_streams is driving the exchange (no re-entry from inside it)
     int merge_stage = 0;                          // 0: local block count pending, 1: all ranks' counts pending, 2: size of the union pending
     hipEvent_t merge_event = nullptr;             // behind the device-to-host copy of the current stage's numbers
     uint64_t* merge_host = nullptr;               // pinned: [0..15] blocks per rank, [16] blocks in the union, [17] this rank's count (source of an H2D copy)
@@ -213,6 +221,8 @@ struct chad_map {
     uint64_t* merge_keys = nullptr; long long* merge_sum = nullptr; uint32_t* merge_cnt = nullptr;   // ... compacted raw (arena a)
     uint64_t merge_total = 0;                     // blocks over all ranks
     uint32_t* merge_heads = nullptr;              // (arena b) per-chunk counts of distinct keys
+    uint64_t* merge_sorted = nullptr;             // (arena b) all ranks' block keys, sorted: kept from stage 1 to stage 2 in a buffer of the exchange's own
+                                                  // (aux_sort belongs to whoever sorts next: an export or a finalize between the two stages)
     // stage timing (CHAD_FLAG_TIMING): a ring of event sets, one per insert, read back lazily by chad_map_stats so
     // that timing adds no synchronisation to insert()
     static constexpr int kTimingRing = 64;
@@ -269,8 +279,19 @@ void free_frame_buffers(FrameSlot& f) {
     f.cap_points = 0;
 }
 
-// Wait for everything enqueued for this map, on all of its streams.
+// Wait for everything enqueued for this map, on all of its streams.  A multi-GPU exchange in progress is driven to its end first:
+// its later stages are only enqueued when the host looks (merge_advance), and a host that blocks here -- in sync, stats, an export,
+// a query, growth -- without looking would leave the peers' collectives waiting on the device for a stage this rank never issues.
+// Every blocking entry point of the library comes through here (or through finish_closing(m, true) itself), so a rank that stops
+// inserting right after a roll-over still completes its share as soon as it calls anything that waits.
+chad_status finish_closing(chad_map* m, bool block);
 chad_status join_streams(chad_map* m) {
+    if (m->closing_comm && !m->in_exchange) {
+        m->in_exchange = true;
+        const chad_status s = finish_closing(m, true);
+        m->in_exchange = false;
+        if (s != CHAD_OK) return s;
+    }
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) HIP_TRY(hipStreamSynchronize(f.prep));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHAD_OK;
@@ -346,18 +367,24 @@ chad_status ensure_aux_sort(chad_map* m, size_t n) {
     return CHAD_OK;
 }
 
-void free_map_storage(MapView& v) {
+void free_map_storage(chad_map* m, MapView& v) {
     (void)hipFree(v.hash_keys); (void)hipFree(v.live_bits);
     (void)hipFree(v.brick_sum); (void)hipFree(v.brick_cnt); (void)hipFree(v.brick_pack); (void)hipFree(v.brick_count);
-    v = MapView{};  // (v.overflow belongs to the chad_map)
+    if (v.overflow) m->overflow_words_used &= ~(1u << uint32_t(v.overflow - m->d_overflow));
+    v = MapView{};
 }
 
 // Hash table + brick pools for `blocks` bricks, empty (keys EMPTY, values PENDING, sums and counts zero).
-chad_status alloc_map_storage(MapView& v, uint64_t blocks, hipStream_t stream, uint32_t* overflow) {
+chad_status alloc_map_storage(chad_map* m, MapView& v, uint64_t blocks, hipStream_t stream) {
     uint64_t hcap = 1024;
     while (hcap < blocks * 2) hcap <<= 1;  // load factor <= 0.5
     v = MapView{};
-    v.overflow = overflow;
+    uint32_t word = 1;
+    while (word < 8 && ((m->overflow_words_used >> word) & 1u)) word++;
+    if (word == 8) return fail(CHAD_ERR_HIP, "internal: more than seven tables alive");
+    m->overflow_words_used |= 1u << word;
+    v.overflow = m->d_overflow + word;
+    HIP_TRY(hipMemsetAsync(v.overflow, 0, 4, stream));
     HIP_TRY(hipMalloc(&v.hash_keys, hcap * 8));
     HIP_TRY(hipMalloc(&v.live_bits, hcap / 8));
     HIP_TRY(hipMalloc(&v.brick_sum, hcap * 512));   // a brick lives at its hash slot; 64-bit sums (map_kernels.hpp)
@@ -478,9 +505,9 @@ chad_status close_active(chad_map* m) {
     TRY(finish_closing(m, true));          // at most one submap closes at a time (roll-overs are many frames apart)
     TRY(flush_pending_clear(m));
     if (!m->has_spare) {                   // first roll-over, or the table has grown since: an empty table of the same size
-        if (alloc_map_storage(m->spare, m->brick_capacity, m->stream, m->d_overflow) != CHAD_OK) {
+        if (alloc_map_storage(m, m->spare, m->brick_capacity, m->stream) != CHAD_OK) {
             // no room for a second table: the synchronous way
-            free_map_storage(m->spare);
+            free_map_storage(m, m->spare);
             g_error.clear();
             uint32_t blocks = 0;
             TRY(read_block_count(m, &blocks));
@@ -521,7 +548,10 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
     TRY(finish_closing(m, true));          // at most one submap closes at a time
     TRY(flush_pending_clear(m));
     if (!m->has_spare) {
-        if (alloc_map_storage(m->spare, m->brick_capacity, m->stream, m->d_overflow) != CHAD_OK) { free_map_storage(m->spare); return CHAD_ERR_OUT_OF_MEMORY; }
+        if (alloc_map_storage(m, m->spare, m->brick_capacity, m->stream) != CHAD_OK) {
+            free_map_storage(m, m->spare);
+            return fail(CHAD_ERR_OUT_OF_MEMORY, "multi-GPU exchange: no room for the spare table the closing submap is swapped against");
+        }
         m->has_spare = true;
     }
     TRY(exclusive_begin(m));               // the map's stream waits for every update enqueued so far ...
@@ -534,7 +564,30 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
     return exclusive_end(m, m->stream);    // ... and later updates (into the new table) wait for this point only
 }
 
+// A stage failed on THIS rank (out of memory for its scratch, an implausible count, a transport error): the closing state is torn
+// down -- the share is dropped, its table cleared and kept as the spare, an empty submap stands in for the lost one so that submap
+// indices stay aligned with their poses -- so that this rank reports the error once instead of re-entering the stage on every later
+// insert.  The remaining collectives of the exchange are NOT issued: the peers' next collective waits for this rank (RCCL's own
+// watchdog, NCCL_TIMEOUT, ends that wait); a failed exchange is fatal for the sharded map as a whole.
+static void merge_abort(chad_map* m) {
+    if (!m->closing) return;
+    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, 0u);
+    (void)hipGetLastError();
+    Submap lost;
+    if (alloc_submap(lost, 0) != CHAD_OK) { free_submap(lost); (void)hipGetLastError(); }
+    m->closed.push_back(lost);
+    m->spare = m->closing_view; m->has_spare = true;
+    m->closing_view = MapView{}; m->closing = false; m->closing_comm = nullptr; m->merge_stage = 0;
+}
+
+static chad_status merge_stages(chad_map* m, bool block);
 chad_status merge_advance(chad_map* m, bool block) {
+    const chad_status s = merge_stages(m, block);
+    if (s != CHAD_OK) { const std::string why = g_error; merge_abort(m); g_error = "multi-GPU exchange abandoned on this rank: " + why; }
+    return s;
+}
+
+static chad_status merge_stages(chad_map* m, bool block) {
     chad_comm* c = m->closing_comm;
     hipStream_t s = m->stream;
     const uint32_t world = uint32_t(c->world);
@@ -573,11 +626,12 @@ chad_status merge_advance(chad_map* m, bool block) {
             if (total >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks over all ranks");
             m->merge_total = total;
             const uint32_t chunks = uint32_t((total + kUniqueChunk - 1) / kUniqueChunk);
-            HIP_TRY(m->merge_b.reserve(Arena::padded(longest * 8) + Arena::padded(longest * 8 * world) + Arena::padded(size_t(chunks) * 4) + Arena::padded(4)));
+            HIP_TRY(m->merge_b.reserve(Arena::padded(longest * 8) + Arena::padded(longest * 8 * world) + Arena::padded(size_t(chunks) * 4) + Arena::padded(4) + Arena::padded(total * 8)));
             uint64_t* send = m->merge_b.take<uint64_t>(longest);
             uint64_t* recv = m->merge_b.take<uint64_t>(longest * world);
             m->merge_heads = m->merge_b.take<uint32_t>(chunks);
             uint32_t* d_union_n = m->merge_b.take<uint32_t>(1);
+            m->merge_sorted = m->merge_b.take<uint64_t>(total);
             if (total) {
                 // all ranks' keys (lists padded to the longest), then the sorted union -- the same on every rank
                 hipLaunchKernelGGL(k_fill_u64, grid_for(longest), dim3(256), 0, s, send, size_t(longest), kEmptyKey);
@@ -588,7 +642,8 @@ chad_status merge_advance(chad_map* m, bool block) {
                 RadixSortSignals sig;
                 sig.fault = m->d_overflow;
                 radix_sort_enqueue(m->aux_sort, uint32_t(total), kMaxPasses, nullptr, s, 0, 0, sig);   // an even number of passes: sorted keys end up in keys[0]
-                hipLaunchKernelGGL(k_unique_count, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(total), m->merge_heads);
+                HIP_TRY(hipMemcpyAsync(m->merge_sorted, m->aux_sort.keys[0], size_t(total) * 8, hipMemcpyDeviceToDevice, s));   // aux_sort is free again behind this copy
+                hipLaunchKernelGGL(k_unique_count, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->merge_sorted, uint32_t(total), m->merge_heads);
                 hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, s, m->merge_heads, chunks, d_union_n);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(&m->merge_host[16], d_union_n, 4, hipMemcpyDeviceToHost, s));
@@ -605,7 +660,7 @@ chad_status merge_advance(chad_map* m, bool block) {
                 HIP_TRY(m->merge_c.reserve(Arena::padded(cells * 8) + Arena::padded(cells * 4)));
                 long long* dense_sum = m->merge_c.take<long long>(cells);
                 uint32_t* dense_cnt = m->merge_c.take<uint32_t>(cells);
-                hipLaunchKernelGGL(k_unique_write, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->aux_sort.keys[0], uint32_t(m->merge_total), m->merge_heads, arch.keys);
+                hipLaunchKernelGGL(k_unique_write, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, m->merge_sorted, uint32_t(m->merge_total), m->merge_heads, arch.keys);
                 // this rank's bricks into dense buffers over the union; the all-reduce: 64-bit integer sums and counts, exact in any order
                 HIP_TRY(hipMemsetAsync(dense_sum, 0, cells * 8, s));
                 HIP_TRY(hipMemsetAsync(dense_cnt, 0, cells * 4, s));
@@ -757,15 +812,16 @@ chad_status grow_if_needed(chad_map* m) {
     if (live < m->brick_capacity / 2) return CHAD_OK;
     TRY(finish_closing(m, true));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->has_spare) { free_map_storage(m->spare); m->has_spare = false; }   // the next roll-over allocates one of the new size
+    if (m->has_spare) { free_map_storage(m, m->spare); m->has_spare = false; }   // the next roll-over allocates one of the new size
     MapView bigger;
     const uint64_t blocks = std::min<uint64_t>(uint64_t(m->brick_capacity) * 2, 1ull << 30);
-    const chad_status s = alloc_map_storage(bigger, blocks, m->stream, m->d_overflow);
-    if (s != CHAD_OK) { free_map_storage(bigger); m->fixed_capacity = true; g_error.clear(); return CHAD_OK; }  // keep going at the old size
+    const chad_status s = alloc_map_storage(m, bigger, blocks, m->stream);
+    if (s != CHAD_OK) { free_map_storage(m, bigger); m->fixed_capacity = true; g_error.clear(); return CHAD_OK; }  // keep going at the old size
     if (live) hipLaunchKernelGGL(k_rehash_bricks, dim3(512), dim3(256), 0, m->stream, m->view, bigger);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(bigger.overflow, m->view.overflow, 4, hipMemcpyDeviceToDevice, m->stream));   // (what the old table has reported stays reported)
     HIP_TRY(hipStreamSynchronize(m->stream));
-    free_map_storage(m->view);
+    free_map_storage(m, m->view);
     m->view = bigger;
     m->brick_capacity = bigger.brick_capacity; m->hash_capacity = bigger.hash_mask + 1;
     *m->h_live_blocks = live;
@@ -944,8 +1000,9 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                      points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
         record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 20;
-        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(256 * normal_waves_per_cu / kNormalWaves), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                     reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, big_groups, item_start);
+        const uint32_t normal_groups = std::max<uint32_t>(2u, m->cu_count * uint32_t(normal_waves_per_cu) / kNormalWaves);
+        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
+                     reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -987,7 +1044,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             else
                 hipLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
         } else  // the tiled kernel; in automatic mode it takes the scatter form itself when the frame is sparse (decided on the device)
-            tile_update_enqueue(points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, list_stride, pack_counter, pack_seen, m->d_stamps,
+            tile_update_enqueue(m->tile, points0, points1, f.d_normals, item_start, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, prep, adaptive, list_stride, pack_counter, pack_seen, m->d_stamps,
                                 time_kernel ? upd_pair[0] : nullptr, time_kernel ? upd_pair[1] : nullptr);
         if (times_stages(m)) record(m, T_UPD, prep);
     } else {
@@ -1050,8 +1107,16 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->res = sdf_res; m->trunc = sdf_trunc;
     m->recip = float(1.0 / double(sdf_res));  // morton.hpp:63, octree.hpp:82
     m->device = dev; m->flags = o.flags;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) m->cu_count = uint32_t(cus);
+        else (void)hipGetLastError();
+        m->tile = tile_launch_shape(sdf_res, sdf_trunc, m->cu_count);
+    }
     m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
     m->fixed_capacity = (o.flags & CHAD_FLAG_FIXED_CAPACITY) != 0;
+    if (const char* e = std::getenv("CHAD_STAGE_MODE")) m->stage_mode = !std::strcmp(e, "staged") ? 1 : !std::strcmp(e, "direct") ? 2 : 0;
+    if (const char* e = std::getenv("CHAD_STAGE_DIRECT_KB")) m->stage_direct_from = size_t(std::max(0, std::atoi(e))) << 10;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
     if (const char* a = std::getenv("CHAD_DEBUG_FOLD_POINTS")) { m->fold_due = uint64_t(std::atoll(a)); m->report_folds = true; }
     if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)hipMalloc(&m->d_stamps, 8192 * 16 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 16 * 8); }
@@ -1060,9 +1125,10 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
     if (o.stream) m->stream = hipStream_t(o.stream);
     else {
-        // The update is what every frame -- and every other operation on the map -- waits for: its stream gets the highest
-        // priority (0.155 -> 0.13 ms per 1 M-point frame with three frames in flight); the preparation streams stay at the
-        // default (lowest priority for them: no further gain at three slots, a collapse at four).
+        // The map's own stream carries what everything else waits for -- the clear behind a reset, a roll-over's table swap, the
+        // archive and the exchange -- and gets the highest priority: at the default priority those queue behind the frames' kernels
+        // (0.132 instead of 0.094 ms per 1 M-point frame, DESIGN.md dead ends).  The frames' own streams (preparation AND update) stay
+        // at the default: priorities between streams that depend on each other invert (a collapse at four slots).
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (std::getenv("CHAD_DEBUG_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
@@ -1078,7 +1144,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
     CREATE_TRY(hipMalloc(&m->d_overflow, 64));
     CREATE_TRY(hipMemsetAsync(m->d_overflow, 0, 64, m->stream));
-    if (alloc_map_storage(m->view, blocks, m->stream, m->d_overflow) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
+    if (alloc_map_storage(m, m->view, blocks, m->stream) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     m->brick_capacity = m->view.brick_capacity; m->hash_capacity = m->view.hash_mask + 1;
     for (uint32_t k = 0; k < m->n_slots; k++) {
         FrameSlot& f = m->slot[k];
@@ -1133,6 +1199,7 @@ void chad_map_destroy(chad_map* m) {
     if (!m) return;
     orphan_iterators(m);   // iterators that outlive the map report invalid instead of dangling
     DeviceGuard guard(m->device);
+    if (m->closing_comm) (void)finish_closing(m, true);   // an exchange in flight is collective: this rank's remaining stages are issued before the map goes
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     g_host_profile.report();
@@ -1181,11 +1248,11 @@ void chad_map_destroy(chad_map* m) {
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
     if (m->closing_counted) (void)hipEventDestroy(m->closing_counted);
     if (m->closing_count) (void)hipHostFree(m->closing_count);
-    if (m->closing) free_map_storage(m->closing_view);
-    if (m->has_spare) free_map_storage(m->spare);
+    if (m->closing) free_map_storage(m, m->closing_view);
+    if (m->has_spare) free_map_storage(m, m->spare);
     for (auto& s : m->closed) free_submap(s);
     free_submap(m->active_copy);
-    free_map_storage(m->view);
+    free_map_storage(m, m->view);
     (void)hipFree(m->d_overflow); (void)hipFree(m->d_cursor);
     if (m->h_live_blocks) (void)hipHostFree(const_cast<uint32_t*>(m->h_live_blocks));
     if (m->h_hdr) (void)hipHostFree(m->h_hdr);
@@ -1235,20 +1302,29 @@ chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float
     FrameSlot* fp = nullptr;
     TRY(prepare_slot(m, n, &fp));
     FrameSlot& f = *fp;
-    if (n) {
-        // The caller's buffer is borrowed for the duration of the call only: copy it into the slot's pinned staging
-        // buffer in chunks, each chunk's DMA overlapping the CPU copy of the next.  No device synchronisation: insert()
-        // returns as soon as the last chunk is staged, and the host copy of frame k+1 overlaps the kernels of frame k.
+    // The caller's buffer is borrowed for the duration of the call only (tsdf.hpp:50-57 even copies it), and it is pageable memory.
+    // Two ways into HBM (scripts/microbench_h2d.hip, 12 MB on an EPYC 9575F box: the pinned-memory ceiling is 0.232 ms):
+    //   direct  hipMemcpy from the caller's pointer: the runtime page-locks the range in place and the DMA engine reads it there --
+    //           0.231 ms, the ceiling itself, and no CPU copy whose speed depends on where the box's memory sits (the staged path
+    //           needed 0.33-2.35 ms over the boxes seen).  The call returns when the bytes are in HBM: the buffer is the caller's
+    //           again, and meanwhile the device works on the frames before this one (their kernels need less than the copy).
+    //   staged  memcpy into the slot's pinned buffer in chunks, every chunk's DMA behind it (CHAD_STAGE_MODE=staged; and for small
+    //           frames, where a memcpy of a few hundred KB beats the runtime's page-locking)
+    const bool direct = m->stage_mode == 2 || (m->stage_mode == 0 && n * 12 >= m->stage_direct_from);
+    if (direct) {
+        // f.d_xyz is free: the frame that used this slot before has read its input for the last time (prepare_slot waited for the device's word)
+        HIP_TRY(hipMemcpy(f.d_xyz, xyz, n * 12, hipMemcpyHostToDevice));
+    } else {
         if (!f.h_stage) HIP_TRY(hipHostMalloc(&f.h_stage, f.cap_points * 12, hipHostMallocDefault));
-        else HIP_TRY(hipEventSynchronize(f.stage_done));  // its previous frame (two inserts ago) has left the buffer
+        else HIP_TRY(hipEventSynchronize(f.stage_done));  // its previous frame (n_slots inserts ago) has left the buffer
         static const size_t chunk = std::getenv("CHAD_STAGE_CHUNK_KB") ? size_t(std::atoi(std::getenv("CHAD_STAGE_CHUNK_KB"))) << 10 : size_t(2) << 20;  // bytes per chunk (scripts/host_insert_sweep.py)
-        static const int helpers = std::getenv("CHAD_STAGE_THREADS") ? std::max(0, std::atoi(std::getenv("CHAD_STAGE_THREADS")) - 1) : 1;   // one helper beside the caller: 0.57 -> 0.40 ms per 12 MB frame; a third thread gains nothing (the DMA is the bound then)
+        static const int helpers = std::getenv("CHAD_STAGE_THREADS") ? std::max(0, std::atoi(std::getenv("CHAD_STAGE_THREADS")) - 1) : 1;   // one helper beside the caller: 0.57 -> 0.40 ms per 12 MB frame; a third thread gains nothing
         const char* src = reinterpret_cast<const char*>(xyz);
         char* pinned = reinterpret_cast<char*>(f.h_stage);
         char* device = reinterpret_cast<char*>(f.d_xyz);
         hipError_t dma = hipSuccess;
         auto start_dma = [&](size_t at, size_t len) { if (dma == hipSuccess) dma = hipMemcpyAsync(device + at, pinned + at, len, hipMemcpyHostToDevice, f.prep); };
-        if (helpers > 0 && n * 12 >= 3 * chunk) {   // a helper thread shares the copy (one thread: ~25 GB/s; the DMA: ~30-50)
+        if (helpers > 0 && n * 12 >= 3 * chunk) {   // a helper thread shares the copy
             if (!m->copy_pool && !m->copy_pool_failed) {
                 try { m->copy_pool.reset(new CopyPool(helpers)); } catch (...) { m->copy_pool_failed = true; }   // (no thread to be had: the caller copies alone)
             }
@@ -1271,7 +1347,10 @@ chad_status read_back_header(chad_map* m, uint32_t* overflow) {
     TRY(flush_pending_clear(m));
     TRY(join_streams(m));
     HIP_TRY(hipMemcpy(m->h_hdr, m->slot[m->last_slot].d_hdr, offsetof(FrameHeader, first_item), hipMemcpyDeviceToHost));   // (the scalars and counters; not the update kernel's item table)
-    HIP_TRY(hipMemcpy(overflow, m->d_overflow, 4, hipMemcpyDeviceToHost));
+    uint32_t words[8];
+    HIP_TRY(hipMemcpy(words, m->d_overflow, sizeof(words), hipMemcpyDeviceToHost));
+    *overflow = words[0];
+    for (uint32_t w = 1; w < 8; w++) if ((m->overflow_words_used >> w) & 1u) *overflow |= words[w];
     return CHAD_OK;
 }
 
@@ -1281,6 +1360,7 @@ chad_status chad_map_sync(chad_map* m) {
     uint32_t overflow = 0;
     TRY(finish_closing(m, true));   // a roll-over's archive (or exchange: every rank syncs at the same point) is part of "all enqueued work"
     TRY(read_back_header(m, &overflow));
+    if (overflow & kSortFaultStalled) (void)hipMemset(m->d_overflow, 0, 4);   // reported once (every stream is idle here); capacity flags stay until a reset
     if (overflow & kSortFaultStalled) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors (workgroups not dispatched in index order?): at least one frame was sorted incompletely");
     if (overflow) return fail(CHAD_ERR_CAPACITY, "block capacity of the active submap exceeded; raise chad_options.max_blocks");
     return CHAD_OK;
@@ -1308,14 +1388,14 @@ chad_status chad_map_reset(chad_map* m) {
     static const bool no_rotation = std::getenv("CHAD_DEBUG_NO_RESET_ROTATION") != nullptr;
     if (!m->pending_clear && !no_rotation) {
         if (!m->has_spare && !m->spare_unaffordable) {
-            if (alloc_map_storage(m->spare, m->brick_capacity, m->stream, m->d_overflow) == CHAD_OK) m->has_spare = true;
-            else { free_map_storage(m->spare); m->spare_unaffordable = true; g_error.clear(); }
+            if (alloc_map_storage(m, m->spare, m->brick_capacity, m->stream) == CHAD_OK) m->has_spare = true;
+            else { free_map_storage(m, m->spare); m->spare_unaffordable = true; g_error.clear(); }
         }
         if (m->has_spare) {
-            HIP_TRY(hipMemsetAsync(m->d_overflow, 0, 4, m->stream));
+            HIP_TRY(hipMemsetAsync(m->spare.overflow, 0, 4, m->stream));   // the spare table's own flag (no frame is using that table)
             TRY(exclusive_end(m, m->stream));   // later updates wait for the map's stream up to HERE: the spare's own clear lies before this point
             TRY(exclusive_begin(m));            // ... and the old table's clear waits for every update enqueued so far, nobody waits for it
-            hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, 0u);
+            hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, 1u);   // (its flag with it: behind the frames that may still raise it)
             HIP_TRY(hipGetLastError());
             std::swap(m->view, m->spare);
             *m->h_live_blocks = 0;
@@ -1550,6 +1630,10 @@ chad_status chad_map_attach_comm(chad_map* m, chad_comm* c) {
     if (!m) return fail(CHAD_ERR_INVALID_ARG, "null map");
     if (c && c->device != m->device) return fail(CHAD_ERR_INVALID_ARG, "the communicator was created on another device than the map's");
     if (c && (m->flags & CHAD_FLAG_SPACE_CARVING)) return fail(CHAD_ERR_INVALID_ARG, "space carving looks at the leaves already in the map: not defined for a map spread over ranks");
+    if (m->closing_comm) {   // an exchange still in flight holds the old communicator (collective, like every other close point): finish it first
+        DeviceGuard guard(m->device);
+        TRY(finish_closing(m, true));
+    }
     m->comm = c;
     m->stream_frames = 0;
     return CHAD_OK;
@@ -1573,12 +1657,16 @@ chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum,
     hc.keys.resize(nb); hc.tsdf.resize(size_t(nb) * 8); hc.weight.resize(want_weights ? size_t(nb) * 8 : 0);
     if (!nb) return CHAD_OK;
     TRY(ensure_aux_sort(m, nb));
-    uint64_t* d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))));
+    DevBuf out;   // (released on every exit path, like the events below)
+    HIP_TRY(out.alloc(size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))));
+    uint64_t* d_out = out.as<uint64_t>();
     uint64_t* d_keys = d_out; uint64_t* d_tsdf = d_out + nb; uint64_t* d_weight = want_weights ? d_tsdf + size_t(nb) * 8 : nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, m->stream));
+    struct Events {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
+    HIP_TRY(hipEventRecord(ev.e0, m->stream));
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
     RadixSortSignals sig;
     sig.fault = m->d_overflow;
@@ -1590,13 +1678,11 @@ chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum,
     HIP_TRY(hipMemcpyAsync(hc.keys.data(), d_keys, size_t(nb) * 8, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(hc.tsdf.data(), d_tsdf, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
     if (want_weights) HIP_TRY(hipMemcpyAsync(hc.weight.data(), d_weight, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipEventRecord(e1, m->stream));
+    HIP_TRY(hipEventRecord(ev.e1, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     float t = 0;
-    (void)hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventElapsedTime(&t, ev.e0, ev.e1);
     if (ms) *ms += t;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(d_out);
     return CHAD_OK;
 }
 

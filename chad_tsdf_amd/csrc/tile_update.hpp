@@ -373,32 +373,44 @@ inline uint32_t tile_reach(float res, float trunc) {
     return r < 2.0f ? 2u : (r > float(kMaxReach) ? kMaxReach : uint32_t(r));   // (at least 2: the read-back of step 2 wants two cells of every brick inside the tile along x)
 }
 
-inline void tile_update_enqueue(const float4* points0, const float4* points1, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
+// Launch shape of the update kernel for one map: fixed by its resolution and truncation distance (the tile's reach) and by the
+// device it lives on -- computed once per map (chad_map_create), on the map's device: nothing here is process-wide, so maps on
+// different devices, or created from different threads, do not share state.
+struct TileLaunch {
+    uint32_t reach = 0, lds = 0;
+    uint32_t groups = 0, groups_stamped = 0;   // persistent workgroups: as many as are resident at once (registers and LDS decide), on every CU
+};
+inline TileLaunch tile_launch_shape(float res, float trunc, uint32_t cu_count) {
+    TileLaunch t;
+    t.reach = tile_reach(res, trunc);
+    const uint32_t d = 8 + 2 * t.reach;
+    t.lds = uint32_t(((size_t(d) * d * d + 3) & ~size_t(1)) * 8 + 16 + 2 * (kListStripes + 1) * 4 + 8);   // tile + two spare zero cells (padded to 16 bytes) + next item's record + list index
+    int resident[2] = {1, 1};
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[0], k_update_tiled<false, 5>, kTileThreads, t.lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[1], k_update_tiled<true, 5>, kTileThreads, t.lds);
+    (void)hipGetLastError();
+    uint32_t per_cu[2];
+    for (int k = 0; k < 2; k++) per_cu[k] = uint32_t(std::max(1, std::min(8, resident[k])));
+    if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu[0] = per_cu[1] = uint32_t(std::max(1, std::min(8, std::atoi(e))));
+    // every workgroup finds its first item in FrameHeader::first_item (kFirstItems entries)
+    t.groups = std::min<uint32_t>(cu_count * per_cu[0], kFirstItems);
+    t.groups_stamped = std::min<uint32_t>(cu_count * per_cu[1], kFirstItems);
+    return t;
+}
+
+inline void tile_update_enqueue(const TileLaunch& shape, const float4* points0, const float4* points1, const float4* normals, const uint4* items, FrameHeader* h, F3 pos, float res, float recip, float trunc,
                                 const MapView& m, hipStream_t stream, bool adaptive, uint32_t items_capacity, uint32_t* pack_counter, uint32_t* pack_seen_host,
                                 unsigned long long* stamps = nullptr, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr) {
-    const uint32_t reach = tile_reach(res, trunc);
-    const uint32_t d = 8 + 2 * reach;
-    const size_t lds = ((size_t(d) * d * d + 3) & ~size_t(1)) * 8 + 16 + 2 * (kListStripes + 1) * 4 + 8;   // tile + two spare zero cells (padded to 16 bytes) + next item's record + list index
-    // persistent workgroups: as many as are resident at once (registers and LDS decide), on every CU
-    static int resident[2] = {0, 0};
-    static size_t resident_lds = 0;
-    if (resident_lds != lds) {
-        resident[0] = resident[1] = 1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[0], k_update_tiled<false, 5>, kTileThreads, lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[1], k_update_tiled<true, 5>, kTileThreads, lds);
-        resident_lds = lds;
-    }
-    uint32_t per_cu = uint32_t(std::max(1, std::min(8, resident[stamps ? 1 : 0])));
-    if (const char* e = std::getenv("CHAD_DEBUG_WAVES_PER_CU")) per_cu = uint32_t(std::max(1, std::min(8, std::atoi(e))));
-    static_assert(256 * 8 <= kFirstItems, "every workgroup finds its first item in FrameHeader::first_item");
+    const uint32_t reach = shape.reach;
+    const size_t lds = shape.lds;
     // 5 waves per SIMD (<= 96 VGPRs): a 6-wave build (80 VGPRs) spills and measured slower
     if (stamps)
-        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
+        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(shape.groups_stamped), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
     else if (started && stopped)  // the events take the dispatch's own begin and end time stamps: the kernel's execution, without marker packets around it
-        hipExtLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), uint32_t(lds), stream, started, stopped, 0u, points0, points1, normals, items, h, pos,
+        hipExtLaunchKernelGGL((k_update_tiled<false, 5>), dim3(shape.groups), dim3(kTileThreads), uint32_t(lds), stream, started, stopped, 0u, points0, points1, normals, items, h, pos,
                               res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
     else
-        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(256 * per_cu), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
+        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(shape.groups), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
 }
 
 }  // namespace chadhip

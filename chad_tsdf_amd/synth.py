@@ -96,3 +96,59 @@ def cfg5_frame(k: int, n: int | None = None):
     lo = np.asarray(c["lo"]) + p
     hi = np.asarray(c["hi"]) + p
     return box_scan(c["n"] if n is None else n, lo, hi, p, 5000 + k), p.astype(np.float32)
+
+
+# ---- the same generators on the GPU (torch tensors; tests and bench.py only -- never part of the product path) ------------------
+# A 5 000-frame trajectory is a billion points: numpy needs 0.2 s per frame and core, the device a millisecond.  Every operation
+# below is one IEEE f64 (or wrapping int64) operation per element and torch op -- no fused multiply-add can form across ops -- so
+# the frames come out bit for bit as box_scan() makes them (tests/test_gpu_streams.py checks that on the frames it hands the oracle).
+def _i64(x: int) -> int:
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _splitmix64_torch(seed: int, count: int, offset: int, device):
+    import torch
+
+    def lsr(z, s):   # logical shift right of an int64
+        return (z >> s) & ((1 << (64 - s)) - 1)
+
+    k = torch.arange(offset + 1, offset + count + 1, dtype=torch.int64, device=device)
+    z = k * _i64(0x9E3779B97F4A7C15) + _i64(seed)
+    z = (z ^ lsr(z, 30)) * _i64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _i64(0x94D049BB133111EB)
+    return z ^ lsr(z, 31)
+
+
+def box_scan_torch(n: int, lo, hi, sensor, seed: int, device="cuda"):
+    """box_scan() on the GPU: f32 [n, 3] torch tensor, the same bits."""
+    import torch
+
+    f64 = dict(dtype=torch.float64, device=device)
+    lo_t, hi_t, o = torch.tensor(lo, **f64), torch.tensor(hi, **f64), torch.tensor(sensor, **f64)
+    parts, have, offset = [], 0, 0
+    while have < n:
+        m = max(1024, int((n - have) * 2.2) + 64)
+        x = _splitmix64_torch(seed, 3 * m, offset, device)
+        u = ((x >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / 9007199254740992.0)
+        d = (2.0 * u).reshape(m, 3) - 1.0
+        offset += 3 * m
+        sq = d * d
+        r = torch.sqrt((sq[:, 0] + sq[:, 1]) + sq[:, 2])
+        keep = (r >= 1e-3) & (r <= 1.0)
+        parts.append(d[keep] / r[keep, None])
+        have += int(parts[-1].shape[0])
+    d = torch.cat(parts, dim=0)[:n]
+    inf = torch.full_like(d, float("inf"))
+    t = torch.where(d > 0, (hi_t - o) / d, torch.where(d < 0, (lo_t - o) / d, inf))
+    tmin = t.min(dim=1).values
+    return (o + tmin[:, None] * d).to(torch.float32)
+
+
+def cfg5_frame_torch(k: int, n: int | None = None, device="cuda"):
+    """cfg5_frame(k) made on the device: (points f32 [n, 3] CUDA tensor, pose f32 numpy [3])."""
+    c = CFG5
+    p = np.array([0.5 * k, 0.0, 0.0])
+    lo = (np.asarray(c["lo"]) + p).tolist()
+    hi = (np.asarray(c["hi"]) + p).tolist()
+    return box_scan_torch(c["n"] if n is None else n, lo, hi, p.tolist(), 5000 + k, device), p.astype(np.float32)

@@ -179,3 +179,90 @@ def test_cfg4_full_stream_on_two_ranks(tmp_path):
         assert np.array_equal(got["sd"].view(np.uint32), want[1].view(np.uint32)), f"submap {s}: two ranks == one GPU, bit for bit"
         assert [int(a.view(np.uint32).astype(np.uint64).sum()) for a in want] == other[s].tolist(), f"submap {s} on rank 1"
     single.close()
+
+
+def test_sorted_exports_between_the_stages_of_an_exchange(monkeypatch):
+    """The exchange keeps the sorted union of the ranks' block keys from its second stage to its third; exports and finalize sort
+    block keys too, with the map's one auxiliary sorter.  An export of the ACTIVE submap (sorted bricks, cluster words) issued right
+    after the roll-over -- while the exchange has stages outstanding -- must leave the merged submap intact (it used to read the
+    sorter's buffer in the third stage).  One-rank communicator that is not short-cut: the three stages really run."""
+    import ctypes as C
+
+    import chad_tsdf_amd
+    from chad_tsdf_amd import _lib
+
+    lib = _lib.load()
+    monkeypatch.setenv("CHAD_DEBUG_COMM_NO_SHORTCUT", "1")
+    uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    _lib.check(lib.chad_comm_unique_id(uid), "unique_id")
+    comm = C.c_void_p()
+    _lib.check(lib.chad_comm_create_rccl(uid, 0, 1, C.byref(comm)), "create_rccl")
+    monkeypatch.delenv("CHAD_DEBUG_COMM_NO_SHORTCUT")
+
+    class Handle:
+        handle = comm
+
+    plain = chad_tsdf_amd.TSDFMap(0.05, 0.10)
+    shard = chad_tsdf_amd.TSDFMap(0.05, 0.10)
+    shard.attach_comm(Handle)
+    for k, (pts, pos) in enumerate(_stream()):
+        plain.insert(pts, pos)
+        shard.insert(pts, pos)
+        if k == 21:   # the frame that closed submap 0 has just been inserted: the exchange is in its first stages
+            keys, tsdf, _ = shard.export_clusters(-1)
+            bk, bs, bc = shard.export_blocks(-1, ordered=True)
+            assert len(keys) == len(bk) > 0 and np.all(np.diff(bk.cpu().numpy().astype(np.uint64)) > 0)
+    plain.close_submap()
+    shard.close_submap()
+    for s in (0, 1):
+        got, want = shard.export_leaves(s), plain.export_leaves(s)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+        assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    shard.attach_comm(None)
+    shard.close(); plain.close()
+    lib.chad_comm_destroy(comm)
+
+
+def _stopping_rank(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chad_tsdf_amd.sharded import ShardedTSDFMap
+
+    sm = ShardedTSDFMap(0.05, 0.10)
+    for k, (pts, pos) in enumerate(_stream()[:22]):   # frame 21 closes submap 0 -- and is the last thing either rank inserts
+        sm.insert(pts if k % world == rank else None, pos)
+    if rank == 0:
+        sm.local.sync()                               # waits for the exchange: needs rank 1's share of every stage
+        mc, sd, w = sm.export_leaves(0)
+        np.savez(os.path.join(outdir, "stopping_submap0.npz"), mc=mc, sd=sd, w=w)
+        sm.local.close()
+    else:
+        sm.local.close()                              # no sync, no further insert: destroying the map issues this rank's remaining stages
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_stops_right_after_a_roll_over_still_completes_the_exchange(tmp_path):
+    """The exchange's later stages are enqueued when the host looks (every insert polls).  A rank whose stream ends with the frame
+    that triggered the roll-over never inserts again: whatever it calls next that waits -- here nothing but the map's destruction,
+    on the other rank a sync -- must drive its share of the exchange to the end, or the peer waits for ever."""
+    import torch.multiprocessing as mp
+
+    import chad_tsdf_amd
+
+    world, port = 2, 29547
+    mp.spawn(_stopping_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    single = chad_tsdf_amd.TSDFMap(0.05, 0.10)
+    for pts, pos in _stream()[:22]:
+        single.insert(pts, pos)
+    single.sync()
+    want = single.export_leaves(0)
+    got = np.load(tmp_path / "stopping_submap0.npz")
+    assert np.array_equal(got["mc"], want[0]) and np.array_equal(got["w"], want[2])
+    assert np.array_equal(got["sd"].view(np.uint32), want[1].view(np.uint32))
+    single.close()
