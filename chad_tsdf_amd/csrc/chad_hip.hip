@@ -18,6 +18,7 @@
 
 #include "comm.hpp"
 #include "dag.hpp"
+#include "dag_device.hpp"
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
 #include "merge_kernels.hpp"
@@ -178,7 +179,11 @@ struct chad_map {
     std::vector<std::array<float, 12>> closed_pose;                    // rigid correction per closed submap (rotation row-major, translation); empty = identity
     std::vector<Submap> closed;                   // tsdf.cpp:54
     Submap active_copy;                           // dense snapshot of the active submap made for the last export call
-    Dag dag;                                      // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps, built lazily (chad_map_finalize)
+    Dag dag;                                      // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps, built lazily (chad_map_finalize).  With the fold on the
+                                                  // device (the default) this is the host's MIRROR of the level arrays, brought up to date by dag_host()
+    DeviceDag ddag;                               // ... the stores and their look-up tables themselves (dag_device.hpp)
+    bool dag_on_host = false;                     // CHAD_DEBUG_DAG_HOST: the sequential host fold of dag.hpp instead (what the tests hold the device fold against)
+    bool dag_mirror_stale = false;
     std::vector<std::array<uint32_t, 2>> dag_roots;  // submap.hpp:108-109 of the closed submaps folded so far (a prefix of `closed`)
     float dag_ms_device = 0, dag_ms_host = 0;
     uint64_t dag_generation = 0;                  // bumped when the DAG is thrown away (chad_map_reset): iterators of an older generation are dead
@@ -1115,6 +1120,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     }
     m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
     m->fixed_capacity = (o.flags & CHAD_FLAG_FIXED_CAPACITY) != 0;
+    m->dag_on_host = std::getenv("CHAD_DEBUG_DAG_HOST") != nullptr;
     if (const char* e = std::getenv("CHAD_STAGE_MODE")) m->stage_mode = !std::strcmp(e, "staged") ? 1 : !std::strcmp(e, "direct") ? 2 : 0;
     if (const char* e = std::getenv("CHAD_STAGE_DIRECT_KB")) m->stage_direct_from = size_t(std::max(0, std::atoi(e))) << 10;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
@@ -1245,6 +1251,7 @@ void chad_map_destroy(chad_map* m) {
     m->merge_a.release(); m->merge_b.release(); m->merge_c.release();
     if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
     free_sort_buffers(m->aux_sort);
+    m->ddag.release();
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
     if (m->closing_counted) (void)hipEventDestroy(m->closing_counted);
     if (m->closing_count) (void)hipHostFree(m->closing_count);
@@ -1377,6 +1384,8 @@ chad_status chad_map_reset(chad_map* m) {
         m->closed.clear();
     }
     m->dag = Dag();
+    m->ddag.release();
+    m->dag_mirror_stale = false;
     m->dag_roots.clear();
     m->dag_generation++;
     m->mesh_submap = INT32_MIN;
@@ -1652,32 +1661,46 @@ namespace {
 
 struct HostClusters { std::vector<uint64_t> keys, tsdf, weight; };
 
-// Device half: the bricks of a dense submap, ordered by block key, as eight cluster words each.
-chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum, const uint32_t* cnt, uint32_t nb, bool want_weights, HostClusters& hc, float* ms) {
-    hc.keys.resize(nb); hc.tsdf.resize(size_t(nb) * 8); hc.weight.resize(want_weights ? size_t(nb) * 8 : 0);
+// Device half: the bricks of a dense submap, ordered by block key, as eight cluster words each -- left on the device in `out`
+// (keys [nb], then tsdf [8 nb], then weight [8 nb] if wanted); `ms`: device time from here to `done` being recorded.
+struct DeviceClusters {
+    DevBuf out;
+    uint64_t* keys = nullptr; uint64_t* tsdf = nullptr; uint64_t* weight = nullptr;
+};
+chad_status device_cluster_words(chad_map* m, const uint64_t* keys, const float* sum, const uint32_t* cnt, uint32_t nb, bool want_weights, DeviceClusters& dc) {
     if (!nb) return CHAD_OK;
     TRY(ensure_aux_sort(m, nb));
-    DevBuf out;   // (released on every exit path, like the events below)
-    HIP_TRY(out.alloc(size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))));
-    uint64_t* d_out = out.as<uint64_t>();
-    uint64_t* d_keys = d_out; uint64_t* d_tsdf = d_out + nb; uint64_t* d_weight = want_weights ? d_tsdf + size_t(nb) * 8 : nullptr;
-    struct Events {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
-    } ev;
-    HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
-    HIP_TRY(hipEventRecord(ev.e0, m->stream));
+    HIP_TRY(dc.out.alloc(size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))));
+    uint64_t* d_out = dc.out.as<uint64_t>();
+    dc.keys = d_out; dc.tsdf = d_out + nb; dc.weight = want_weights ? dc.tsdf + size_t(nb) * 8 : nullptr;
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
     RadixSortSignals sig;
     sig.fault = m->d_overflow;
     hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
     radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
     hipLaunchKernelGGL(k_leaf_clusters, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, 1.0f / m->trunc /* submap.hpp:23 */,
-                       d_keys, d_tsdf, d_weight);
+                       dc.keys, dc.tsdf, dc.weight);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(hc.keys.data(), d_keys, size_t(nb) * 8, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(hc.tsdf.data(), d_tsdf, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
-    if (want_weights) HIP_TRY(hipMemcpyAsync(hc.weight.data(), d_weight, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
+    return CHAD_OK;
+}
+
+struct TimedSpan {   // device time of a stretch of the map's stream (events released on every exit path)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~TimedSpan() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+
+// ... and on the host (the host fold, chad_map_export_clusters)
+chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum, const uint32_t* cnt, uint32_t nb, bool want_weights, HostClusters& hc, float* ms) {
+    hc.keys.resize(nb); hc.tsdf.resize(size_t(nb) * 8); hc.weight.resize(want_weights ? size_t(nb) * 8 : 0);
+    if (!nb) return CHAD_OK;
+    TimedSpan ev;
+    HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
+    HIP_TRY(hipEventRecord(ev.e0, m->stream));
+    DeviceClusters dc;
+    TRY(device_cluster_words(m, keys, sum, cnt, nb, want_weights, dc));
+    HIP_TRY(hipMemcpyAsync(hc.keys.data(), dc.keys, size_t(nb) * 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(hc.tsdf.data(), dc.tsdf, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
+    if (want_weights) HIP_TRY(hipMemcpyAsync(hc.weight.data(), dc.weight, size_t(nb) * 64, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipEventRecord(ev.e1, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     float t = 0;
@@ -1696,15 +1719,40 @@ chad_status finalize_closed(chad_map* m) {
     double ms_host = 0;
     while (m->dag_roots.size() < m->closed.size()) {
         const Submap& s = m->closed[m->dag_roots.size()];
-        HostClusters hc;
-        TRY(device_clusters(m, s.keys, s.sum, s.cnt, s.blocks, saturate, hc, &ms_device));
-        const auto t0 = std::chrono::steady_clock::now();
         uint32_t root_tsdf = 0, root_weight = 0;
-        dag_add_submap(m->dag, hc.keys.data(), hc.tsdf.data(), saturate ? hc.weight.data() : nullptr, s.blocks, &root_tsdf, &root_weight);
-        ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (m->dag_on_host) {   // CHAD_DEBUG_DAG_HOST: cluster words to the host, the sequential fold of dag.hpp
+            HostClusters hc;
+            TRY(device_clusters(m, s.keys, s.sum, s.cnt, s.blocks, saturate, hc, &ms_device));
+            const auto t0 = std::chrono::steady_clock::now();
+            dag_add_submap(m->dag, hc.keys.data(), hc.tsdf.data(), saturate ? hc.weight.data() : nullptr, s.blocks, &root_tsdf, &root_weight);
+            ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        } else {                // the DAG lives on the device: level by level, bottom-up (dag_device.hpp)
+            TimedSpan ev;
+            HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1));
+            HIP_TRY(hipEventRecord(ev.e0, m->stream));
+            DeviceClusters dc;
+            TRY(device_cluster_words(m, s.keys, s.sum, s.cnt, s.blocks, saturate, dc));
+            HIP_TRY(dag_device_add_submap(m->ddag, dc.keys, dc.tsdf, saturate ? dc.weight : nullptr, s.blocks, m->stream, &root_tsdf, &root_weight));
+            HIP_TRY(hipEventRecord(ev.e1, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            float t = 0;
+            (void)hipEventElapsedTime(&t, ev.e0, ev.e1);
+            ms_device += t;
+            m->dag_mirror_stale = true;
+        }
         m->dag_roots.push_back({root_tsdf, root_weight});
     }
     m->dag_ms_device = ms_device; m->dag_ms_host = float(ms_host);
+    return CHAD_OK;
+}
+
+// The host's copy of the level arrays, up to date (the device fold leaves the new words on the device until somebody reads them here).
+chad_status dag_host(chad_map* m) {
+    if (!m->dag_mirror_stale) return CHAD_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(dag_device_mirror(m->ddag, m->dag, m->stream));
+    m->dag_ms_host += float(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    m->dag_mirror_stale = false;
     return CHAD_OK;
 }
 
@@ -1730,6 +1778,7 @@ chad_status chad_map_dag_level_words(chad_map* m, uint32_t level, size_t* words)
     if (level > CHAD_DAG_CLUSTER_LEVEL) return fail(CHAD_ERR_INVALID_ARG, "level out of range");
     DeviceGuard guard(m->device);
     TRY(finalize_closed(m));
+    if (!m->dag_on_host && m->ddag.ready) { *words = m->ddag.h_scalars[level].size; return CHAD_OK; }   // (no need to bring the words over to count them)
     *words = level < kDagDepth ? m->dag.nodes[level].raw.size() : m->dag.clusters.raw.size();
     return CHAD_OK;
 }
@@ -1739,6 +1788,8 @@ chad_status chad_map_dag_level_copy(chad_map* m, uint32_t level, void* out, size
     TRY(chad_map_dag_level_words(m, level, &words));
     if (capacity_words < words) return fail(CHAD_ERR_INVALID_ARG, "capacity_words too small");
     if (!out) return fail(CHAD_ERR_INVALID_ARG, "null output");
+    DeviceGuard guard(m->device);
+    TRY(dag_host(m));
     if (level < kDagDepth) std::memcpy(out, m->dag.nodes[level].raw.data(), words * 4);
     else std::memcpy(out, m->dag.clusters.raw.data(), words * 8);
     return CHAD_OK;
@@ -1750,8 +1801,12 @@ chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
     TRY(finalize_closed(m));
     std::memset(out, 0, sizeof(*out));
     out->submaps = m->dag_roots.size();
-    for (uint32_t l = 0; l < kDagDepth; l++) { out->uniques[l] = m->dag.nodes[l].uniques; out->dupes[l] = m->dag.nodes[l].dupes; }
-    out->uniques[kDagDepth] = m->dag.clusters.uniques; out->dupes[kDagDepth] = m->dag.clusters.dupes;
+    if (!m->dag_on_host && m->ddag.ready)
+        for (uint32_t l = 0; l <= kDagDepth; l++) { out->uniques[l] = uint32_t(m->ddag.h_scalars[l].uniques); out->dupes[l] = uint32_t(m->ddag.h_scalars[l].dupes); }
+    else {
+        for (uint32_t l = 0; l < kDagDepth; l++) { out->uniques[l] = m->dag.nodes[l].uniques; out->dupes[l] = m->dag.nodes[l].dupes; }
+        out->uniques[kDagDepth] = m->dag.clusters.uniques; out->dupes[kDagDepth] = m->dag.clusters.dupes;
+    }
     out->ms_device = m->dag_ms_device; out->ms_host = m->dag_ms_host;
     return CHAD_OK;
 }
@@ -1761,6 +1816,7 @@ chad_status chad_map_dag_leaves(chad_map* m, int32_t submap, uint64_t* mc, float
     DeviceGuard guard(m->device);
     TRY(finalize_closed(m));
     if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
+    TRY(dag_host(m));
     size_t k = 0;
     const float trunc = m->trunc;
     dag_walk(m->dag, m->dag_roots[size_t(submap)][0], [&](uint64_t code, uint8_t bits) {
@@ -1817,6 +1873,7 @@ chad_status chad_map_iter_begin(chad_map* m, int32_t submap, chad_iter** out) {
     TRY(finalize_closed(m));
     // tsdf.cpp:106-110: "chad::TSDFMap::begin() given faulty root address"
     if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
+    TRY(dag_host(m));
     chad_iter* it = new chad_iter{m, m->dag_generation, submap, DagCursor{}};
     it->cursor.open(m->dag, m->dag_roots[size_t(submap)][0], m->dag_roots[size_t(submap)][1]);
     it->cursor.first();
@@ -1996,6 +2053,7 @@ chad_status mesh_source(chad_map* m, int32_t submap, DevBuf& keys_sorted, DevBuf
         // what the reference meshes (lvr2.cpp:30-90): the leaves read back through the DAG, signed distances de-quantised from 8 bits
         TRY(finalize_closed(m));
         if (size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
+        TRY(dag_host(m));
         std::vector<uint64_t> keys;
         std::vector<float> sd;
         DagCursor c;

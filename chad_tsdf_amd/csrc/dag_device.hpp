@@ -1,0 +1,602 @@
+// dag_device.hpp -- Submap::finalize (submap.hpp:10-106) with the map-wide DAG of NodeLevels (levels.hpp:141-199) RESIDENT ON THE DEVICE.
+//
+// The reference adds every node of a submap's octree, child first, to a per-level store that keeps each distinct value once and
+// hands out addresses in order of first occurrence (NodeLevel::add levels.hpp:57-88, LeafClusterLevel::add levels.hpp:123-139).
+// The levels are independent stores: the addresses a level hands out depend only on the SEQUENCE of values added to it, and a
+// node's value only on the addresses of its children one level down.  So the fold runs bottom-up, one level at a time, and every
+// level is a batch problem: given the level's values in the reference's order of addition (ascending Morton order of the nodes,
+// the signed-distance tree's node before the weight tree's), find for each value the address of its first occurrence -- in the
+// store if the value is already there from an earlier submap, else new, with new addresses handed out in sequence order.
+//   1. probe: every candidate looks its value up in the level's open-addressed table (u32 slots: 0 free, else the address of a
+//      stored value, compared by CONTENT, never by hash alone).  A candidate that reaches a free slot claims it with
+//      kDagPending | its index; a candidate that meets a pending slot of equal content lowers the index (atomicMin): after the
+//      pass every slot claimed in this batch names the batch's FIRST candidate of that content.
+//   2. the candidates that own their slot are the level's new values: an exclusive scan of their word counts in sequence order
+//      gives their addresses behind the store's end -- the order of first occurrence, as the reference hands them out;
+//   3. commit: they append their words to the store and put their address into their slot;  4. resolve: everybody reads its slot.
+// The host half this replaces (dag.hpp: dag_add_submap, a sequential fold of the cluster stream) needs 0.8 ms for a cfg2 frame
+// and 0.6 s for a submap of BASELINE config 5 (1.65 M blocks, 4.8 M cluster words) on one EPYC core: at one roll-over per eleven
+// frames that is 55 ms per frame, against 0.2 ms for the frame itself.  dag.hpp stays: it is the host's READ side (dag_walk,
+// DagCursor over the mirrored arrays) and the fold of CHAD_DEBUG_DAG_HOST=1, which the tests hold this file against word for word.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "dag.hpp"
+#include "merge_kernels.hpp"
+
+namespace chadhip {
+
+constexpr uint32_t kDagPending = 0x80000000u;   // table slot: claimed during the current batch by candidate (slot & ~kDagPending)
+constexpr uint32_t kDagChunk = 2048;            // candidates per workgroup step: 256 threads x 8 CONSECUTIVE candidates (sequence order matters)
+constexpr uint32_t kDagPer = kDagChunk / 256;
+constexpr uint32_t kDagNone = 0xffffffffu;
+
+struct DagScalars {   // one per level, device-resident (mirrored to the host after every fold)
+    uint32_t size;        // words of the level's store in use (address 0 is reserved: levels.hpp:52, :118)
+    uint32_t batch_base;  // size before the current batch's new values
+    uint32_t entries;     // values stored (= table slots in use)
+    uint32_t pad;
+    unsigned long long uniques, dupes;   // levels.hpp:90, :141 (_uniques_n / _dupes_n)
+};
+
+struct DagLevelDev {
+    uint32_t* table = nullptr;
+    uint32_t table_slots = 0;      // power of two
+    void* raw = nullptr;           // u32 words (node levels) or u64 words (cluster level)
+    uint32_t raw_capacity = 0;     // words
+};
+
+__device__ __forceinline__ uint64_t dag_mix_dev(uint64_t h) { h ^= h >> 31; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29; return h; }
+__device__ __forceinline__ uint32_t dag_hash_children(const uint32_t c[8]) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) h = dag_mix_dev(h ^ (uint64_t(c[i]) | (uint64_t(c[i + 1]) << 32))) + uint64_t(i);
+    return uint32_t(dag_mix_dev(h) >> 17);
+}
+__device__ __forceinline__ uint32_t dag_hash_cluster(uint64_t v) { return uint32_t(dag_mix_dev(v ^ 0x9E3779B97F4A7C15ull) >> 17); }
+// a stored node [mask, children of the set bits ...] against a candidate's eight child slots (0 = no child: address 0 is never a child)
+__device__ __forceinline__ bool dag_node_equals(const uint32_t* __restrict__ raw, uint32_t addr, const uint32_t c[8]) {
+    uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) mask |= c[i] ? 1u << i : 0u;
+    if (raw[addr] != mask) return false;
+    uint32_t at = addr + 1;
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (c[i]) same = same && raw[at++] == c[i];
+    return same;
+}
+__device__ __forceinline__ void dag_load8(const uint32_t* __restrict__ p, uint32_t c[8]) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+}
+
+// ---- u64 block scan (two 32-bit fields per value: both stay below 2^32 over a whole level) -----------------------------------
+__device__ __forceinline__ unsigned long long dag_block_scan(unsigned long long v, unsigned long long* total) {   // 256 threads; exclusive
+    __shared__ unsigned long long wave_sum_[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(incl, o); if (int(lane) >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63u) wave_sum_[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (uint32_t w = 0; w < wave; w++) before += wave_sum_[w];
+    *total = wave_sum_[0] + wave_sum_[1] + wave_sum_[2] + wave_sum_[3];
+    return before + incl - v;
+}
+// exclusive scan of the chunk sums (one workgroup), total to *total_out
+__global__ void __launch_bounds__(256)
+k_dag_scan_sums(unsigned long long* __restrict__ sums, uint32_t chunks, unsigned long long* __restrict__ total_out) {
+    unsigned long long carry = 0;
+    for (uint32_t c0 = 0; c0 < chunks; c0 += 256) {
+        const uint32_t c = c0 + threadIdx.x;
+        const unsigned long long v = c < chunks ? sums[c] : 0ull;
+        unsigned long long total;
+        const unsigned long long excl = dag_block_scan(v, &total);
+        if (c < chunks) sums[c] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+// ---- step 0: the blocks that hold leaves, and the cluster level's candidates -------------------------------------------------
+// per block: [valid : 32 | non-empty octets : 32]
+__device__ __forceinline__ unsigned long long dag_block_value(const uint64_t* __restrict__ tsdf, uint32_t b) {
+    uint32_t octets = 0;
+#pragma unroll
+    for (uint32_t o = 0; o < 8; o++) octets += tsdf[size_t(b) * 8 + o] != kClusterEmpty ? 1u : 0u;
+    return octets ? (1ull << 32) | octets : 0ull;   // a brick that was claimed but never written has no counterpart in the octree (dag.hpp)
+}
+__global__ void __launch_bounds__(256)
+k_dag_block_sums(const uint64_t* __restrict__ tsdf, uint32_t nb, unsigned long long* __restrict__ sums) {
+    const uint32_t chunks = (nb + kDagChunk - 1) / kDagChunk;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        unsigned long long mine = 0;
+        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t b = c * kDagChunk + threadIdx.x * kDagPer + j; if (b < nb) mine += dag_block_value(tsdf, b); }
+        unsigned long long total;
+        dag_block_scan(mine, &total);
+        if (threadIdx.x == 0) sums[c] = total;
+    }
+}
+// The cluster level's sequence of additions (submap.hpp:70-99): for every non-empty octet, in block and octet order, the
+// signed-distance word and then the weight word.  saturate == 0 (the reference's own behaviour, Q6): every weight word is all
+// ones, so the sequence is [t0, ones, t1, t2, ...] -- the constant is looked up once, as the second candidate, and the other
+// additions of it are counted as duplicates by the host.  saturate != 0: [t0, w0, t1, w1, ...].
+__global__ void __launch_bounds__(256)
+k_dag_block_apply(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tsdf, const uint64_t* __restrict__ weight, uint32_t nb, uint32_t saturate,
+                  const unsigned long long* __restrict__ sums, uint64_t* __restrict__ vkeys, uint32_t* __restrict__ vblock, uint32_t* __restrict__ oct_before,
+                  uint64_t* __restrict__ cand) {
+    const uint32_t chunks = (nb + kDagChunk - 1) / kDagChunk;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        unsigned long long v[kDagPer], mine = 0;
+        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t b = c * kDagChunk + threadIdx.x * kDagPer + j; v[j] = b < nb ? dag_block_value(tsdf, b) : 0ull; mine += v[j]; }
+        unsigned long long total;
+        unsigned long long at = sums[c] + dag_block_scan(mine, &total);
+        for (uint32_t j = 0; j < kDagPer; j++) {
+            if (!v[j]) continue;
+            const uint32_t b = c * kDagChunk + threadIdx.x * kDagPer + j;
+            const uint32_t rank = uint32_t(at >> 32);
+            uint32_t k = uint32_t(at);
+            vkeys[rank] = keys[b]; vblock[rank] = b; oct_before[rank] = k;
+            for (uint32_t o = 0; o < 8; o++) {
+                const uint64_t t = tsdf[size_t(b) * 8 + o];
+                if (t == kClusterEmpty) continue;
+                if (saturate) { cand[2 * size_t(k)] = t; cand[2 * size_t(k) + 1] = weight[size_t(b) * 8 + o]; }
+                else { cand[k ? k + 1 : 0] = t; if (!k) cand[1] = kClusterEmpty; }
+                k++;
+            }
+            at += v[j];
+        }
+    }
+}
+// candidate index of the k-th non-empty octet's signed-distance word / weight word
+__device__ __forceinline__ uint32_t dag_cluster_cand_t(uint32_t k, uint32_t saturate) { return saturate ? 2u * k : (k ? k + 1u : 0u); }
+__device__ __forceinline__ uint32_t dag_cluster_cand_w(uint32_t k, uint32_t saturate) { return saturate ? 2u * k + 1u : 1u; }
+
+// how many nodes every level gets from this submap: block b > 0 opens a new node at every level below the first digit in which its
+// key parts from its predecessor's (digits 0..18 name a block: three bits per level, root first -- octree.hpp:45-47)
+__global__ void __launch_bounds__(256)
+k_dag_parted_histogram(const uint64_t* __restrict__ vkeys, uint32_t nbv, uint32_t* __restrict__ hist /* [32], zeroed */) {
+    __shared__ uint32_t local[32];
+    if (threadIdx.x < 32) local[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t b = size_t(blockIdx.x) * blockDim.x + threadIdx.x + 1; b < nbv; b += size_t(gridDim.x) * blockDim.x) {
+        const uint64_t x = vkeys[b] ^ vkeys[b - 1];
+        const uint32_t parted = (62u - (63u - uint32_t(__clzll((long long)x)))) / 3u;   // dag.hpp: first depth at which the two paths part
+        atomicAdd(&local[parted & 31u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
+}
+
+// ---- the batch: probe / count / commit / resolve -----------------------------------------------------------------------------
+// kNode: candidates are rows of eight child addresses (0 = no child); else 64-bit cluster words.
+template <bool kNode>
+__global__ void __launch_bounds__(256)
+k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict__ raw_, const void* __restrict__ cand_, uint32_t n, uint32_t* __restrict__ pos) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        uint32_t mine[8];
+        uint64_t value = 0;
+        uint32_t p;
+        if (kNode) { dag_load8(static_cast<const uint32_t*>(cand_) + i * 8, mine); p = dag_hash_children(mine) & mask; }
+        else { value = static_cast<const uint64_t*>(cand_)[i]; p = dag_hash_cluster(value) & mask; }
+        const uint32_t me = kDagPending | uint32_t(i);
+        for (;; p = (p + 1u) & mask) {
+            uint32_t v = __hip_atomic_load(&table[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == 0u) {
+                v = atomicCAS(&table[p], 0u, me);
+                if (v == 0u) break;   // claimed
+            }
+            bool same;
+            if (v & kDagPending) {   // claimed in this batch by candidate j: the same value?
+                const size_t j = v & ~kDagPending;
+                if (kNode) {
+                    uint32_t other[8];
+                    dag_load8(static_cast<const uint32_t*>(cand_) + j * 8, other);
+                    same = true;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) same = same && other[k] == mine[k];
+                } else same = static_cast<const uint64_t*>(cand_)[j] == value;
+                if (same && v > me) atomicMin(&table[p], me);   // the first candidate of a value owns its slot
+            } else same = kNode ? dag_node_equals(static_cast<const uint32_t*>(raw_), v, mine) : static_cast<const uint64_t*>(raw_)[v] == value;
+            if (same) break;
+        }
+        pos[i] = p;
+    }
+}
+template <bool kNode>
+__device__ __forceinline__ unsigned long long dag_new_value(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t i) {
+    if (table[pos[i]] != (kDagPending | i)) return 0ull;   // [new values : 32 | their words : 32]
+    uint32_t words = 1;
+    if (kNode) { uint32_t c[8]; dag_load8(cand + size_t(i) * 8, c); for (int k = 0; k < 8; k++) words += c[k] ? 1u : 0u; }
+    return (1ull << 32) | words;
+}
+template <bool kNode>
+__global__ void __launch_bounds__(256)
+k_dag_new_sums(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t n, unsigned long long* __restrict__ sums) {
+    const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        unsigned long long mine = 0;
+        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j; if (i < n) mine += dag_new_value<kNode>(table, pos, cand, i); }
+        unsigned long long total;
+        dag_block_scan(mine, &total);
+        if (threadIdx.x == 0) sums[c] = total;
+    }
+}
+// the batch's totals into the level's scalars (one thread, behind k_dag_scan_sums)
+__global__ void k_dag_account(DagScalars* __restrict__ s, const unsigned long long* __restrict__ total, uint32_t n, unsigned long long extra_dupes) {
+    const uint32_t fresh = uint32_t(*total >> 32), words = uint32_t(*total);
+    s->batch_base = s->size;
+    s->size += words;
+    s->entries += fresh;
+    s->uniques += fresh;
+    s->dupes += (unsigned long long)(n - fresh) + extra_dupes;
+}
+template <bool kNode>
+__global__ void __launch_bounds__(256)
+k_dag_commit(uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const void* __restrict__ cand_, uint32_t n, const unsigned long long* __restrict__ sums,
+             const DagScalars* __restrict__ s, void* __restrict__ raw_, uint32_t raw_capacity, uint32_t* __restrict__ result) {
+    const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
+    const uint32_t base = s->batch_base;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        unsigned long long v[kDagPer], mine = 0;
+        for (uint32_t j = 0; j < kDagPer; j++) {
+            const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
+            v[j] = i < n ? dag_new_value<kNode>(table, pos, static_cast<const uint32_t*>(cand_), i) : 0ull;
+            mine += v[j];
+        }
+        unsigned long long total;
+        uint32_t at = base + uint32_t(sums[c] + dag_block_scan(mine, &total));   // (low field: words before this candidate among the batch's new values)
+        for (uint32_t j = 0; j < kDagPer; j++) {
+            const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
+            if (i >= n) break;
+            if (!v[j]) { result[i] = 0u; continue; }
+            const uint32_t words = uint32_t(v[j]);
+            if (at + words <= raw_capacity) {   // (the host sizes the store for the worst case: always true)
+                if (kNode) {
+                    uint32_t ch[8];
+                    dag_load8(static_cast<const uint32_t*>(cand_) + size_t(i) * 8, ch);
+                    uint32_t* raw = static_cast<uint32_t*>(raw_);
+                    uint32_t mask = 0, w = at + 1;
+                    for (int k = 0; k < 8; k++) if (ch[k]) { mask |= 1u << k; raw[w++] = ch[k]; }
+                    raw[at] = mask;
+                } else static_cast<uint64_t*>(raw_)[at] = static_cast<const uint64_t*>(cand_)[i];
+            }
+            table[pos[i]] = at;
+            result[i] = at;
+            at += words;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_dag_resolve(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, uint32_t n, uint32_t* __restrict__ result) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+        if (!result[i]) result[i] = table[pos[i]];
+}
+
+// ---- the node levels' candidates -------------------------------------------------------------------------------------------
+// level 19 (one node per block that holds leaves, submap.hpp:70-99): the eight cluster addresses of each tree
+__global__ void __launch_bounds__(256)
+k_dag_block_nodes(const uint64_t* __restrict__ tsdf, const uint32_t* __restrict__ vblock, const uint32_t* __restrict__ oct_before, uint32_t nbv, uint32_t saturate,
+                  const uint32_t* __restrict__ cluster_addr, uint32_t* __restrict__ children /* [2 nbv][8] */) {
+    for (size_t r = size_t(blockIdx.x) * blockDim.x + threadIdx.x; r < nbv; r += size_t(gridDim.x) * blockDim.x) {
+        const uint32_t b = vblock[r];
+        uint32_t k = oct_before[r];
+        uint32_t t[8], w[8];
+#pragma unroll
+        for (uint32_t o = 0; o < 8; o++) {
+            const bool there = tsdf[size_t(b) * 8 + o] != kClusterEmpty;
+            t[o] = there ? cluster_addr[dag_cluster_cand_t(k, saturate)] : 0u;
+            w[o] = there ? cluster_addr[dag_cluster_cand_w(k, saturate)] : 0u;
+            k += there ? 1u : 0u;
+        }
+        uint4* out = reinterpret_cast<uint4*>(children + r * 16);
+        out[0] = make_uint4(t[0], t[1], t[2], t[3]); out[1] = make_uint4(t[4], t[5], t[6], t[7]);
+        out[2] = make_uint4(w[0], w[1], w[2], w[3]); out[3] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+// level d from level d + 1: node j of the level below (prefix[j] = its digits 0..d, i.e. its Morton prefix) belongs to the parent
+// prefix[j] >> 3 and sits in child slot prefix[j] & 7.  Heads (first child of a parent) per chunk, then their ranks.
+__global__ void __launch_bounds__(256)
+k_dag_head_sums(const uint64_t* __restrict__ prefix, uint32_t n, unsigned long long* __restrict__ sums) {
+    const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        unsigned long long mine = 0;
+        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j; if (i < n && (i == 0 || (prefix[i] >> 3) != (prefix[i - 1] >> 3))) mine++; }
+        unsigned long long total;
+        dag_block_scan(mine, &total);
+        if (threadIdx.x == 0) sums[c] = total;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_dag_head_apply(const uint64_t* __restrict__ prefix, uint32_t n, const unsigned long long* __restrict__ sums, uint32_t* __restrict__ head_pos /* [parents + 1] */,
+                 uint64_t* __restrict__ parent_prefix, uint32_t parents) {
+    const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
+    if (blockIdx.x == 0 && threadIdx.x == 0) head_pos[parents] = n;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        unsigned long long mine = 0;
+        bool head[kDagPer];
+        for (uint32_t j = 0; j < kDagPer; j++) {
+            const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
+            head[j] = i < n && (i == 0 || (prefix[i] >> 3) != (prefix[i - 1] >> 3));
+            mine += head[j] ? 1u : 0u;
+        }
+        unsigned long long total;
+        uint32_t at = uint32_t(sums[c] + dag_block_scan(mine, &total));
+        for (uint32_t j = 0; j < kDagPer; j++)
+            if (head[j]) {
+                const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
+                if (at < parents) { head_pos[at] = i; parent_prefix[at] = prefix[i] >> 3; }
+                at++;
+            }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_dag_parent_nodes(const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ head_pos, uint32_t parents, const uint32_t* __restrict__ child_addr /* [2 n] */,
+                   uint32_t* __restrict__ children /* [2 parents][8] */) {
+    for (size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x; p < parents; p += size_t(gridDim.x) * blockDim.x) {
+        uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t first = head_pos[p], end = head_pos[p + 1];
+        for (uint32_t j = first; j < end && j < first + 8u; j++) {
+            const uint32_t digit = uint32_t(prefix[j]) & 7u;
+            const uint32_t a = child_addr[2 * size_t(j)], b = child_addr[2 * size_t(j) + 1];
+#pragma unroll
+            for (uint32_t o = 0; o < 8; o++) { t[o] = o == digit ? a : t[o]; w[o] = o == digit ? b : w[o]; }   // (no runtime-indexed registers)
+        }
+        uint4* out = reinterpret_cast<uint4*>(children + p * 16);
+        out[0] = make_uint4(t[0], t[1], t[2], t[3]); out[1] = make_uint4(t[4], t[5], t[6], t[7]);
+        out[2] = make_uint4(w[0], w[1], w[2], w[3]); out[3] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+__global__ void k_dag_block_prefix(const uint64_t* __restrict__ vkeys, uint32_t nbv, uint64_t* __restrict__ prefix) {
+    for (size_t r = size_t(blockIdx.x) * blockDim.x + threadIdx.x; r < nbv; r += size_t(gridDim.x) * blockDim.x) prefix[r] = vkeys[r] >> 6;   // digits 0..18
+}
+
+// ---- table growth ------------------------------------------------------------------------------------------------------------
+template <bool kNode>
+__global__ void __launch_bounds__(256)
+k_dag_rehash(const uint32_t* __restrict__ old_table, uint32_t old_slots, const void* __restrict__ raw_, uint32_t* __restrict__ table, uint32_t mask) {
+    for (size_t s = size_t(blockIdx.x) * blockDim.x + threadIdx.x; s < old_slots; s += size_t(gridDim.x) * blockDim.x) {
+        const uint32_t a = old_table[s];
+        if (!a) continue;
+        uint32_t p;
+        if (kNode) {
+            const uint32_t* raw = static_cast<const uint32_t*>(raw_);
+            uint32_t c[8], at = a + 1;
+            const uint32_t m = raw[a];
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = (m >> k) & 1u ? raw[at++] : 0u;
+            p = dag_hash_children(c) & mask;
+        } else p = dag_hash_cluster(static_cast<const uint64_t*>(raw_)[a]) & mask;
+        while (atomicCAS(&table[p], 0u, a) != 0u) p = (p + 1u) & mask;   // (stored values are distinct: no comparison needed)
+    }
+}
+
+// ==== host side ===============================================================================================================
+struct DeviceDag {
+    DagLevelDev level[kDagDepth + 1];          // [0..19] node levels, [20] the cluster level
+    DagScalars* d_scalars = nullptr;           // [21]
+    DagScalars h_scalars[kDagDepth + 1] = {};  // as of the last fold
+    unsigned long long* d_total = nullptr;     // scan totals: [0] blocks, [1..] per batch
+    uint32_t* d_hist = nullptr;                // [32]
+    uint32_t* h_small = nullptr;               // pinned: what a fold reads back in the middle (block totals, level histogram) and at its end (roots)
+    char* arena = nullptr; size_t arena_cap = 0;
+    bool ready = false;
+
+    void release() {
+        for (auto& l : level) { (void)hipFree(l.table); (void)hipFree(l.raw); l = DagLevelDev{}; }
+        (void)hipFree(d_scalars); (void)hipFree(d_total); (void)hipFree(d_hist); (void)hipFree(arena);
+        if (h_small) (void)hipHostFree(h_small);
+        d_scalars = nullptr; d_total = nullptr; d_hist = nullptr; arena = nullptr; h_small = nullptr; arena_cap = 0; ready = false;
+        for (auto& s : h_scalars) s = DagScalars{};
+    }
+};
+
+inline dim3 dag_grid(size_t n, uint32_t per = 256, uint32_t cap = 2048) { return dim3(unsigned(std::max<size_t>(1, std::min<size_t>(cap, (n + per - 1) / per)))); }
+
+inline hipError_t dag_device_init(DeviceDag& d, hipStream_t s) {
+    if (d.ready) return hipSuccess;
+    hipError_t e;
+    if ((e = hipMalloc(&d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1))) != hipSuccess) return e;
+    if ((e = hipMalloc(&d.d_total, 8 * 64)) != hipSuccess) return e;
+    if ((e = hipMalloc(&d.d_hist, 4 * 32)) != hipSuccess) return e;
+    if ((e = hipHostMalloc(&d.h_small, 4096)) != hipSuccess) return e;
+    for (uint32_t l = 0; l <= kDagDepth; l++) {
+        DagLevelDev& L = d.level[l];
+        L.table_slots = 1024; L.raw_capacity = 1024;
+        if ((e = hipMalloc(&L.table, size_t(L.table_slots) * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4))) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(L.table, 0, size_t(L.table_slots) * 4, s)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(L.raw, 0, l == kDagDepth ? 8 : 4, s)) != hipSuccess) return e;   // address 0: the reserved word (levels.hpp:52, :118)
+        d.h_scalars[l] = DagScalars{};
+        d.h_scalars[l].size = 1;
+    }
+    if ((e = hipMemcpyAsync(d.d_scalars, d.h_scalars, sizeof(d.h_scalars), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;   // (h_scalars is the source of an asynchronous copy)
+    d.ready = true;
+    return hipSuccess;
+}
+
+// room in level l for `n` more candidates of at most `words_each` words: the table stays at most half full, the store never overflows
+inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t words_each, hipStream_t s) {
+    DagLevelDev& L = d.level[l];
+    const bool cluster = l == kDagDepth;
+    const size_t need_slots = 2 * (size_t(d.h_scalars[l].entries) + n) + 16;
+    hipError_t e;
+    if (need_slots > L.table_slots) {
+        size_t slots = L.table_slots;
+        while (slots < need_slots) slots <<= 1;
+        if (slots > (size_t(1) << 31)) return hipErrorOutOfMemory;
+        uint32_t* bigger = nullptr;
+        if ((e = hipMalloc(&bigger, slots * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(bigger, 0, slots * 4, s)) != hipSuccess) { (void)hipFree(bigger); return e; }
+        if (cluster) hipLaunchKernelGGL(k_dag_rehash<false>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
+        else hipLaunchKernelGGL(k_dag_rehash<true>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipFree(bigger); return e; }
+        (void)hipFree(L.table);
+        L.table = bigger; L.table_slots = uint32_t(slots);
+    }
+    const size_t need_words = size_t(d.h_scalars[l].size) + n * words_each + 16;
+    if (need_words > L.raw_capacity) {
+        size_t words = L.raw_capacity;
+        while (words < need_words) words += words / 2 + 1024;
+        if (need_words >= (size_t(1) << 31)) return hipErrorOutOfMemory;   // addresses are 31 bits here (the top bit marks a pending table slot)
+        words = std::min<size_t>(words, (size_t(1) << 31) - 1);
+        const size_t unit = cluster ? 8 : 4;
+        void* bigger = nullptr;
+        if ((e = hipMalloc(&bigger, words * unit)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(bigger, L.raw, size_t(d.h_scalars[l].size) * unit, hipMemcpyDeviceToDevice, s)) != hipSuccess) { (void)hipFree(bigger); return e; }
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipFree(bigger); return e; }
+        (void)hipFree(L.raw);
+        L.raw = bigger; L.raw_capacity = uint32_t(words);
+    }
+    return hipSuccess;
+}
+
+// One batch on level l: candidates `cand` (n rows of eight child addresses, or n cluster words) -> result[i] = address of candidate i's value.
+inline void dag_batch(DeviceDag& d, uint32_t l, const void* cand, uint32_t n, uint32_t* pos, uint32_t* result, unsigned long long* sums, unsigned long long* total,
+                      unsigned long long extra_dupes, hipStream_t s) {
+    DagLevelDev& L = d.level[l];
+    const uint32_t mask = L.table_slots - 1, chunks = (n + kDagChunk - 1) / kDagChunk;
+    const dim3 flat = dag_grid(n), chunked = dim3(std::max(1u, std::min(chunks, 2048u)));
+    if (l == kDagDepth) {
+        if (n) hipLaunchKernelGGL(k_dag_probe<false>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, pos);
+        if (n) hipLaunchKernelGGL(k_dag_new_sums<false>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(nullptr), n, sums);
+    } else {
+        if (n) hipLaunchKernelGGL(k_dag_probe<true>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, pos);
+        if (n) hipLaunchKernelGGL(k_dag_new_sums<true>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(cand), n, sums);
+    }
+    hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, total);
+    hipLaunchKernelGGL(k_dag_account, dim3(1), dim3(1), 0, s, d.d_scalars + l, total, n, extra_dupes);
+    if (!n) return;
+    if (l == kDagDepth) hipLaunchKernelGGL(k_dag_commit<false>, chunked, dim3(256), 0, s, L.table, pos, cand, n, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
+    else hipLaunchKernelGGL(k_dag_commit<true>, chunked, dim3(256), 0, s, L.table, pos, cand, n, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
+    hipLaunchKernelGGL(k_dag_resolve, flat, dim3(256), 0, s, L.table, pos, n, result);
+}
+
+// Fold one submap: keys[nb] ascending block keys, tsdf[8 nb] / weight[8 nb] (null: the reference's all-ones weights) cluster words, all
+// on the device.  Synchronises the stream twice (block totals + per-level node counts in the middle, roots + scalars at the end).
+inline hipError_t dag_device_add_submap(DeviceDag& d, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, uint32_t nb, hipStream_t s,
+                                        uint32_t* root_tsdf, uint32_t* root_weight) {
+    hipError_t e;
+    if ((e = dag_device_init(d, s)) != hipSuccess) return e;
+    const uint32_t saturate = weight ? 1u : 0u;
+    const size_t cc_ub = saturate ? size_t(16) * nb : size_t(8) * nb + 2;       // cluster candidates at most
+    const size_t chunks_ub = (std::max<size_t>(cc_ub, 2 * size_t(nb) + 2) + kDagChunk - 1) / kDagChunk + 1;
+    auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+    const size_t nbp = size_t(nb) + 1;
+    const size_t need = padded(nbp * 8) + 2 * padded(nbp * 4) + padded(cc_ub * 8) + 2 * padded(cc_ub * 4) + padded(chunks_ub * 8) +
+                        2 * (padded(nbp * 8) + padded(nbp * 64) + 2 * padded(nbp * 8) + padded((nbp + 1) * 4));
+    if (need > d.arena_cap) {
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        (void)hipFree(d.arena); d.arena = nullptr; d.arena_cap = 0;
+        if ((e = hipMalloc(&d.arena, need + need / 4)) != hipSuccess) return e;
+        d.arena_cap = need + need / 4;
+    }
+    size_t used = 0;
+    auto take = [&](size_t bytes) { void* p = d.arena + used; used += padded(bytes); return p; };
+    uint64_t* vkeys = static_cast<uint64_t*>(take(nbp * 8));
+    uint32_t* vblock = static_cast<uint32_t*>(take(nbp * 4));
+    uint32_t* oct_before = static_cast<uint32_t*>(take(nbp * 4));
+    uint64_t* ccand = static_cast<uint64_t*>(take(cc_ub * 8));
+    uint32_t* cpos = static_cast<uint32_t*>(take(cc_ub * 4));
+    uint32_t* caddr = static_cast<uint32_t*>(take(cc_ub * 4));
+    unsigned long long* sums = static_cast<unsigned long long*>(take(chunks_ub * 8));
+    struct LevelScratch { uint64_t* prefix; uint32_t* children; uint32_t* pos; uint32_t* addr; uint32_t* head_pos; } ls[2];
+    for (auto& x : ls) {
+        x.prefix = static_cast<uint64_t*>(take(nbp * 8)); x.children = static_cast<uint32_t*>(take(nbp * 64));
+        x.pos = static_cast<uint32_t*>(take(nbp * 8)); x.addr = static_cast<uint32_t*>(take(nbp * 8)); x.head_pos = static_cast<uint32_t*>(take((nbp + 1) * 4));
+    }
+
+    // step 0: the blocks that hold leaves, the cluster candidates, the number of nodes per level
+    const uint32_t bchunks = (nb + kDagChunk - 1) / kDagChunk;
+    uint32_t nbv = 0, octets = 0;
+    uint32_t level_nodes[kDagDepth] = {};
+    if (nb) {
+        hipLaunchKernelGGL(k_dag_block_sums, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, tsdf, nb, sums);
+        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, bchunks, d.d_total);
+        hipLaunchKernelGGL(k_dag_block_apply, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, keys, tsdf, weight, nb, saturate, sums, vkeys, vblock, oct_before, ccand);
+        if ((e = hipMemsetAsync(d.d_hist, 0, 128, s)) != hipSuccess) return e;
+        // (the histogram needs the number of valid blocks: it is at most nb, and entries beyond it are never written -- so count over vkeys
+        //  only after the total is known: one small round trip, which also gives every later launch its exact size)
+        if ((e = hipMemcpyAsync(d.h_small, d.d_total, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        const unsigned long long t = *reinterpret_cast<unsigned long long*>(d.h_small);
+        nbv = uint32_t(t >> 32); octets = uint32_t(t);
+    }
+    if (nbv) {
+        hipLaunchKernelGGL(k_dag_parted_histogram, dag_grid(nbv, 256, 1024), dim3(256), 0, s, vkeys, nbv, d.d_hist);
+        if ((e = hipMemcpyAsync(d.h_small + 16, d.d_hist, 128, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    }
+    // the cluster level meanwhile (its size is known)
+    const uint32_t ncc = octets ? (saturate ? 2u * octets : octets + 1u) : 0u;
+    if ((e = dag_level_reserve(d, kDagDepth, ncc, 1, s)) != hipSuccess) return e;
+    if (ncc) dag_batch(d, kDagDepth, ccand, ncc, cpos, caddr, sums, d.d_total + 1, saturate ? 0ull : (unsigned long long)(octets - 1u), s);
+    if (nbv) {
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        uint32_t running = 1;   // n_d = 1 + #{blocks that part from their predecessor at a depth below d}
+        for (uint32_t dd = 0; dd < kDagDepth; dd++) { level_nodes[dd] = running; running += d.h_small[16 + dd]; }
+    }
+    // level 19, then upwards
+    uint32_t cur = 0;
+    if (nbv) {
+        hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, tsdf, vblock, oct_before, nbv, saturate, caddr, ls[cur].children);
+        hipLaunchKernelGGL(k_dag_block_prefix, dag_grid(nbv), dim3(256), 0, s, vkeys, nbv, ls[cur].prefix);
+        if ((e = dag_level_reserve(d, kDagDepth - 1, 2 * size_t(nbv), 9, s)) != hipSuccess) return e;
+        dag_batch(d, kDagDepth - 1, ls[cur].children, 2 * nbv, ls[cur].pos, ls[cur].addr, sums, d.d_total + 2, 0ull, s);
+    }
+    uint32_t n_below = nbv;
+    for (int dd = int(kDagDepth) - 2; dd >= 0; dd--) {
+        const uint32_t parents = nbv ? level_nodes[dd] : (dd == 0 ? 1u : 0u);   // an empty octree still yields a childless root pair (submap.hpp:29-44)
+        LevelScratch& below = ls[cur];
+        LevelScratch& here = ls[cur ^ 1];
+        if (parents) {
+            if (n_below) {
+                const uint32_t chunks = (n_below + kDagChunk - 1) / kDagChunk;
+                hipLaunchKernelGGL(k_dag_head_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums);
+                hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, d.d_total + 3);
+                hipLaunchKernelGGL(k_dag_head_apply, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums, here.head_pos, here.prefix, parents);
+                hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents, below.addr, here.children);
+            } else if ((e = hipMemsetAsync(here.children, 0, 64, s)) != hipSuccess) return e;   // the childless root pair
+            if ((e = dag_level_reserve(d, uint32_t(dd), 2 * size_t(parents), 9, s)) != hipSuccess) return e;
+            dag_batch(d, uint32_t(dd), here.children, 2 * parents, here.pos, here.addr, sums, d.d_total + 4, 0ull, s);
+        }
+        n_below = parents;
+        cur ^= 1;
+    }
+    // roots and the levels' scalars
+    if ((e = hipMemcpyAsync(d.h_small + 64, ls[cur].addr, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d.h_small + 128, d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    *root_tsdf = d.h_small[64]; *root_weight = d.h_small[65];
+    std::memcpy(d.h_scalars, d.h_small + 128, sizeof(d.h_scalars));
+    return hipSuccess;
+}
+
+// The host's mirror of the stores (what dag_walk / DagCursor / chad_map_dag_level_copy read): the words added since the last call.
+inline hipError_t dag_device_mirror(DeviceDag& d, Dag& host, hipStream_t s) {
+    if (!d.ready) return hipSuccess;
+    hipError_t e;
+    for (uint32_t l = 0; l <= kDagDepth; l++) {
+        const size_t size = d.h_scalars[l].size;
+        if (l == kDagDepth) {
+            const size_t have = host.clusters.raw.size();
+            if (have < size) { host.clusters.raw.resize(size); if ((e = hipMemcpyAsync(host.clusters.raw.data() + have, static_cast<uint64_t*>(d.level[l].raw) + have, (size - have) * 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e; }
+            host.clusters.uniques = uint32_t(d.h_scalars[l].uniques); host.clusters.dupes = uint32_t(d.h_scalars[l].dupes);
+        } else {
+            const size_t have = host.nodes[l].raw.size();
+            if (have < size) { host.nodes[l].raw.resize(size); if ((e = hipMemcpyAsync(host.nodes[l].raw.data() + have, static_cast<uint32_t*>(d.level[l].raw) + have, (size - have) * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e; }
+            host.nodes[l].uniques = uint32_t(d.h_scalars[l].uniques); host.nodes[l].dupes = uint32_t(d.h_scalars[l].dupes);
+        }
+    }
+    return hipStreamSynchronize(s);
+}
+
+}  // namespace chadhip
