@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--backend", default="auto", help="exchange transport for N > 1: nccl (= RCCL), gloo (only to rehearse several ranks on one GPU), auto")
     ap.add_argument("--stream-frames", type=int, default=500, help="frames of the cfg3 / cfg4 stream leg (0 = skip)")
-    ap.add_argument("--outdoor-frames", type=int, default=33, help="frames of the cfg5 leg (0 = skip)")
+    ap.add_argument("--outdoor-frames", type=int, default=5000, help="frames of the cfg5 leg: BASELINE config 5's trajectory (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's line (no cfg3/4/5, pcie, per-kernel and large-frame legs)")
     return ap.parse_args()
 
@@ -119,7 +119,7 @@ def main():
     workers = min(8, cpu_share)
     stream_idx = list(range(rank, args.stream_frames, world)) if extras else []
     stream_frames = make_frames("cfg3", stream_idx, workers)
-    outdoor_frames = make_frames("cfg5", list(range(args.outdoor_frames)), workers) if extras and rank == 0 and world == 1 else {}
+    outdoor = extras and rank == 0 and world == 1 and args.outdoor_frames > 0   # (its frames are made on the device, below)
     res, trunc = synth.CFG2["res"], synth.CFG2["trunc"]
     host_scans = []
     for j in range(args.frames):
@@ -388,36 +388,61 @@ def main():
         del dev
         out["cfg4" if world > 1 else "cfg3"] = leg
 
-    # ---- cfg5's shape on one GPU ---------------------------------------------------------------------------------------
-    if outdoor_frames:
+    # ---- cfg5: BASELINE config 5's trajectory on one GPU -------------------------------------------------------------------
+    if outdoor:
         c5 = synth.CFG5
-        dev = [torch.from_numpy(outdoor_frames[k][0]).cuda() for k in range(args.outdoor_frames)]
+        n5 = args.outdoor_frames
+        # frames made on the device by the generator's torch twin (bit for bit the numpy frames: tests/test_gpu_streams.py), resident
+        # before the clock starts: 5 000 x 2.4 MB
+        dev = [synth.cfg5_frame_torch(k) for k in range(n5)]
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
-        # the map at the size this trajectory needs (2^22 blocks: no table doubling inside the timed region) and its spare table made
-        # by a roll-over in the warm-up: multi-GB hipMalloc / hipFree calls take anything from 2 to 200 ms depending on the box
-        m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22)
-        m5.insert(dev[0], outdoor_frames[0][1], ready=True)
-        v5 = len(m5.export_leaves()[0])   # distinct voxels one frame touches (into an empty map)
-        m5.close_submap(); m5.sync()
-        m5.reset(); m5.sync(); m5.stats()
-        t1 = time.perf_counter()
-        for k in range(args.outdoor_frames):
-            m5.insert(dev[k], outdoor_frames[k][1], ready=True)
-        m5.sync()
-        t5 = time.perf_counter() - t1
+
+        def run_cfg5(frames_n, dag_only):
+            # the map at the size this trajectory needs (2^22 blocks: no table doubling inside the timed region); its spare table and the
+            # DAG's first allocations are made by the warm-up: multi-GB hipMalloc / hipFree calls take 2 to 200 ms depending on the box
+            m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22, dag_only=dag_only)
+            for k in range(min(12, frames_n)):
+                m5.insert(dev[k][0], dev[k][1], ready=True)
+            m5.sync()
+            if dag_only:
+                m5.finalize()
+            m5.reset(); m5.sync(); m5.stats()
+            t1 = time.perf_counter()
+            for k in range(frames_n):
+                m5.insert(dev[k][0], dev[k][1], ready=True)
+            t_host = time.perf_counter() - t1
+            m5.sync()
+            if dag_only:
+                m5.finalize()   # every closed submap is in the DAG when the clock stops (the reference finalizes at the roll-over: tsdf.cpp:53)
+            t5 = time.perf_counter() - t1
+            return m5, t5, t_host
+
+        m5, t5, t5_host = run_cfg5(n5, True)
         s5 = m5.stats()
+        ds5 = m5.dag_stats()
         held = free0 - torch.cuda.mem_get_info()[0]
+        m1 = TSDFMap(c5["res"], c5["trunc"], max_points=c5["n"], max_blocks=1 << 22)
+        m1.insert(dev[0][0], dev[0][1], ready=True)
+        v5 = len(m1.export_leaves()[0])   # distinct voxels one frame touches (into an empty map)
+        m1.close()
         b5 = 24 * c5["n"] + 16 * v5
         u5 = float(s5["ms_oct_upd"])
-        out["cfg5"] = {"workload": f"{args.outdoor_frames} frames x {c5['n']} points, 40x40x11.5 m box sliding with the sensor (0.5 m per frame, roll-over every 11 frames), voxel 0.02 m, trunc 0.06 m; table pre-sized to 2^22 blocks",
-                       "ms_per_frame": round(t5 / args.outdoor_frames * 1e3, 4), "points_per_s": round(args.outdoor_frames * c5["n"] / t5),
+        out["cfg5"] = {"workload": f"{n5} frames x {c5['n']} points, 40x40x11.5 m box sliding with the sensor (0.5 m per frame, roll-over every 11 frames), voxel 0.02 m, trunc 0.06 m; "
+                                   "closed submaps kept as their DAG only (CHAD_FLAG_DAG_ONLY: the reference's policy), Submap::finalize on the device inside the timed region; "
+                                   "table pre-sized to 2^22 blocks",
+                       "frames": n5, "ms_per_frame": round(t5 / n5 * 1e3, 4), "points_per_s": round(n5 * c5["n"] / t5), "host_enqueue_ms_per_frame": round(t5_host / n5 * 1e3, 4),
                        "update_kernel_ms": round(u5, 4), "update_algorithmic_bytes": b5, "update_GBps": round(b5 / u5 / 1e6, 1) if u5 > 0 else None,
                        "update_frac": round(b5 / u5 / 1e6 / HBM_PEAK_GBS, 5) if u5 > 0 else None, "voxels_per_frame": v5,
                        "live_blocks": int(s5["blocks"]), "block_capacity": int(s5["block_capacity"]), "closed_submaps": int(s5["closed_submaps"]),
                        "hash_load": round(s5["blocks"] / s5["hash_capacity"], 5), "table_bytes": int(s5["hash_capacity"]) * (8 + 512 + 256 + 512) + int(s5["hash_capacity"]) // 8,
-                       "hbm_held_bytes": int(held), "overflow": int(s5["overflow"])}
+                       "hbm_held_bytes": int(held), "dag_device_bytes": int(ds5["device_bytes"]), "dag_unique_clusters": int(ds5["uniques"][20]),
+                       "overflow": int(s5["overflow"])}
         m5.close()
+        # the same frames with the dense archives kept (the library's default; rounds 1-3 quoted this leg): 33 frames, three roll-overs
+        mk5, tk, _ = run_cfg5(min(33, n5), False)
+        out["cfg5"]["archives_kept_33_frames_ms_per_frame"] = round(tk / min(33, n5) * 1e3, 4)
+        mk5.close()
         del dev
 
     # ---- the row behind the path and the CPU baseline, outside every timed region ---------------------

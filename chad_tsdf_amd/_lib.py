@@ -78,6 +78,7 @@ class DagStats(C.Structure):
         ("dupes", C.c_uint32 * 21),
         ("ms_device", C.c_float),
         ("ms_host", C.c_float),
+        ("device_bytes", C.c_uint64),
     ]
 
 
@@ -126,6 +127,7 @@ SYMBOLS = {
     "chad_map_query_sd_device": (_i32, [_vp, _vp, _sz, _i32, _vp, _vp]),
     "chad_map_raycast": (_i32, [_vp, _vp, _vp, _sz, _f32, _vp]),
     "chad_map_mesh": (_i32, [_vp, _i32, _vp, _sz, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "chad_map_mesh_cells": (_i32, [_vp, _i32, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_save_mesh": (_i32, [_vp, _i32, C.c_char_p]),
     "chad_map_submap_positions": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_set_submap_pose": (_i32, [_vp, _i32, _vp, _vp]),

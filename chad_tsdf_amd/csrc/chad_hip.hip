@@ -63,6 +63,7 @@ struct Submap {  // a closed submap: dense copies of its bricks (stands in for t
     uint32_t* cnt = nullptr;
     uint32_t blocks = 0;
     bool released = false;  // CHAD_FLAG_DAG_ONLY: folded into the DAG, the dense copy given back
+    bool borrowed = false;  // its arrays are carved out of chad_map::archive_arena (CHAD_FLAG_DAG_ONLY: the copy lives from the roll-over to the fold), not allocations of their own
 };
 
 struct DevBuf {   // device allocation released on every exit path
@@ -222,6 +223,8 @@ struct chad_map {
     hipEvent_t merge_event = nullptr;             // behind the device-to-host copy of the current stage's numbers
     uint64_t* merge_host = nullptr;               // pinned: [0..15] blocks per rank, [16] blocks in the union, [17] this rank's count (source of an H2D copy)
     Arena merge_a, merge_b, merge_c;              // scratch of the three stages
+    Arena archive_arena;                          // CHAD_FLAG_DAG_ONLY: the closing submap's dense copy, from its roll-over to its fold (borrow_submap)
+    Arena cluster_arena;                          // the cluster words of the submap being folded (device_cluster_words)
     uint32_t merge_blocks = 0;                    // this rank's blocks
     uint64_t* merge_keys = nullptr; long long* merge_sum = nullptr; uint32_t* merge_cnt = nullptr;   // ... compacted raw (arena a)
     uint64_t merge_total = 0;                     // blocks over all ranks
@@ -439,8 +442,20 @@ chad_status finalize_closed(chad_map* m);  // (further down, with the rest of Su
 chad_status ensure_aux_sort(chad_map* m, size_t n);
 
 void free_submap(Submap& s) {
-    (void)hipFree(s.keys); (void)hipFree(s.sum); (void)hipFree(s.cnt);
+    if (!s.borrowed) { (void)hipFree(s.keys); (void)hipFree(s.sum); (void)hipFree(s.cnt); }
     s = Submap{};
+}
+
+// A closed submap's dense copy under CHAD_FLAG_DAG_ONLY lives only until it has been folded into the DAG, a moment later: it is
+// carved out of a grow-only arena instead of being allocated and freed (hipMalloc / hipFree of hundreds of MB stall the whole
+// device, once per roll-over: every eleven frames in BASELINE config 5).
+chad_status borrow_submap(chad_map* m, Submap& s, uint32_t blocks) {
+    s.blocks = blocks; s.borrowed = true;
+    const size_t nb = std::max<uint32_t>(blocks, 1);
+    if (Arena::padded(nb * 8) + 2 * Arena::padded(nb * 256) > m->archive_arena.cap) HIP_TRY(hipStreamSynchronize(m->stream));   // (the arena is about to move)
+    HIP_TRY(m->archive_arena.reserve(Arena::padded(nb * 8) + 2 * Arena::padded(nb * 256)));
+    s.keys = m->archive_arena.take<uint64_t>(nb); s.sum = m->archive_arena.take<float>(nb * 64); s.cnt = m->archive_arena.take<uint32_t>(nb * 64);
+    return CHAD_OK;
 }
 
 chad_status alloc_submap(Submap& s, uint32_t blocks) {
@@ -488,7 +503,7 @@ chad_status finish_closing(chad_map* m, bool block) {
     uint32_t blocks = 0;
     for (uint32_t k = 0; k < kCountStripes; k++) blocks += m->closing_count[k * 16];
     Submap s;
-    TRY(alloc_submap(s, blocks));
+    if (m->flags & CHAD_FLAG_DAG_ONLY) TRY(borrow_submap(m, s, blocks)); else TRY(alloc_submap(s, blocks));
     if (blocks) {
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
         hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
@@ -1148,7 +1163,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
 
     uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
     if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
-    CREATE_TRY(hipMalloc(&m->d_overflow, 64));
+    CREATE_TRY(hipMalloc(&m->d_overflow, 64));   // 16 words: [0] sort faults, [1..7] the tables' flags, [8] staging-word launches, [9..15] the tables' clear counters
     CREATE_TRY(hipMemsetAsync(m->d_overflow, 0, 64, m->stream));
     if (alloc_map_storage(m, m->view, blocks, m->stream) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     m->brick_capacity = m->view.brick_capacity; m->hash_capacity = m->view.hash_mask + 1;
@@ -1248,7 +1263,7 @@ void chad_map_destroy(chad_map* m) {
     if (m->producer_ready) (void)hipEventDestroy(m->producer_ready);
     if (m->merge_event) (void)hipEventDestroy(m->merge_event);
     if (m->merge_host) (void)hipHostFree(m->merge_host);
-    m->merge_a.release(); m->merge_b.release(); m->merge_c.release();
+    m->merge_a.release(); m->merge_b.release(); m->merge_c.release(); m->archive_arena.release(); m->cluster_arena.release();
     if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
     free_sort_buffers(m->aux_sort);
     m->ddag.release();
@@ -1357,7 +1372,7 @@ chad_status read_back_header(chad_map* m, uint32_t* overflow) {
     uint32_t words[8];
     HIP_TRY(hipMemcpy(words, m->d_overflow, sizeof(words), hipMemcpyDeviceToHost));
     *overflow = words[0];
-    for (uint32_t w = 1; w < 8; w++) if ((m->overflow_words_used >> w) & 1u) *overflow |= words[w];
+    for (uint32_t w = 1; w < 8; w++) if ((m->overflow_words_used >> w) & 1u) *overflow |= words[w] & kTableOverflowed;   // (bit 2 of a table's word: its exact rows are in use)
     return CHAD_OK;
 }
 
@@ -1663,15 +1678,16 @@ struct HostClusters { std::vector<uint64_t> keys, tsdf, weight; };
 
 // Device half: the bricks of a dense submap, ordered by block key, as eight cluster words each -- left on the device in `out`
 // (keys [nb], then tsdf [8 nb], then weight [8 nb] if wanted); `ms`: device time from here to `done` being recorded.
-struct DeviceClusters {
-    DevBuf out;
+struct DeviceClusters {   // (in chad_map::cluster_arena: valid until the next call)
     uint64_t* keys = nullptr; uint64_t* tsdf = nullptr; uint64_t* weight = nullptr;
 };
 chad_status device_cluster_words(chad_map* m, const uint64_t* keys, const float* sum, const uint32_t* cnt, uint32_t nb, bool want_weights, DeviceClusters& dc) {
     if (!nb) return CHAD_OK;
     TRY(ensure_aux_sort(m, nb));
-    HIP_TRY(dc.out.alloc(size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))));
-    uint64_t* d_out = dc.out.as<uint64_t>();
+    const size_t need = Arena::padded(size_t(nb) * (8 + 64 + (want_weights ? 64 : 0)));
+    if (need > m->cluster_arena.cap) HIP_TRY(hipStreamSynchronize(m->stream));   // (the arena is about to move: nobody may still be reading the old one)
+    HIP_TRY(m->cluster_arena.reserve(need));
+    uint64_t* d_out = m->cluster_arena.take<uint64_t>(need / 8 - 32);
     dc.keys = d_out; dc.tsdf = d_out + nb; dc.weight = want_weights ? dc.tsdf + size_t(nb) * 8 : nullptr;
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
     RadixSortSignals sig;
@@ -1808,6 +1824,8 @@ chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
         out->uniques[kDagDepth] = m->dag.clusters.uniques; out->dupes[kDagDepth] = m->dag.clusters.dupes;
     }
     out->ms_device = m->dag_ms_device; out->ms_host = m->dag_ms_host;
+    out->device_bytes = m->ddag.arena_cap;
+    for (uint32_t l = 0; l <= kDagDepth && m->ddag.ready; l++) out->device_bytes += size_t(m->ddag.level[l].table_slots) * 4 + size_t(m->ddag.level[l].raw_capacity) * (l == kDagDepth ? 8 : 4);
     return CHAD_OK;
 }
 
@@ -2127,6 +2145,35 @@ chad_status chad_map_mesh(chad_map* m, int32_t submap, float* vertices, size_t v
     }
     if (triangles && triangle_capacity >= *triangle_count) std::memcpy(triangles, m->mesh_triangles.data(), m->mesh_triangles.size() * 4);
     if ((vertices && vertex_capacity < *vertex_count) || (triangles && triangle_capacity < *triangle_count)) return fail(CHAD_ERR_INVALID_ARG, "mesh buffers too small");
+    return CHAD_OK;
+}
+
+chad_status chad_map_mesh_cells(chad_map* m, int32_t submap, uint64_t* codes, float* corners, size_t capacity, size_t* count) {
+    if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    DevBuf keys, means;
+    uint32_t nb = 0;
+    TRY(mesh_source(m, submap, keys, means, &nb));
+    *count = 0;
+    if (!nb) return CHAD_OK;
+    DevBuf counts, d_total;
+    HIP_TRY(counts.alloc(size_t(nb) * 4)); HIP_TRY(d_total.alloc(4));
+    hipLaunchKernelGGL((k_mesh_cells<false>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, counts.as<uint32_t>(), (uint64_t*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, m->stream, counts.as<uint32_t>(), nb, d_total.as<uint32_t>());
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_total.p, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    *count = total;
+    if (!codes && !corners) return CHAD_OK;
+    if (capacity < total || !codes || !corners) return fail(CHAD_ERR_INVALID_ARG, "cell buffers too small");
+    if (!total) return CHAD_OK;
+    DevBuf d_codes, d_corners;
+    HIP_TRY(d_codes.alloc(size_t(total) * 8)); HIP_TRY(d_corners.alloc(size_t(total) * 32));
+    hipLaunchKernelGGL((k_mesh_cells<true>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, counts.as<uint32_t>(), d_codes.as<uint64_t>(), d_corners.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(codes, d_codes.p, size_t(total) * 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(corners, d_corners.p, size_t(total) * 32, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
     return CHAD_OK;
 }
 

@@ -9,7 +9,8 @@
 // store if the value is already there from an earlier submap, else new, with new addresses handed out in sequence order.
 //   1. probe: every candidate looks its value up in the level's open-addressed table (u32 slots: 0 free, else the address of a
 //      stored value, compared by CONTENT, never by hash alone).  A candidate that reaches a free slot claims it with
-//      kDagPending | its index; a candidate that meets a pending slot of equal content lowers the index (atomicMin): after the
+//      (the store's size before the batch) + its index -- a number no stored value's address can be, so addresses keep all 32 bits,
+//      as in the reference -- and a candidate that meets a pending slot of equal content lowers the index (atomicMin): after the
 //      pass every slot claimed in this batch names the batch's FIRST candidate of that content.
 //   2. the candidates that own their slot are the level's new values: an exclusive scan of their word counts in sequence order
 //      gives their addresses behind the store's end -- the order of first occurrence, as the reference hands them out;
@@ -30,7 +31,7 @@
 
 namespace chadhip {
 
-constexpr uint32_t kDagPending = 0x80000000u;   // table slot: claimed during the current batch by candidate (slot & ~kDagPending)
+// (a table slot >= the store's size at the start of the batch is pending: claimed during the batch by candidate slot - size)
 constexpr uint32_t kDagChunk = 2048;            // candidates per workgroup step: 256 threads x 8 CONSECUTIVE candidates (sequence order matters)
 constexpr uint32_t kDagPer = kDagChunk / 256;
 constexpr uint32_t kDagNone = 0xffffffffu;
@@ -179,14 +180,16 @@ k_dag_parted_histogram(const uint64_t* __restrict__ vkeys, uint32_t nbv, uint32_
 // kNode: candidates are rows of eight child addresses (0 = no child); else 64-bit cluster words.
 template <bool kNode>
 __global__ void __launch_bounds__(256)
-k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict__ raw_, const void* __restrict__ cand_, uint32_t n, uint32_t* __restrict__ pos) {
+k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict__ raw_, const void* __restrict__ cand_, uint32_t n, const DagScalars* __restrict__ scalars,
+            uint32_t* __restrict__ pos) {
+    const uint32_t base = scalars->size;   // addresses below it are stored values; base + i marks a slot claimed by candidate i of this batch
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         uint32_t mine[8];
         uint64_t value = 0;
         uint32_t p;
         if (kNode) { dag_load8(static_cast<const uint32_t*>(cand_) + i * 8, mine); p = dag_hash_children(mine) & mask; }
         else { value = static_cast<const uint64_t*>(cand_)[i]; p = dag_hash_cluster(value) & mask; }
-        const uint32_t me = kDagPending | uint32_t(i);
+        const uint32_t me = base + uint32_t(i);
         for (;; p = (p + 1u) & mask) {
             uint32_t v = __hip_atomic_load(&table[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v == 0u) {
@@ -194,8 +197,8 @@ k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict_
                 if (v == 0u) break;   // claimed
             }
             bool same;
-            if (v & kDagPending) {   // claimed in this batch by candidate j: the same value?
-                const size_t j = v & ~kDagPending;
+            if (v >= base) {   // claimed in this batch by candidate j: the same value?
+                const size_t j = v - base;
                 if (kNode) {
                     uint32_t other[8];
                     dag_load8(static_cast<const uint32_t*>(cand_) + j * 8, other);
@@ -210,20 +213,29 @@ k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict_
         pos[i] = p;
     }
 }
+// words candidate i adds to the store: 0 unless it owns its slot (the first candidate of a value the store does not hold yet)
 template <bool kNode>
-__device__ __forceinline__ unsigned long long dag_new_value(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t i) {
-    if (table[pos[i]] != (kDagPending | i)) return 0ull;   // [new values : 32 | their words : 32]
+__device__ __forceinline__ uint32_t dag_new_words(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t base, uint32_t i) {
+    if (table[pos[i]] != base + i) return 0u;
     uint32_t words = 1;
     if (kNode) { uint32_t c[8]; dag_load8(cand + size_t(i) * 8, c); for (int k = 0; k < 8; k++) words += c[k] ? 1u : 0u; }
-    return (1ull << 32) | words;
+    return words;
 }
 template <bool kNode>
 __global__ void __launch_bounds__(256)
-k_dag_new_sums(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t n, unsigned long long* __restrict__ sums) {
+k_dag_new_sums(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t n, const DagScalars* __restrict__ scalars,
+               uint8_t* __restrict__ new_words, unsigned long long* __restrict__ sums) {
     const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
+    const uint32_t base = scalars->size;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        unsigned long long mine = 0;
-        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j; if (i < n) mine += dag_new_value<kNode>(table, pos, cand, i); }
+        unsigned long long mine = 0;   // [new values : 32 | their words : 32]
+        for (uint32_t j = 0; j < kDagPer; j++) {
+            const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
+            if (i >= n) break;
+            const uint32_t w = dag_new_words<kNode>(table, pos, cand, base, i);
+            new_words[i] = uint8_t(w);   // (kept: once values are committed a slot no longer tells who owned it)
+            mine += w ? (1ull << 32) | w : 0ull;
+        }
         unsigned long long total;
         dag_block_scan(mine, &total);
         if (threadIdx.x == 0) sums[c] = total;
@@ -240,15 +252,15 @@ __global__ void k_dag_account(DagScalars* __restrict__ s, const unsigned long lo
 }
 template <bool kNode>
 __global__ void __launch_bounds__(256)
-k_dag_commit(uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const void* __restrict__ cand_, uint32_t n, const unsigned long long* __restrict__ sums,
-             const DagScalars* __restrict__ s, void* __restrict__ raw_, uint32_t raw_capacity, uint32_t* __restrict__ result) {
+k_dag_commit(uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const void* __restrict__ cand_, uint32_t n, const uint8_t* __restrict__ new_words,
+             const unsigned long long* __restrict__ sums, const DagScalars* __restrict__ s, void* __restrict__ raw_, uint32_t raw_capacity, uint32_t* __restrict__ result) {
     const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
     const uint32_t base = s->batch_base;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         unsigned long long v[kDagPer], mine = 0;
         for (uint32_t j = 0; j < kDagPer; j++) {
             const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
-            v[j] = i < n ? dag_new_value<kNode>(table, pos, static_cast<const uint32_t*>(cand_), i) : 0ull;
+            v[j] = i < n && new_words[i] ? (1ull << 32) | new_words[i] : 0ull;
             mine += v[j];
         }
         unsigned long long total;
@@ -358,6 +370,143 @@ __global__ void k_dag_block_prefix(const uint64_t* __restrict__ vkeys, uint32_t 
     for (size_t r = size_t(blockIdx.x) * blockDim.x + threadIdx.x; r < nbv; r += size_t(gridDim.x) * blockDim.x) prefix[r] = vkeys[r] >> 6;   // digits 0..18
 }
 
+
+// ---- the upper levels in ONE launch -------------------------------------------------------------------------------------------
+// Above the first few levels a submap has a handful of nodes per level (a cfg2 room: 9 409 blocks, 1 500 nodes one level up, 250,
+// 50, ... 1), and a level costs ten dependent launches in the generic form above: nineteen levels are two hundred launches, 1-2 ms
+// for work of microseconds.  One workgroup of 1 024 threads runs the same four steps for every level from `top` down to the root,
+// as long as the level below has at most kDagSmall nodes: candidates in LDS, the tables and stores in global memory as before.
+constexpr uint32_t kDagSmall = 1024;
+struct DagLevelsArg { uint32_t* table[kDagDepth]; uint32_t* raw[kDagDepth]; uint32_t mask[kDagDepth]; uint32_t capacity[kDagDepth]; };
+
+__device__ __forceinline__ uint32_t dag_scan1024(uint32_t v, uint32_t* total, uint32_t* scratch /* 17 words of LDS */) {   // exclusive, 1 024 threads
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (int(lane) >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63u) scratch[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t t = scratch[w]; before += w < wave ? t : 0u; all += t; }
+    *total = all;
+    return before + incl - v;
+}
+
+__global__ void __launch_bounds__(1024)
+k_dag_small_levels(DagLevelsArg L, DagScalars* __restrict__ scalars, int top /* first level to build */, uint32_t n_below,
+                   const uint64_t* __restrict__ prefix_below, const uint32_t* __restrict__ addr_below /* [2 n_below] */, uint32_t* __restrict__ roots_out) {
+    __shared__ uint64_t prefix[2][kDagSmall];
+    __shared__ uint32_t addr[2][2 * kDagSmall];
+    __shared__ uint32_t cand[2 * kDagSmall][8];
+    __shared__ uint32_t head_pos[kDagSmall + 1];
+    __shared__ uint32_t scratch[17];
+    __shared__ uint32_t batch_base;
+    const uint32_t t = threadIdx.x;
+    uint32_t cur = 0;
+    if (t < n_below) { prefix[0][t] = prefix_below[t]; addr[0][2 * t] = addr_below[2 * t]; addr[0][2 * t + 1] = addr_below[2 * t + 1]; }
+    __syncthreads();
+    for (int d = top; d >= 0; d--) {
+        // parents of the level below
+        const bool head = t < n_below && (t == 0 || (prefix[cur][t] >> 3) != (prefix[cur][t - 1] >> 3));
+        uint32_t parents;
+        const uint32_t rank = dag_scan1024(head ? 1u : 0u, &parents, scratch);
+        if (head) { head_pos[rank] = t; prefix[cur ^ 1][rank] = prefix[cur][t] >> 3; }
+        if (n_below == 0u) parents = d == 0 ? 1u : 0u;   // an empty octree still yields a childless root pair (submap.hpp:29-44)
+        if (t == 0) head_pos[parents] = n_below;
+        __syncthreads();
+        if (t < parents) {
+            uint32_t ct[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint32_t first = n_below ? head_pos[t] : 0u, end = n_below ? head_pos[t + 1] : 0u;
+            for (uint32_t j = first; j < end && j < first + 8u; j++) {
+                const uint32_t digit = uint32_t(prefix[cur][j]) & 7u, a = addr[cur][2 * j], b = addr[cur][2 * j + 1];
+#pragma unroll
+                for (uint32_t o = 0; o < 8; o++) { ct[o] = o == digit ? a : ct[o]; cw[o] = o == digit ? b : cw[o]; }
+            }
+#pragma unroll
+            for (uint32_t o = 0; o < 8; o++) { cand[2 * t][o] = ct[o]; cand[2 * t + 1][o] = cw[o]; }
+        }
+        __syncthreads();
+        // probe: thread t owns candidates 2t and 2t + 1 (consecutive: sequence order)
+        const uint32_t n = 2u * parents;
+        uint32_t* table = L.table[d];
+        uint32_t* raw = L.raw[d];
+        const uint32_t mask = L.mask[d];
+        uint32_t pos[2] = {0, 0};
+        const uint32_t base = __hip_atomic_load(&scalars[d].size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (updated by thread 0 only behind the next barriers)
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t i = 2 * t + k;
+            if (i >= n) break;
+            uint32_t mine[8];
+#pragma unroll
+            for (int o = 0; o < 8; o++) mine[o] = cand[i][o];
+            const uint32_t me = base + i;
+            uint32_t p = dag_hash_children(mine) & mask;
+            for (;; p = (p + 1u) & mask) {
+                uint32_t v = __hip_atomic_load(&table[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v == 0u) { v = atomicCAS(&table[p], 0u, me); if (v == 0u) break; }
+                bool same;
+                if (v >= base) {
+                    const uint32_t j = v - base;
+                    same = true;
+#pragma unroll
+                    for (int o = 0; o < 8; o++) same = same && cand[j][o] == mine[o];
+                    if (same && v > me) (void)atomicMin(&table[p], me);
+                } else same = dag_node_equals(raw, v, mine);
+                if (same) break;
+            }
+            pos[k] = p;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (atomicMin returns nothing: it must have been performed before anybody reads the slot)
+        __syncthreads();
+        unsigned long long v[2] = {0, 0};
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t i = 2 * t + k;
+            if (i < n && __hip_atomic_load(&table[pos[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == base + i) {
+                uint32_t words = 1;
+                for (int o = 0; o < 8; o++) words += cand[i][o] ? 1u : 0u;
+                v[k] = (1ull << 32) | words;
+            }
+        }
+        uint32_t total_words, total_new;
+        uint32_t at = dag_scan1024(uint32_t(v[0]) + uint32_t(v[1]), &total_words, scratch);
+        (void)dag_scan1024(uint32_t(v[0] >> 32) + uint32_t(v[1] >> 32), &total_new, scratch);
+        if (t == 0) {
+            DagScalars* s = scalars + d;
+            batch_base = s->size;
+            s->batch_base = s->size; __hip_atomic_store(&s->size, s->size + total_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s->entries += total_new; s->uniques += total_new; s->dupes += n - total_new;
+        }
+        __syncthreads();
+        at += batch_base;
+        uint32_t result[2] = {0, 0};
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t i = 2 * t + k;
+            if (i >= n || !v[k]) continue;
+            const uint32_t words = uint32_t(v[k]);
+            if (at + words <= L.capacity[d]) {
+                uint32_t m = 0, w = at + 1;
+                for (int o = 0; o < 8; o++) if (cand[i][o]) { m |= 1u << o; raw[w++] = cand[i][o]; }
+                raw[at] = m;
+            }
+            table[pos[k]] = at;
+            result[k] = at;
+            at += words;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t i = 2 * t + k;
+            if (i >= n) break;
+            if (!result[k]) result[k] = __hip_atomic_load(&table[pos[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            addr[cur ^ 1][i] = result[k];
+        }
+        __syncthreads();
+        cur ^= 1;
+        n_below = parents;
+    }
+    if (t < 2) roots_out[t] = addr[cur][t];
+}
+
 // ---- table growth ------------------------------------------------------------------------------------------------------------
 template <bool kNode>
 __global__ void __launch_bounds__(256)
@@ -409,7 +558,7 @@ inline hipError_t dag_device_init(DeviceDag& d, hipStream_t s) {
     if ((e = hipHostMalloc(&d.h_small, 4096)) != hipSuccess) return e;
     for (uint32_t l = 0; l <= kDagDepth; l++) {
         DagLevelDev& L = d.level[l];
-        L.table_slots = 1024; L.raw_capacity = 1024;
+        L.table_slots = 1u << 16; L.raw_capacity = 1u << 16;
         if ((e = hipMalloc(&L.table, size_t(L.table_slots) * 4)) != hipSuccess) return e;
         if ((e = hipMalloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4))) != hipSuccess) return e;
         if ((e = hipMemsetAsync(L.table, 0, size_t(L.table_slots) * 4, s)) != hipSuccess) return e;
@@ -431,8 +580,9 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
     hipError_t e;
     if (need_slots > L.table_slots) {
         size_t slots = L.table_slots;
-        while (slots < need_slots) slots <<= 1;
-        if (slots > (size_t(1) << 31)) return hipErrorOutOfMemory;
+        while (slots < 2 * need_slots) slots <<= 1;   // (room for as much again: growth is a device-wide stall)
+        slots = std::min<size_t>(slots, size_t(1) << 31);
+        if (need_slots > (size_t(1) << 31)) return hipErrorOutOfMemory;   // (a table of 2^31 slots: a billion values in one level)
         uint32_t* bigger = nullptr;
         if ((e = hipMalloc(&bigger, slots * 4)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(bigger, 0, slots * 4, s)) != hipSuccess) { (void)hipFree(bigger); return e; }
@@ -445,9 +595,9 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
     const size_t need_words = size_t(d.h_scalars[l].size) + n * words_each + 16;
     if (need_words > L.raw_capacity) {
         size_t words = L.raw_capacity;
-        while (words < need_words) words += words / 2 + 1024;
-        if (need_words >= (size_t(1) << 31)) return hipErrorOutOfMemory;   // addresses are 31 bits here (the top bit marks a pending table slot)
-        words = std::min<size_t>(words, (size_t(1) << 31) - 1);
+        while (words < need_words + need_words / 2) words += words / 2 + 1024;
+        if (need_words + n >= (size_t(1) << 32)) return hipErrorOutOfMemory;   // addresses are 32 bits, as in the reference (levels.hpp:50, :117); the batch's pending marks lie above them
+        words = std::min<size_t>(words, (size_t(1) << 32) - 1 - n);
         const size_t unit = cluster ? 8 : 4;
         void* bigger = nullptr;
         if ((e = hipMalloc(&bigger, words * unit)) != hipSuccess) return e;
@@ -460,23 +610,23 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
 }
 
 // One batch on level l: candidates `cand` (n rows of eight child addresses, or n cluster words) -> result[i] = address of candidate i's value.
-inline void dag_batch(DeviceDag& d, uint32_t l, const void* cand, uint32_t n, uint32_t* pos, uint32_t* result, unsigned long long* sums, unsigned long long* total,
+inline void dag_batch(DeviceDag& d, uint32_t l, const void* cand, uint32_t n, uint32_t* pos, uint32_t* result, uint8_t* new_words, unsigned long long* sums, unsigned long long* total,
                       unsigned long long extra_dupes, hipStream_t s) {
     DagLevelDev& L = d.level[l];
     const uint32_t mask = L.table_slots - 1, chunks = (n + kDagChunk - 1) / kDagChunk;
     const dim3 flat = dag_grid(n), chunked = dim3(std::max(1u, std::min(chunks, 2048u)));
     if (l == kDagDepth) {
-        if (n) hipLaunchKernelGGL(k_dag_probe<false>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, pos);
-        if (n) hipLaunchKernelGGL(k_dag_new_sums<false>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(nullptr), n, sums);
+        if (n) hipLaunchKernelGGL(k_dag_probe<false>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, d.d_scalars + l, pos);
+        if (n) hipLaunchKernelGGL(k_dag_new_sums<false>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(nullptr), n, d.d_scalars + l, new_words, sums);
     } else {
-        if (n) hipLaunchKernelGGL(k_dag_probe<true>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, pos);
-        if (n) hipLaunchKernelGGL(k_dag_new_sums<true>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(cand), n, sums);
+        if (n) hipLaunchKernelGGL(k_dag_probe<true>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, d.d_scalars + l, pos);
+        if (n) hipLaunchKernelGGL(k_dag_new_sums<true>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(cand), n, d.d_scalars + l, new_words, sums);
     }
     hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, total);
     hipLaunchKernelGGL(k_dag_account, dim3(1), dim3(1), 0, s, d.d_scalars + l, total, n, extra_dupes);
     if (!n) return;
-    if (l == kDagDepth) hipLaunchKernelGGL(k_dag_commit<false>, chunked, dim3(256), 0, s, L.table, pos, cand, n, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
-    else hipLaunchKernelGGL(k_dag_commit<true>, chunked, dim3(256), 0, s, L.table, pos, cand, n, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
+    if (l == kDagDepth) hipLaunchKernelGGL(k_dag_commit<false>, chunked, dim3(256), 0, s, L.table, pos, cand, n, new_words, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
+    else hipLaunchKernelGGL(k_dag_commit<true>, chunked, dim3(256), 0, s, L.table, pos, cand, n, new_words, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
     hipLaunchKernelGGL(k_dag_resolve, flat, dim3(256), 0, s, L.table, pos, n, result);
 }
 
@@ -491,7 +641,7 @@ inline hipError_t dag_device_add_submap(DeviceDag& d, const uint64_t* keys, cons
     const size_t chunks_ub = (std::max<size_t>(cc_ub, 2 * size_t(nb) + 2) + kDagChunk - 1) / kDagChunk + 1;
     auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
     const size_t nbp = size_t(nb) + 1;
-    const size_t need = padded(nbp * 8) + 2 * padded(nbp * 4) + padded(cc_ub * 8) + 2 * padded(cc_ub * 4) + padded(chunks_ub * 8) +
+    const size_t need = padded(nbp * 8) + 2 * padded(nbp * 4) + padded(cc_ub * 8) + 2 * padded(cc_ub * 4) + padded(chunks_ub * 8) + padded(std::max<size_t>(cc_ub, 2 * nbp)) +
                         2 * (padded(nbp * 8) + padded(nbp * 64) + 2 * padded(nbp * 8) + padded((nbp + 1) * 4));
     if (need > d.arena_cap) {
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
@@ -508,6 +658,7 @@ inline hipError_t dag_device_add_submap(DeviceDag& d, const uint64_t* keys, cons
     uint32_t* cpos = static_cast<uint32_t*>(take(cc_ub * 4));
     uint32_t* caddr = static_cast<uint32_t*>(take(cc_ub * 4));
     unsigned long long* sums = static_cast<unsigned long long*>(take(chunks_ub * 8));
+    uint8_t* new_words = static_cast<uint8_t*>(take(std::max<size_t>(cc_ub, 2 * nbp)));
     struct LevelScratch { uint64_t* prefix; uint32_t* children; uint32_t* pos; uint32_t* addr; uint32_t* head_pos; } ls[2];
     for (auto& x : ls) {
         x.prefix = static_cast<uint64_t*>(take(nbp * 8)); x.children = static_cast<uint32_t*>(take(nbp * 64));
@@ -537,7 +688,7 @@ inline hipError_t dag_device_add_submap(DeviceDag& d, const uint64_t* keys, cons
     // the cluster level meanwhile (its size is known)
     const uint32_t ncc = octets ? (saturate ? 2u * octets : octets + 1u) : 0u;
     if ((e = dag_level_reserve(d, kDagDepth, ncc, 1, s)) != hipSuccess) return e;
-    if (ncc) dag_batch(d, kDagDepth, ccand, ncc, cpos, caddr, sums, d.d_total + 1, saturate ? 0ull : (unsigned long long)(octets - 1u), s);
+    if (ncc) dag_batch(d, kDagDepth, ccand, ncc, cpos, caddr, new_words, sums, d.d_total + 1, saturate ? 0ull : (unsigned long long)(octets - 1u), s);
     if (nbv) {
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         uint32_t running = 1;   // n_d = 1 + #{blocks that part from their predecessor at a depth below d}
@@ -549,29 +700,41 @@ inline hipError_t dag_device_add_submap(DeviceDag& d, const uint64_t* keys, cons
         hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, tsdf, vblock, oct_before, nbv, saturate, caddr, ls[cur].children);
         hipLaunchKernelGGL(k_dag_block_prefix, dag_grid(nbv), dim3(256), 0, s, vkeys, nbv, ls[cur].prefix);
         if ((e = dag_level_reserve(d, kDagDepth - 1, 2 * size_t(nbv), 9, s)) != hipSuccess) return e;
-        dag_batch(d, kDagDepth - 1, ls[cur].children, 2 * nbv, ls[cur].pos, ls[cur].addr, sums, d.d_total + 2, 0ull, s);
+        dag_batch(d, kDagDepth - 1, ls[cur].children, 2 * nbv, ls[cur].pos, ls[cur].addr, new_words, sums, d.d_total + 2, 0ull, s);
     }
     uint32_t n_below = nbv;
+    uint32_t* d_roots = d.d_hist + 24;   // (two spare words behind the histogram's twenty)
+    bool fused = false;
     for (int dd = int(kDagDepth) - 2; dd >= 0; dd--) {
-        const uint32_t parents = nbv ? level_nodes[dd] : (dd == 0 ? 1u : 0u);   // an empty octree still yields a childless root pair (submap.hpp:29-44)
+        if (n_below <= kDagSmall) {   // this level and everything above it in one launch (node counts only shrink towards the root)
+            DagLevelsArg arg{};
+            for (int u = dd; u >= 0; u--) {
+                const uint32_t parents_u = nbv ? level_nodes[u] : (u == 0 ? 1u : 0u);
+                if ((e = dag_level_reserve(d, uint32_t(u), 2 * size_t(parents_u), 9, s)) != hipSuccess) return e;
+            }
+            for (uint32_t u = 0; u < kDagDepth; u++) {
+                arg.table[u] = d.level[u].table; arg.raw[u] = static_cast<uint32_t*>(d.level[u].raw);
+                arg.mask[u] = d.level[u].table_slots - 1; arg.capacity[u] = d.level[u].raw_capacity;
+            }
+            hipLaunchKernelGGL(k_dag_small_levels, dim3(1), dim3(1024), 0, s, arg, d.d_scalars, dd, n_below, ls[cur].prefix, ls[cur].addr, d_roots);
+            fused = true;
+            break;
+        }
+        const uint32_t parents = level_nodes[dd];   // (n_below > kDagSmall: the submap is not empty)
         LevelScratch& below = ls[cur];
         LevelScratch& here = ls[cur ^ 1];
-        if (parents) {
-            if (n_below) {
-                const uint32_t chunks = (n_below + kDagChunk - 1) / kDagChunk;
-                hipLaunchKernelGGL(k_dag_head_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums);
-                hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, d.d_total + 3);
-                hipLaunchKernelGGL(k_dag_head_apply, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums, here.head_pos, here.prefix, parents);
-                hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents, below.addr, here.children);
-            } else if ((e = hipMemsetAsync(here.children, 0, 64, s)) != hipSuccess) return e;   // the childless root pair
-            if ((e = dag_level_reserve(d, uint32_t(dd), 2 * size_t(parents), 9, s)) != hipSuccess) return e;
-            dag_batch(d, uint32_t(dd), here.children, 2 * parents, here.pos, here.addr, sums, d.d_total + 4, 0ull, s);
-        }
+        const uint32_t chunks = (n_below + kDagChunk - 1) / kDagChunk;
+        hipLaunchKernelGGL(k_dag_head_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums);
+        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, d.d_total + 3);
+        hipLaunchKernelGGL(k_dag_head_apply, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums, here.head_pos, here.prefix, parents);
+        hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents, below.addr, here.children);
+        if ((e = dag_level_reserve(d, uint32_t(dd), 2 * size_t(parents), 9, s)) != hipSuccess) return e;
+        dag_batch(d, uint32_t(dd), here.children, 2 * parents, here.pos, here.addr, new_words, sums, d.d_total + 4, 0ull, s);
         n_below = parents;
         cur ^= 1;
     }
     // roots and the levels' scalars
-    if ((e = hipMemcpyAsync(d.h_small + 64, ls[cur].addr, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d.h_small + 64, fused ? d_roots : ls[cur].addr, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(d.h_small + 128, d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;

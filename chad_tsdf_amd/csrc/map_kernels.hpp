@@ -32,6 +32,12 @@
 namespace chadhip {
 
 constexpr uint64_t kEmptyKey = ~0ull;
+// MapView::overflow, one word per table: bit 0 = a block found no slot (sticky until a reset); bit 2 = the table's exact rows
+// (brick_sum, brick_cnt) have been written since it was last cleared.  A table that only ever took the scatter form's staging
+// words (sparse frames: BASELINE config 5) has all-zero exact rows, and everything that walks the live bricks -- the archive's
+// compaction, the exchange's, the clear -- then touches 512 of a slot's 1 288 bytes (1.65 M live bricks per cfg5 submap: 2.1 GB
+// less to read and 1.3 GB less to zero per roll-over).  Raised by one lane per launch (or per rare event), never per observation.
+constexpr uint32_t kTableOverflowed = 1u, kTableExactRows = 4u;
 constexpr uint32_t kNoBrick = 0xfffffffeu;   // table too full: updates to this block are dropped (overflow flag set)
 constexpr uint32_t kMaxProbes = 256;         // at load <= 0.5 probe sequences are a handful of slots long
 
@@ -78,6 +84,9 @@ struct MapView {
     uint32_t brick_capacity; // nominal capacity (H / 2 or less): the pools grow once half of it is in use
 };
 
+__device__ __forceinline__ bool table_pack_only(const MapView& m) { return (__hip_atomic_load(m.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kTableExactRows) == 0u; }
+__device__ __forceinline__ void mark_exact_rows(const MapView& m) { atomicOr(m.overflow, kTableExactRows); }
+
 // One observation into cell `at` of the active map (the scatter form; the tiled update adds whole partial sums).
 __device__ __forceinline__ void add_observation(const MapView& m, size_t at, float d, float units_per_metre) {
     if (d == d) atomicAdd(reinterpret_cast<unsigned long long*>(&m.brick_sum[at]), (unsigned long long)sum_units(d, units_per_metre));
@@ -89,7 +98,7 @@ __device__ __forceinline__ void add_observation(const MapView& m, size_t at, flo
 __device__ __forceinline__ void add_observation_packed(const MapView& m, size_t at, float d, float pack_units_per_metre) {
     unsigned long long word = 1ull << kPackCountShift;
     if (d == d) word += (unsigned long long)(long long)rintf(d * pack_units_per_metre);
-    else atomicOr(&m.brick_cnt[at], kPoisonedCount);
+    else { atomicOr(&m.brick_cnt[at], kPoisonedCount); mark_exact_rows(m); }
     atomicAdd(&m.brick_pack[at], word);
 }
 __device__ __forceinline__ void unpack_staged(unsigned long long word, long long* sum_units_out, uint32_t* count_out) {
@@ -98,9 +107,10 @@ __device__ __forceinline__ void unpack_staged(unsigned long long word, long long
     *sum_units_out = staged * kPackToSum;
 }
 // What voxel `at` holds: the exact sums plus whatever is still staged.  count keeps the poison flag in its top bit.
-__device__ __forceinline__ void voxel_totals(const MapView& m, size_t at, long long* sum, uint32_t* count) {
-    long long s = m.brick_sum[at];
-    uint32_t c = m.brick_cnt[at];
+// pack_only (wave-uniform, table_pack_only() read once per kernel behind the table's last update): the exact rows are known to be zero
+__device__ __forceinline__ void voxel_totals(const MapView& m, size_t at, long long* sum, uint32_t* count, bool pack_only = false) {
+    long long s = pack_only ? 0ll : m.brick_sum[at];
+    uint32_t c = pack_only ? 0u : m.brick_cnt[at];
     const unsigned long long word = m.brick_pack[at];
     if (word) {
         long long staged_sum; uint32_t staged_count;
@@ -162,6 +172,7 @@ __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, c
     const bool packed = n <= kPackMaxPoints;
     if (packed && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(pack_seen_host, atomicAdd(pack_counter, 1u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!packed && blockIdx.x == 0 && threadIdx.x == 0) mark_exact_rows(m);   // two exact atomics per observation: the exact rows are in use
     const float pack_units = kPackOne / trunc, sum_units_per_metre = kSumOne / trunc;
     const uint32_t lane = threadIdx.x & 63u, rows = packed ? min(stage_rows, 16u) : 0u;
     constexpr unsigned long long kNothing = ~0ull;
@@ -191,7 +202,7 @@ __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, c
                     const size_t at = size_t(brick) * 64 + (uint32_t(mc) & 63u);
                     const float d = observe(w.cur, p, nrm, res, trunc);
                     if (k < rows) {   // noted: [cell : 40 | distance in staging units : 24, two's complement]
-                        if (!(d == d)) atomicOr(&m.brick_cnt[at], kPoisonedCount);   // NaN (Q4): counted, adds nothing, poisons
+                        if (!(d == d)) { atomicOr(&m.brick_cnt[at], kPoisonedCount); mark_exact_rows(m); }   // NaN (Q4): counted, adds nothing, poisons (the flag lives in the exact count row)
                         note = (uint64_t(at) << 24) | (uint32_t(d == d ? int(rintf(d * pack_units)) : 0) & 0xffffffu);
                     } else if (packed) add_observation_packed(m, at, d, pack_units);
                     else add_observation(m, at, d, sum_units_per_metre);
@@ -351,6 +362,7 @@ __global__ void __launch_bounds__(256)
 k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, uint64_t* __restrict__ out_key, float* __restrict__ out_sum,
                  uint32_t* __restrict__ out_cnt, float trunc) {
     const double metres_per_unit = double(trunc) / double(kSumOne);
+    const bool pack_only = table_pack_only(m);   // (this kernel runs behind the table's last update)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
@@ -374,7 +386,7 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
 #pragma unroll
             for (uint32_t i = 0; i < 4; i++)
                 if (i < queued && k + i < capacity) {
-                    voxel_totals(m, size_t(slot[i]) * 64 + lane, &units[i], &count[i]);
+                    voxel_totals(m, size_t(slot[i]) * 64 + lane, &units[i], &count[i], pack_only);
                     if (lane == 0) key[i] = m.hash_keys[slot[i]];
                 }
 #pragma unroll
@@ -405,10 +417,13 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
 __global__ void __launch_bounds__(256)
 k_clear_bricks(MapView m, uint32_t clear_overflow) {
     const uint32_t lane = threadIdx.x & 63;
+    const bool pack_only = table_pack_only(m);   // exact rows never written since the last clear: they are zero already
     for_each_live_brick(m, [&](uint32_t slot) {
         if (lane == 0) m.hash_keys[slot] = kEmptyKey;
-        m.brick_sum[size_t(slot) * 64 + lane] = 0ll;
-        m.brick_cnt[size_t(slot) * 64 + lane] = 0u;
+        if (!pack_only) {
+            m.brick_sum[size_t(slot) * 64 + lane] = 0ll;
+            m.brick_cnt[size_t(slot) * 64 + lane] = 0u;
+        }
         m.brick_pack[size_t(slot) * 64 + lane] = 0ull;
     });
     // each wave clears exactly the words it has just read
@@ -418,20 +433,30 @@ k_clear_bricks(MapView m, uint32_t clear_overflow) {
     for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u)
         if (w0 + lane < words && m.live_bits[w0 + lane]) m.live_bits[w0 + lane] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < kCountStripes) m.brick_count[threadIdx.x * 16] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && clear_overflow) *m.overflow = 0u;
+    // the table's flags go last, when every workgroup has read the "exact rows" bit: the last one to arrive resets it (and, at a reset
+    // of the map, the overflow bit) and re-arms the counter
+    uint32_t* done = m.overflow + 8;   // the table's arrival counter: chad_map::d_overflow words 9..15 belong to the tables of words 1..7 (zero between clears)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(done, 1u) == gridDim.x - 1u) {
+        atomicAnd(m.overflow, clear_overflow ? ~(kTableExactRows | kTableOverflowed) : ~kTableExactRows);
+        *done = 0u;
+    }
 }
 
 // Move the bricks of a map into a larger, empty one (capacity growth between frames).
 __global__ void __launch_bounds__(256)
 k_rehash_bricks(MapView from, MapView to) {
     const uint32_t lane = threadIdx.x & 63;
+    const bool pack_only = table_pack_only(from);   // (the new table's exact rows are zero from its allocation; the host copies the flag word over)
     for_each_live_brick(from, [&](uint32_t slot) {
         uint32_t dst = 0;
         if (lane == 0) dst = find_or_create_brick(to, from.hash_keys[slot]);
         dst = uint32_t(__builtin_amdgcn_readfirstlane(int(dst)));
         if (dst == kNoBrick) return;
-        to.brick_sum[size_t(dst) * 64 + lane] = from.brick_sum[size_t(slot) * 64 + lane];
-        to.brick_cnt[size_t(dst) * 64 + lane] = from.brick_cnt[size_t(slot) * 64 + lane];
+        if (!pack_only) {
+            to.brick_sum[size_t(dst) * 64 + lane] = from.brick_sum[size_t(slot) * 64 + lane];
+            to.brick_cnt[size_t(dst) * 64 + lane] = from.brick_cnt[size_t(slot) * 64 + lane];
+        }
         to.brick_pack[size_t(dst) * 64 + lane] = from.brick_pack[size_t(slot) * 64 + lane];
     });
 }
@@ -442,6 +467,7 @@ k_rehash_bricks(MapView from, MapView to) {
 __global__ void __launch_bounds__(256)
 k_fold_packed(MapView m) {
     const uint32_t lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) mark_exact_rows(m);
     for_each_live_brick(m, [&](uint32_t slot) {
         const size_t at = size_t(slot) * 64 + lane;
         if (m.brick_pack[at] == 0ull) return;

@@ -23,6 +23,7 @@ __global__ void __launch_bounds__(256)
 k_compact_bricks_raw(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, uint64_t* __restrict__ out_key, long long* __restrict__ out_sum,
                      uint32_t* __restrict__ out_cnt) {
     const uint32_t lane = threadIdx.x & 63;
+    const bool pack_only = table_pack_only(m);
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t words = (m.hash_mask >> 5) + 1u;
@@ -42,7 +43,7 @@ k_compact_bricks_raw(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity
                 if (k >= capacity) continue;
                 const uint32_t slot = (w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u;
                 long long units; uint32_t count;
-                voxel_totals(m, size_t(slot) * 64 + lane, &units, &count);
+                voxel_totals(m, size_t(slot) * 64 + lane, &units, &count, pack_only);
                 out_sum[size_t(k) * 64 + lane] = units;
                 out_cnt[size_t(k) * 64 + lane] = (count & kWireCountMask) | ((count & kPoisonedCount) ? (1u << 28) : 0u);
                 if (lane == 0) out_key[k] = m.hash_keys[slot];

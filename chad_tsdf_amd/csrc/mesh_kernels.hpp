@@ -38,6 +38,64 @@ k_brick_means(const uint32_t* __restrict__ order, uint32_t count, const uint64_t
     }
 }
 
+// The 5 x 5 x 5 corner values of brick k's 4 x 4 x 4 cells into `corner` (index x + 5 y + 25 z; NaN where there is no leaf), from the
+// brick itself and its up to seven neighbours in +x / +y / +z (found by binary search in the sorted keys).  One wave; returns the
+// brick's lowest voxel.
+__device__ __forceinline__ I3 stage_brick_corners(const uint64_t* __restrict__ keys, const float* __restrict__ sd, uint32_t bricks, uint32_t k, float* corner, uint32_t* neighbour) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t key = keys[k];
+    const I3 base = morton_decode(key);   // lowest voxel of the brick
+    if (lane < 8) {
+        const uint64_t nk = morton_encode(base.x + 4 * int(lane & 1u), base.y + 4 * int((lane >> 1) & 1u), base.z + 4 * int(lane >> 2));
+        neighbour[lane] = lane == 0 ? k : find_sorted(keys, bricks, nk);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (uint32_t e = lane; e < 125; e += 64) {
+        const uint32_t x = e % 5, y = (e / 5) % 5, z = e / 25;
+        const uint32_t nb = neighbour[(x >> 2) | ((y >> 2) << 1) | ((z >> 2) << 2)];
+        const uint32_t lx = x & 3, ly = y & 3, lz = z & 3;
+        const uint32_t voxel = (lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2) | ((lx >> 1) << 3) | ((ly >> 1) << 4) | ((lz >> 1) << 5);   // low 6 Morton bits
+        corner[e] = nb == ~0u ? __int_as_float(0x7fc00000) : sd[size_t(nb) * 64 + voxel];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return base;
+}
+
+// The grid ChadGrid hands to the triangulation (lvr2.cpp:15-133), read back for parity: the COMPLETE cells -- all eight corners hold
+// a leaf (lvr2.cpp:115-129) -- as (Morton code of the cell's lowest corner, the eight corner values in the reference's vertex order,
+// lvr2.cpp:92-102).  Lane = cell in Morton order inside the brick, bricks ascending by key: the output is ascending by code.
+// kWrite false: cell_count[k] = complete cells of brick k.  kWrite true: cell_count holds the exclusive scan.
+template <bool kWrite>
+__global__ void __launch_bounds__(256)
+k_mesh_cells(const uint64_t* __restrict__ keys, const float* __restrict__ sd, uint32_t bricks, uint32_t* __restrict__ cell_count, uint64_t* __restrict__ out_code, float* __restrict__ out_corner) {
+    __shared__ float corner[4][128];
+    __shared__ uint32_t neighbour[4][8];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + w, waves = gridDim.x * (blockDim.x >> 6);
+    constexpr int kVx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, kVy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, kVz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    for (uint32_t k = wave; k < bricks; k += waves) {
+        const I3 base = stage_brick_corners(keys, sd, bricks, k, corner[w], neighbour[w]);
+        const int cx = int((lane & 1u) | ((lane >> 2) & 2u)), cy = int(((lane >> 1) & 1u) | ((lane >> 3) & 2u)), cz = int(((lane >> 2) & 1u) | ((lane >> 4) & 2u));
+        float val[8];
+        bool complete = true;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            val[v] = corner[w][(cx + kVx[v]) + 5 * (cy + kVy[v]) + 25 * (cz + kVz[v])];
+            complete = complete && val[v] == val[v];
+        }
+        const uint64_t have = __ballot(complete);
+        if (!kWrite) { if (lane == 0) cell_count[k] = uint32_t(__popcll(have)); continue; }
+        if (!complete) continue;
+        const size_t at = size_t(cell_count[k]) + uint32_t(__popcll(have & ((1ull << lane) - 1ull)));
+        out_code[at] = keys[k] | lane;   // (the cell's lowest corner is voxel `lane` of the brick)
+        (void)base;
+#pragma unroll
+        for (int v = 0; v < 8; v++) out_corner[at * 8 + v] = val[v];
+    }
+}
+
 struct MeshVertex { float x, y, z; };
 
 // kWrite false: tri_count[k] = triangles of brick k.  kWrite true: tri_count holds the exclusive scan; triangles are written to
@@ -54,23 +112,7 @@ k_mesh_bricks(const uint64_t* __restrict__ keys, const float* __restrict__ sd, u
     constexpr int kTet[6][4] = {{0, 1, 2, 6}, {0, 3, 2, 6}, {0, 3, 7, 6}, {0, 4, 7, 6}, {0, 4, 5, 6}, {0, 1, 5, 6}};
     constexpr int kVx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, kVy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, kVz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
     for (uint32_t k = wave; k < bricks; k += waves) {
-        const uint64_t key = keys[k];
-        const I3 base = morton_decode(key);   // lowest voxel of the brick
-        if (lane < 8) {
-            const uint64_t nk = morton_encode(base.x + 4 * int(lane & 1u), base.y + 4 * int((lane >> 1) & 1u), base.z + 4 * int(lane >> 2));
-            neighbour[w][lane] = lane == 0 ? k : find_sorted(keys, bricks, nk);
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (uint32_t e = lane; e < 125; e += 64) {
-            const uint32_t x = e % 5, y = (e / 5) % 5, z = e / 25;
-            const uint32_t nb = neighbour[w][(x >> 2) | ((y >> 2) << 1) | ((z >> 2) << 2)];
-            const uint32_t lx = x & 3, ly = y & 3, lz = z & 3;
-            const uint32_t voxel = (lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2) | ((lx >> 1) << 3) | ((ly >> 1) << 4) | ((lz >> 1) << 5);   // low 6 Morton bits
-            corner[w][e] = nb == ~0u ? __int_as_float(0x7fc00000) : sd[size_t(nb) * 64 + voxel];
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const I3 base = stage_brick_corners(keys, sd, bricks, k, corner[w], neighbour[w]);
         // lane = cell (cx, cy, cz)
         const int cx = int(lane & 3u), cy = int((lane >> 2) & 3u), cz = int(lane >> 4);
         float val[8];

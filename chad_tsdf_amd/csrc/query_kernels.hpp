@@ -71,6 +71,7 @@ k_carve(const float4* __restrict__ points0, const float4* __restrict__ points1, 
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order (any order would do)
     const uint32_t n = h->n_usable;
     unsigned long long carved = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) mark_exact_rows(m);   // carving adds to the exact rows (map_kernels.hpp, kTableExactRows)
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const float4 q = pts[i];
         const F3 p{q.x, q.y, q.z};

@@ -129,6 +129,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
         scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host, tile + wave * (stage_rows * kStageRow), stage_rows);
         return;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) mark_exact_rows(m);   // the tile flush adds to the exact rows (map_kernels.hpp, kTableExactRows)
     if (kStamps) wall_lists = wall_clock64();
     const uint32_t n_long = first_long[kListStripes], nitems = n_long + first_short[kListStripes];
     auto item_record = [&](uint32_t v) {

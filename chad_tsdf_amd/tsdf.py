@@ -161,6 +161,15 @@ class TSDFMap:
         return v, t
 
     # ---- extensions ---------------------------------------------------------------------------------
+    def mesh_cells(self, submap: int = 0):
+        """The grid the mesh is cut from (ChadGrid, lvr2.cpp:15-133): (codes u64 [C] ascending, corners f32 [C, 8]) of the complete cells."""
+        n = C.c_size_t()
+        _lib.check(self._lib.chad_map_mesh_cells(self._h, submap, None, None, 0, C.byref(n)), "TSDFMap.mesh_cells")
+        codes = np.empty(n.value, dtype=np.uint64)
+        corners = np.empty((n.value, 8), dtype=np.float32)
+        _lib.check(self._lib.chad_map_mesh_cells(self._h, submap, codes.ctypes.data, corners.ctypes.data, n.value, C.byref(n)), "TSDFMap.mesh_cells")
+        return codes, corners
+
     def sync(self):
         _lib.check(self._lib.chad_map_sync(self._h), "TSDFMap.sync")
 
@@ -257,7 +266,7 @@ class TSDFMap:
     def dag_stats(self) -> dict:
         st = _lib.DagStats()
         _lib.check(self._lib.chad_map_dag_stats(self._h, C.byref(st)), "TSDFMap.dag_stats")
-        return {"submaps": int(st.submaps), "uniques": list(st.uniques), "dupes": list(st.dupes), "ms_device": st.ms_device, "ms_host": st.ms_host}
+        return {"submaps": int(st.submaps), "uniques": list(st.uniques), "dupes": list(st.dupes), "ms_device": st.ms_device, "ms_host": st.ms_host, "device_bytes": int(st.device_bytes)}
 
     def dag_leaves(self, submap: int):
         """(mc u64, sd f32) read back through the DAG (lvr2.cpp:30-90), sd de-quantised from 8 bits, ascending by code."""

@@ -210,7 +210,10 @@ enum { CHAD_DAG_NODE_LEVELS = 20, CHAD_DAG_CLUSTER_LEVEL = 20 };
 typedef struct chad_dag_stats {
     uint64_t submaps;               /* closed submaps folded into the DAG so far */
     uint32_t uniques[21], dupes[21]; /* NodeLevel::_uniques_n/_dupes_n per level (levels.hpp:88); [20] = leaf clusters (levels.hpp:136) */
-    float ms_device, ms_host;       /* of the last chad_map_finalize that had work: cluster kernel (+ key sort, copies) / DAG build */
+    float ms_device, ms_host;       /* of the last chad_map_finalize that had work: device time (key sort, cluster kernel, the fold of the levels) /
+                                     * host time (bringing the level arrays over when they are read; the whole fold under CHAD_DEBUG_DAG_HOST) */
+    uint64_t device_bytes;          /* HBM held by the DAG: the levels' stores, their look-up tables, the fold's scratch (the reference keeps its
+                                     * NodeLevels in host memory; here Submap::finalize runs on the device, so the DAG lives there) */
 } chad_dag_stats;
 chad_status chad_map_finalize(chad_map* map);
 /* Submap::root_addr_tsdf / root_addr_weight (submap.hpp:108-109) of closed submap `submap`: addresses into level 0 */
@@ -272,6 +275,13 @@ chad_status chad_map_raycast(chad_map* map, const float* origins, const float* d
 chad_status chad_map_mesh(chad_map* map, int32_t submap, float* vertices, size_t vertex_capacity, uint32_t* triangles, size_t triangle_capacity,
                           size_t* vertex_count, size_t* triangle_count);
 chad_status chad_map_save_mesh(chad_map* map, int32_t submap, const char* filename);   /* binary little-endian PLY */
+/* Stage read-back for parity: the grid itself, i.e. what ChadGrid's constructor (lvr2.cpp:15-133) leaves in m_cells / m_queryPoints before
+ * LVR2 triangulates it -- the COMPLETE cells (all eight corners hold a leaf, lvr2.cpp:115-129), ascending by the Morton code of their
+ * lowest corner (MortonCode(cell_chunk)._value, lvr2.cpp:105); corners[8 * c + i] = signed distance of the query point at vertex i
+ * of cell c, vertex order of lvr2.cpp:92-102 (0 (0,0,0), 1 (1,0,0), 2 (1,1,0), 3 (0,1,0), 4..7 the same at z + 1).  Values as the mesh
+ * takes them: the exact means, or -- CHAD_FLAG_MESH_FROM_DAG / CHAD_FLAG_DAG_ONLY -- the DAG's de-quantised bytes (cluster.hpp:33-52),
+ * which is what the reference meshes.  Host pointers; call with NULL buffers for the count. */
+chad_status chad_map_mesh_cells(chad_map* map, int32_t submap, uint64_t* codes, float* corners, size_t capacity, size_t* count);
 
 /* ---- Loop-closure support (upstream's roadmap lists "Loop closure" as open, README.md:59, and keeps what it would
  * need: the poses of a submap's frames, Submap::positions, submap.hpp:110).  EXTENSION, nothing upstream to compare with.

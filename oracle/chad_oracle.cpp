@@ -454,6 +454,84 @@ void finalize(const Octree& oct, NodeLevels& lv, float trunc, bool saturate_weig
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The half of TSDFMap::save's mesh extraction that is the reference's own code (src/chad/detail/lvr2.cpp:15-133, ChadGrid's
+// constructor): walk a submap's signed-distance tree, make a query point per leaf, put it into the eight cells
+// around it, cull the cells with a missing corner.  What it hands to LVR2 (the triangulation, lvr2.cpp:235-270: third-party,
+// absent, parity unpinned) is exactly this: the set of complete cells with their eight corner values.
+inline uint32_t dag_child_addr(const NodeLevels& lv, uint32_t depth, uint32_t parent_addr, uint32_t child_i) {   // levels.hpp:147-161 (get_child_addr)
+    const uint32_t child_mask = lv.nodes[depth].raw[parent_addr];
+    const uint32_t child_bit = 1u << child_i;
+    if (!(child_mask & child_bit)) return 0;
+    const uint32_t child_count = uint32_t(__builtin_popcount(child_mask & (child_bit - 1u) & 0xffu));
+    return lv.nodes[depth].raw[parent_addr + child_count + 1u];
+}
+// cluster.hpp:33-52 (TSDFs::try_get)
+inline bool cluster_try_get(uint64_t value, uint32_t leaf_i, float sdf_trunc, float& signed_distance) {
+    const uint64_t leaf_bits = (value >> uint64_t(leaf_i * 8)) & 0xff;
+    if (leaf_bits == 0xff) return false;
+    float sd = float(leaf_bits) - 127.0f;   // sd_range_abs = 255 / 2
+    sd *= float(1.0 / float(127));
+    sd *= sdf_trunc;
+    signed_distance = sd;
+    return true;
+}
+struct GridCell { uint64_t code; uint32_t vertex[8]; };   // MortonCode(cell_chunk)._value; query point per corner, 0xffffffff = FastBox::INVALID_INDEX
+struct ChadGridOut {
+    std::vector<V3> qp_pos; std::vector<float> qp_sd;      // m_queryPoints (lvr2.cpp:87-88)
+    std::vector<GridCell> cells;                            // m_cells after the culling of lvr2.cpp:115-129, ascending by code (the reference's map is unordered)
+};
+void chad_grid(const NodeLevels& lv, uint32_t root_addr, float voxel_res, float trunc_dist, ChadGridOut& out) {
+    constexpr uint32_t D = NodeLevels::MAX_DEPTH;
+    uint8_t path_child[D] = {};
+    uint32_t path_addr[D] = {};
+    path_addr[0] = root_addr;                                // lvr2.cpp:24-29
+    std::unordered_map<uint64_t, std::array<uint32_t, 8>> cells;
+    uint32_t depth = 0;
+    while (true) {                                           // :32-113
+        const uint8_t child_i = path_child[depth]++;
+        if (child_i == 8) {                                  // :37-40
+            if (depth > 0) depth--; else break;
+        } else if (depth < D - 1) {                          // :43-53
+            const uint32_t child_addr = dag_child_addr(lv, depth, path_addr[depth], child_i);
+            if (child_addr > 0) { depth++; path_child[depth] = 0; path_addr[depth] = child_addr; }
+        } else {                                             // :55-112: leaf clusters
+            const uint32_t cluster_addr = dag_child_addr(lv, D - 1, path_addr[depth], child_i);   // try_get_lc, levels.hpp:178-192
+            if (!(lv.nodes[D - 1].raw[path_addr[depth]] & (1u << child_i))) continue;
+            const uint64_t cluster = lv.leaf_clusters.raw[cluster_addr];
+            uint64_t code = 0;                               // :61-66: the Morton code from the path
+            for (uint64_t k = 0; k < 63 / 3 - 1; k++) code |= uint64_t(path_child[k] - 1) << uint64_t(60 - k * 3);
+            int32_t cx, cy, cz;
+            morton_decode(code, cx, cy, cz);                 // :67-68
+            uint32_t leaf_i = 0;
+            for (int32_t z = 0; z <= 1; z++) for (int32_t y = 0; y <= 1; y++) for (int32_t x = 0; x <= 1; x++, leaf_i++) {   // :70-73
+                float signed_distance;
+                if (!cluster_try_get(cluster, leaf_i, trunc_dist, signed_distance)) continue;   // :75-76
+                const int32_t lx = cx + x, ly = cy + y, lz = cz + z;                              // :79
+                const V3 leaf_pos{float(lx) * voxel_res, float(ly) * voxel_res, float(lz) * voxel_res};   // :80
+                const uint32_t querypoint_i = uint32_t(out.qp_sd.size());                        // :88-89
+                out.qp_pos.push_back(leaf_pos); out.qp_sd.push_back(signed_distance);
+                static const int32_t cell_offsets[8][3] = {{0, 0, 0}, {-1, 0, 0}, {-1, -1, 0}, {0, -1, 0}, {0, 0, -1}, {-1, 0, -1}, {-1, -1, -1}, {0, -1, -1}};   // :92-102
+                for (uint32_t i = 0; i < 8; i++) {           // :103-110
+                    const uint64_t cell_code = morton_encode(lx + cell_offsets[i][0], ly + cell_offsets[i][1], lz + cell_offsets[i][2]);
+                    auto [it, emplaced] = cells.try_emplace(cell_code);
+                    if (emplaced) it->second.fill(0xffffffffu);
+                    it->second[i] = querypoint_i;
+                }
+            }
+        }
+    }
+    for (const auto& [code, vertex] : cells) {               // :115-129: cull incomplete cells
+        bool incomplete = false;
+        for (uint32_t i = 0; i < 8; i++) if (vertex[i] == 0xffffffffu) incomplete = true;
+        if (incomplete) continue;
+        GridCell c; c.code = code;
+        for (uint32_t i = 0; i < 8; i++) c.vertex[i] = vertex[i];
+        out.cells.push_back(c);
+    }
+    std::sort(out.cells.begin(), out.cells.end(), [](const GridCell& a, const GridCell& b) { return a.code < b.code; });
+}
+
 struct Snapshot {  // a closed submap's leaves, sorted by code (stands in for the out-of-scope DAG)
     std::vector<uint64_t> mc; std::vector<float> sd; std::vector<uint32_t> w;
 };
@@ -677,6 +755,22 @@ void oracle_map_close_submap_from_leaves(void* h, const uint64_t* mc, const floa
     m->roots.push_back({rt, rw});
     m->closed.emplace_back();
     snapshot(o, m->closed.back());
+}
+
+// ChadGrid (lvr2.cpp:15-133) of closed submap `submap`: the complete cells, ascending by the Morton code of their lowest corner;
+// corners[8 * c + i] = signed distance of the query point at vertex i of cell c (vertex order of lvr2.cpp:92-102).  Returns the
+// number of complete cells; writes at most cap of them.  query_points (optional): out[0] = number of query points.
+size_t oracle_chad_grid(void* h, uint32_t submap, uint64_t* codes, float* corners, size_t cap, uint64_t* query_points) {
+    Map* m = static_cast<Map*>(h);
+    if (submap >= m->roots.size()) return 0;
+    ChadGridOut g;
+    chad_grid(m->levels, m->roots[submap][0], m->res, m->trunc, g);
+    if (query_points) *query_points = g.qp_sd.size();
+    for (size_t c = 0; c < g.cells.size() && c < cap; c++) {
+        if (codes) codes[c] = g.cells[c].code;
+        if (corners) for (uint32_t i = 0; i < 8; i++) corners[8 * c + i] = g.qp_sd[g.cells[c].vertex[i]];
+    }
+    return g.cells.size();
 }
 
 // ---- stage-level entry points for unit parity tests ----

@@ -67,6 +67,8 @@ def lib():
         L.oracle_map_finalize_ms.restype = C.c_double
         L.oracle_map_finalize_ms.argtypes = [vp]
         L.oracle_map_close_submap_from_leaves.argtypes = [vp, vp, vp, vp, sz]
+        L.oracle_chad_grid.restype = sz
+        L.oracle_chad_grid.argtypes = [vp, C.c_uint32, vp, vp, sz, vp]
         _lib = L
     return _lib
 
@@ -150,6 +152,16 @@ class OracleMap:
         if lib().oracle_dag_roots(self._h, submap, _p(out)):
             raise IndexError(submap)
         return int(out[0]), int(out[1])
+
+    def chad_grid(self, submap: int):
+        """ChadGrid of a closed submap (lvr2.cpp:15-133): (codes u64 [C] ascending -- Morton code of each complete cell's lowest corner --,
+        corners f32 [C, 8] -- the query points' signed distances in the cell's vertex order, lvr2.cpp:92-102 --, number of query points)."""
+        qp = np.zeros(1, dtype=np.uint64)
+        n = lib().oracle_chad_grid(self._h, submap, None, None, 0, _p(qp))
+        codes = np.empty(n, dtype=np.uint64)
+        corners = np.empty((n, 8), dtype=np.float32)
+        lib().oracle_chad_grid(self._h, submap, _p(codes), _p(corners), n, _p(qp))
+        return codes, corners, int(qp[0])
 
     @property
     def finalize_ms(self) -> float:

@@ -247,6 +247,45 @@ def test_mesh_of_the_reference_demo_sphere(chad, tmp_path, from_dag):
     m.close()
 
 
+@pytest.mark.parametrize("scene", ["sphere", "cfg2"])
+def test_mesh_grid_is_the_references_chad_grid(chad, oracle, scene):
+    """f3, the half that IS reference code: ChadGrid's constructor (lvr2.cpp:15-133) walks the submap's DAG, makes a query point per
+    leaf at its voxel corner with the de-quantised byte (cluster.hpp:33-52), puts it into the eight cells around it and culls the
+    cells with a missing corner (lvr2.cpp:115-129).  The oracle restates exactly that over its own NodeLevels; the device hands out
+    the grid its mesh kernel cuts (chad_map_mesh_cells).  With the mesh read through the DAG (CHAD_FLAG_MESH_FROM_DAG, what the
+    reference does) the complete-cell sets must be identical and every corner value bit-equal; from the exact means the cell set
+    is the same and a corner differs by at most the 8-bit step.  (The triangulation behind it is LVR2's: parity unpinned.)"""
+    pts, pos = sphere_scan(400_000) if scene == "sphere" else synth.cfg2_frame(300_000)
+    res, trunc = 0.05, 0.10
+    m = chad.TSDFMap(res, trunc, mesh_from_dag=True)
+    m.insert(pts, pos)
+    mc, sd, w = m.export_leaves()
+    m.close_submap()
+    o = oracle.OracleMap(res, trunc)
+    o.close_submap_from_leaves(mc, sd, w)     # the same leaves: the DAGs are word for word the same (test_gpu_finalize.py)
+    assert m.dag_roots(0) == o.dag_roots(0)
+    want_codes, want_corners, query_points = o.chad_grid(0)
+    assert query_points == len(mc) and len(want_codes) > 10_000
+    codes, corners = m.mesh_cells(0)
+    assert np.array_equal(codes, want_codes), "complete-cell sets differ"
+    assert np.array_equal(corners.view(np.uint32), want_corners.view(np.uint32)), "corner values differ from the reference's de-quantisation"
+    m.close()
+    exact = chad.TSDFMap(res, trunc)          # the library's default: the exact means of the dense archive
+    exact.insert(pts, pos)
+    exact.close_submap()
+    codes2, corners2 = exact.mesh_cells(0)
+    assert np.array_equal(codes2, want_codes)
+    assert np.abs(corners2 - want_corners).max() <= trunc / 127 + 1e-6
+    exact.close()
+    # ... and against the oracle's OWN inserts: the same leaf set, hence the same cells; a byte may fall on the other side of a step
+    own = oracle.OracleMap(res, trunc)
+    own.insert(pts, pos)
+    own.close_submap()
+    own_codes, own_corners, _ = own.chad_grid(0)
+    assert np.array_equal(codes, own_codes)
+    assert np.abs(corners - own_corners).max() <= trunc / 127 + 1e-6 and (corners != own_corners).mean() < 2e-3
+
+
 def test_mesh_of_a_room_and_of_the_active_submap(chad):
     """A box room seen from inside: planar walls (every vertex within a voxel of a wall plane), and the active submap (-1) meshes
     like the closed one it becomes."""

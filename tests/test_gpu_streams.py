@@ -213,30 +213,44 @@ def test_cfg5_stream_with_roll_overs_and_table_growth(chad, oracle):
     m.close()
 
 
-def test_cfg5_long_trajectory_keeps_only_the_dag(chad, oracle):
-    """BASELINE config 5 is a 5 000-frame trajectory; what bounds its length is what a closed submap leaves behind.  221 frames of
-    its shape (20 roll-overs) under CHAD_FLAG_DAG_ONLY -- the reference's own policy: a closed submap is its DAG and nothing else --:
-    the device holds the active submap only, however many have been closed, and a submap read back through the DAG at the start,
-    in the middle and at the end of the trajectory is the oracle's (leaf sets exact, signed distances within one byte step)."""
+def test_cfg5_full_trajectory_keeps_only_the_dag(chad, oracle):
+    """BASELINE config 5 at its stated size: 5 000 frames x 200 k points, 0.02 m voxels, 0.06 m truncation, the sensor advancing 0.5 m
+    per frame -- a roll-over every eleven frames, 454 closed submaps -- under CHAD_FLAG_DAG_ONLY, the reference's own policy: a closed
+    submap is its DAG and nothing else (tsdf.cpp:53-54).  Submap::finalize runs on the device (dag_device.hpp): the host fold of
+    earlier rounds needed 0.6 s per submap of this shape.  The frames are made on the device by the generator's torch twin, which
+    is held against the numpy generator on every frame handed to the oracle.
+    Asserts: 454 closed submaps, no overflow, hash load <= 0.5; what the device holds beyond the DAG itself does not grow with the
+    trajectory (frame 500 against frame 4 999); three submaps -- the first, one in the middle, the last -- read back through the DAG
+    are the oracle's: leaf sets exact, signed distances within one byte step of the 8-bit code."""
     import torch
 
-    n_frames = 221
-    m = chad.TSDFMap(0.02, 0.06, max_blocks=1 << 22, dag_only=True)
-    free = {}
+    n_frames, per = 5000, 11
+    m = chad.TSDFMap(0.02, 0.06, max_points=200_000, max_blocks=1 << 22, dag_only=True)
+    held = {}
+    free0 = torch.cuda.mem_get_info()[0]
     for k in range(n_frames):
-        pts, pos = synth.cfg5_frame(k)
+        pts, pos = synth.cfg5_frame_torch(k)
         m.insert(pts, pos)
-        if k in (60, 220):
+        if k in (500, n_frames - 1):
             m.sync()
-            free[k] = torch.cuda.mem_get_info()[0]
-    m.sync()
-    st = m.stats()
-    assert m.closed_submaps == 20 and st["overflow"] == 0 and st["blocks"] / st["hash_capacity"] <= 0.5
-    assert free[60] - free[220] < (1 << 30), "device memory grows with the number of closed submaps"
-    for s in (0, 9, 19):
+            ds = m.dag_stats()   # (folds what has been closed)
+            st = m.stats()
+            assert st["overflow"] == 0 and st["blocks"] / st["hash_capacity"] <= 0.5
+            del pts
+            torch.cuda.empty_cache()
+            held[k] = (free0 - torch.cuda.mem_get_info()[0], ds["device_bytes"], ds["submaps"])
+    assert m.closed_submaps == (n_frames - 1) // per == 454
+    (total_a, dag_a, sub_a), (total_b, dag_b, sub_b) = held[500], held[n_frames - 1]
+    assert sub_a == 45 and sub_b == 454
+    # the DAG itself grows with the trajectory, as the reference's NodeLevels do in host memory; nothing else may
+    assert (total_b - dag_b) - (total_a - dag_a) < (1 << 30), f"device memory beyond the DAG grew by {((total_b - dag_b) - (total_a - dag_a)) / 2**20:.0f} MiB between frame 500 and frame {n_frames - 1}"
+    for s in (0, 227, 453):
         o = oracle.OracleMap(0.02, 0.06)
-        for k in range(11 * s, 11 * s + 11):      # frame 11 s arrives more than 5 m from submap s - 1's first pose and opens submap s
-            o.insert(*synth.cfg5_frame(k))
+        for k in range(per * s, per * s + per):      # frame 11 s arrives more than 5 m from submap s - 1's first pose and opens submap s
+            pts, pos = synth.cfg5_frame(k)
+            dpts, dpos = synth.cfg5_frame_torch(k)
+            assert np.array_equal(dpts.cpu().numpy().view(np.uint32), pts.view(np.uint32)) and np.array_equal(dpos, pos), f"frame {k}: the device generator differs"
+            o.insert(pts, pos)
         omc, osd, _ = o.export_leaves(-1)
         mc, sd = m.dag_leaves(s)
         assert np.array_equal(mc, omc), f"submap {s}"

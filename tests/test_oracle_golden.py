@@ -167,3 +167,32 @@ def test_running_mean_drift_of_the_reference_arithmetic(oracle):
     assert drift[w <= 1000].max() < 2e-5
     assert drift[w <= 4096].max() < 5e-5                 # tests/util.py DRIFT_FREE_WEIGHT
     assert drift.max() > 1e-4                            # ... and past it the reference itself is off by more than the bound
+
+
+def test_chad_grid_is_the_set_of_complete_cells(oracle):
+    """The oracle's restatement of ChadGrid (lvr2.cpp:15-133) against a brute-force numpy statement of the same definition: a cell
+    is kept iff all eight voxels c + {0,1}^3 hold a leaf; its corner values are the de-quantised bytes in the vertex order of
+    lvr2.cpp:92-102."""
+    from chad_tsdf_amd.tsdf import decode_morton
+
+    res, trunc = 0.05, 0.10
+    pts, pos = synth.cfg2_frame(40_000)
+    o = oracle.OracleMap(res, trunc)
+    o.insert(pts, pos)
+    o.close_submap()
+    mc, sd, _ = o.export_leaves(0)
+    codes, corners, query_points = o.chad_grid(0)
+    assert query_points == len(mc)
+    # de-quantised byte per leaf (cluster.hpp:13-26 then :33-52)
+    q = (np.clip(sd * (np.float32(1.0) / np.float32(trunc)), -1, 1).astype(np.float32) * np.float32(127) + np.float32(127)).astype(np.uint8)
+    back = (q.astype(np.float32) - np.float32(127)) * np.float32(1.0 / 127.0) * np.float32(trunc)
+    value = dict(zip(map(tuple, decode_morton(mc).tolist()), back.tolist()))
+    order = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    want = {}
+    for (x, y, z) in value:
+        c = [value.get((x + dx, y + dy, z + dz)) for dx, dy, dz in order]
+        if all(v is not None for v in c):
+            want[(x, y, z)] = c
+    got = dict(zip(map(tuple, decode_morton(codes).tolist()), corners.tolist()))
+    assert got.keys() == want.keys() and len(got) > 5_000
+    assert all(np.array_equal(np.float32(got[k]), np.float32(want[k])) for k in want)
