@@ -360,6 +360,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         max_load = 0.0
+        local.host_times()   # (restart the host-time counters)
         t1 = time.perf_counter()
         if world > 1:
             for k in range(args.stream_frames):
@@ -376,14 +377,41 @@ def main():
         t_stream = time.perf_counter() - t1
         t_stream, t_host = max_over_ranks(t_stream, t_host)
         s3 = local.stats()
+        h3 = local.host_times()
         leg = {"workload": f"{args.stream_frames} frames x {c3['n']} points, corridor 30x8x3 m, voxel 0.05 m, trunc 0.10 m, sensor moving 0.05 m/frame"
                            + (f"; frames round-robin over {world} ranks, block partials merged ({comm.transport}) at every submap close" if world > 1 else ""),
                "scaling": "strong", "n_gpus": world, "ms_per_frame": round(t_stream / args.stream_frames * 1e3, 4),
                "points_per_s": round(args.stream_frames * c3["n"] / t_stream), "host_enqueue_ms_per_frame": round(t_host / args.stream_frames * 1e3, 4),
+               # the host's side of an insert call on this rank, in microseconds per call: its own work (bookkeeping + launches, or one graph
+               # submit), and the time it waited for the device to hand a frame slot back (three frames in flight: the device's pace)
+               "host_us_per_insert": {"work": round(h3["us_host_work"], 2), "wait_for_device": round(h3["us_wait"], 2), "calls": h3["inserts"]},
                "closed_submaps": int(s3["closed_submaps"]), "live_blocks": int(s3["blocks"]), "hash_load": round(s3["blocks"] / s3["hash_capacity"], 5),
                "overflow": int(s3["overflow"])}
         if world == 1:   # the fullest the table gets: right before a roll-over (100 frames into a submap)
             leg["hash_load_max"] = round(max(local.block_count(s) for s in range(int(s3["closed_submaps"]))) / s3["hash_capacity"], 5) if s3["closed_submaps"] else leg["hash_load"]
+        if world > 1:
+            # the same stream on ONE of these GPUs, in this job (rank 0 alone, the others wait): what cfg4's strong scaling is measured against
+            del dev
+            t_one = 0.0
+            if rank == 0:
+                one = TSDFMap(c3["res"], c3["trunc"], max_points=c3["n"])
+                all_frames = [synth.cfg3_frame_torch(k) for k in range(args.stream_frames)]
+                torch.cuda.synchronize()
+                for k in range(min(12, args.stream_frames)):
+                    one.insert(all_frames[k][0], all_frames[k][1], ready=True)
+                one.sync(); one.reset(); one.sync()
+                t1 = time.perf_counter()
+                for k in range(args.stream_frames):
+                    one.insert(all_frames[k][0], all_frames[k][1], ready=True)
+                one.sync()
+                t_one = time.perf_counter() - t1
+                one.close()
+                del all_frames
+            barrier()
+            (t_one,) = max_over_ranks(t_one)
+            leg["one_gpu_same_job_ms_per_frame"] = round(t_one / args.stream_frames * 1e3, 4)
+            leg["speedup_vs_1gpu"] = round(t_one / t_stream, 3)
+            dev = {}
         local.close()
         del dev
         out["cfg4" if world > 1 else "cfg3"] = leg

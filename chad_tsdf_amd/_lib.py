@@ -82,6 +82,10 @@ class DagStats(C.Structure):
     ]
 
 
+class HostTimes(C.Structure):
+    _fields_ = [("inserts", C.c_uint64), ("insert_s", C.c_double), ("wait_s", C.c_double), ("copy_s", C.c_double)]
+
+
 # every symbol include/chad_hip.h declares: name -> (restype, argtypes)
 _vp, _sz, _i32, _f32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_float
 SYMBOLS = {
@@ -114,6 +118,7 @@ SYMBOLS = {
     "chad_map_dag_level_words": (_i32, [_vp, C.c_uint32, C.POINTER(_sz)]),
     "chad_map_dag_level_copy": (_i32, [_vp, C.c_uint32, _vp, _sz]),
     "chad_map_dag_stats": (_i32, [_vp, C.POINTER(DagStats)]),
+    "chad_map_host_times": (_i32, [_vp, C.POINTER(HostTimes)]),
     "chad_map_dag_leaves": (_i32, [_vp, _i32, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_export_clusters": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_iter_begin": (_i32, [_vp, _i32, C.POINTER(_vp)]),

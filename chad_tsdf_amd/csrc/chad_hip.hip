@@ -19,6 +19,7 @@
 #include "comm.hpp"
 #include "dag.hpp"
 #include "dag_device.hpp"
+#include "frame_graph.hpp"
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
 #include "merge_kernels.hpp"
@@ -106,7 +107,16 @@ enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
 // idle) and then the update.  Updates of different frames commute (sums and counts, added atomically), so the streams
 // need no ordering among themselves.  What does need the map to itself -- clearing it, a roll-over, growth, an export --
 // waits for the updates enqueued so far and makes the later ones wait for it (exclusive_begin / exclusive_end below).
+// what a recorded chain of preparation kernels depends on besides its arguments: grids, kernels and buffers
+struct FrameShape {
+    uint32_t count = 0, digit_bits = 0, sort_launches = 0;
+    size_t cap_points = 0;
+    bool operator==(const FrameShape& o) const { return count == o.count && digit_bits == o.digit_bits && sort_launches == o.sort_launches && cap_points == o.cap_points; }
+};
+
 struct FrameSlot {
+    FrameLauncher chain;                // the slot's preparation chain: launched kernel by kernel, or recorded and replayed as a hipGraph (frame_graph.hpp)
+    FrameShape chain_shape;             // ... the shape it was recorded for
     hipStream_t prep = nullptr;
     hipEvent_t update_done = nullptr;   // recorded on `prep` behind its last update when somebody has to wait for it (updates_done)
     bool tail_unrecorded = false;       // frames have been enqueued on `prep` since update_done was last recorded
@@ -141,6 +151,15 @@ struct chad_map {
     uint32_t* d_consumed = nullptr;           // (its device address)
     RadixSortBuffers aux_sort{};        // block-key sorter of exports and of Submap::finalize (never a frame slot's: those belong to frames in flight)
     size_t aux_cap = 0;
+    bool use_graphs = false;            // CHAD_GRAPHS=1: replay a slot's preparation chain as a hipGraph when the frame shape repeats.  Off by default: measured
+                                        // (scripts/graph_ab.py, ROCm 7.2) the replay with every node's arguments replaced costs the host as much as the seven
+                                        // launches it stands for -- 26.9 against 24.5 us of host work per 200 k-point insert, 20.6 against 25.1 at 20 k points --
+                                        // and the streams are paced by the device anyway (the host waits 21-23 us per cfg3 insert for a frame slot)
+    FrameShape last_shape;              // shape of the previous insert's frame (a chain is recorded when a shape turns up twice in a row)
+    // host time of the insert path, cumulative (chad_map_host_times): in the insert calls altogether / of that, waiting for the device to
+    // hand a frame slot back (prepare_slot: the bound of three frames in flight) / of that, in the H2D copy of chad_map_insert
+    double host_insert_s = 0, host_wait_s = 0, host_copy_s = 0;
+    uint64_t host_inserts = 0;
     uint32_t cu_count = 256;            // compute units of the map's device (hipDeviceProp_t::multiProcessorCount): every grid that is sized "per CU" uses it
     TileLaunch tile{};                  // launch shape of the update kernel on this device for this map's resolution / truncation (tile_update.hpp)
     uint32_t sort_resident = 0;         // workgroups of the frame sort's pass kernel the device certainly holds at once (radix_resident_workgroups)
@@ -278,6 +297,7 @@ void free_sort_buffers(RadixSortBuffers& b) {
 }
 
 void free_frame_buffers(FrameSlot& f) {
+    f.chain.destroy();   // (its nodes name the buffers)
     if (f.h_stage) (void)hipHostFree(f.h_stage);
     f.h_stage = nullptr;
     (void)hipFree(f.d_xyz);
@@ -894,6 +914,7 @@ chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
             __builtin_ia32_pause();
 #endif
         }
+        m->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     TRY(ensure_frame_capacity(m, f, n));
     if (m->caller_ready) {  // caller-supplied stream: the caller's work enqueued so far (it may produce the points) comes first
@@ -994,11 +1015,6 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         static const uint32_t forced_bits = std::getenv("CHAD_DEBUG_DIGIT_BITS") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_DIGIT_BITS"))) : 0u;
         const uint32_t key_bits_hint = uint32_t(m->h_live_blocks[2]);
         const uint32_t digit_bits = forced_bits == 8u || forced_bits == 9u ? forced_bits : (key_bits_hint ? radix_digit_bits(key_bits_hint) : uint32_t(kRadixBits));
-        LAUNCH_TIMED(m, CHAD_KERNEL_BOUNDS, k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
-        LAUNCH_TIMED(m, CHAD_KERNEL_KEYS, k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
-                     f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks, digit_bits);
-        record(m, T_CALC, prep);
-        g_host_profile.mark(1);
         // as many single-pass kernels as recent frames needed (hint mirrored by the device into host-mapped memory), the
         // last of them covering whatever else the frame turns out to need (radix_sort.hpp, k_radix_onesweep to_limit)
         // launches: what a key of the reported width needs at this frame's digit width (all eight until a frame has reported)
@@ -1007,22 +1023,62 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                                                : std::min<uint32_t>(uint32_t(kMaxPasses), std::max<uint32_t>(1u, uint32_t(m->h_live_blocks[1]))));
         RadixSortSignals sig;
         sig.fault = m->d_overflow; sig.consumed = m->d_consumed + m->last_slot * 16u; sig.seq = ++f.input_seq;
-        uint32_t pass_launches = 0;
-        if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
-        radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits);
-        g_host_profile.mark(2);
         static const uint32_t big_block = std::getenv("CHAD_DEBUG_BIG_BLOCK") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_BLOCK"))) : kBigBlock;
         static const uint32_t big_groups = std::getenv("CHAD_DEBUG_BIG_GROUPS") ? uint32_t(std::atoi(std::getenv("CHAD_DEBUG_BIG_GROUPS"))) : kNormalBigGroups;
-        const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
-        const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
-        if (times_kernels(m)) m->kev_launched[m->ktimed_end % chad_map::kKernelRing] |= ((1u << pass_launches) - 1u) << CHAD_KERNEL_SORT_PASS0;
-        LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, k_frame_gather, dim3(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk)), dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                     points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
-        record(m, T_SORT, prep);
         static const int normal_waves_per_cu = std::getenv("CHAD_DEBUG_NORMAL_WAVES") ? std::atoi(std::getenv("CHAD_DEBUG_NORMAL_WAVES")) : 20;
         const uint32_t normal_groups = std::max<uint32_t>(2u, m->cu_count * uint32_t(normal_waves_per_cu) / kNormalWaves);
-        LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                     reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
+        const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
+        const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
+        const dim3 gather_grid(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk));
+        if (times_kernels(m) || times_stages(m)) {   // timing modes: every kernel (or stage) bracketed, one launch at a time
+            LAUNCH_TIMED(m, CHAD_KERNEL_BOUNDS, k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
+            LAUNCH_TIMED(m, CHAD_KERNEL_KEYS, k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
+                         f.sort.digit_base, f.sort.tile_status, uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks, digit_bits);
+            record(m, T_CALC, prep);
+            uint32_t pass_launches = 0;
+            if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
+            radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits);
+            if (times_kernels(m)) m->kev_launched[m->ktimed_end % chad_map::kKernelRing] |= ((1u << pass_launches) - 1u) << CHAD_KERNEL_SORT_PASS0;
+            LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, k_frame_gather, gather_grid, dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
+                         points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
+            record(m, T_SORT, prep);
+            LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
+                         reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
+        } else {
+            // The chain of preparation kernels, every launch through the slot's FrameLauncher: launched one by one, or -- when the
+            // frame has the shape of the one recorded for this slot (same size, digit width, pass count, buffers) -- replayed as a
+            // hipGraph with this frame's arguments (frame_graph.hpp: one submit instead of seven to nine).
+            auto chain = [&](FrameLauncher& L) {
+                L(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
+                L(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.digit_base, f.sort.tile_status,
+                  uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks, digit_bits);
+                radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, &L);
+                L(k_frame_gather, gather_grid, dim3(256), 0, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1], points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start,
+                  list_stride, sig.consumed, sig.seq, big_block);
+                L(k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
+                  reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
+            };
+            const FrameShape shape{count, digit_bits, hint, f.cap_points};
+            FrameLauncher& L = f.chain;
+            L.stream = prep;
+            bool submitted = false;
+            if (m->use_graphs && L.recorded() && f.chain_shape == shape) {
+                L.begin_update();
+                chain(L);
+                hipError_t e = hipSuccess;
+                submitted = L.end_update_and_launch(&e);
+                if (submitted) HIP_TRY(e);
+                else L.destroy();   // another kernel or grid than recorded (the sort's residency share has changed ...): forget the recording
+            } else if (m->use_graphs && shape == m->last_shape) {   // the second frame of this shape in a row: worth recording
+                if (L.begin_build() == hipSuccess) {
+                    chain(L);
+                    if (L.end_build() == hipSuccess) { f.chain_shape = shape; HIP_TRY(hipGraphLaunch(L.exec, prep)); submitted = true; }
+                }
+                if (!submitted) { (void)hipGetLastError(); L.destroy(); }
+            }
+            if (!submitted) { L.mode = FrameLauncher::kEager; chain(L); }
+            m->last_shape = shape;
+        }
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
         record(m, T_CALC, prep); record(m, T_SORT, prep); if (times_stages(m)) record(m, T_NORM, prep);
@@ -1136,6 +1192,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
     m->fixed_capacity = (o.flags & CHAD_FLAG_FIXED_CAPACITY) != 0;
     m->dag_on_host = std::getenv("CHAD_DEBUG_DAG_HOST") != nullptr;
+    if (const char* e = std::getenv("CHAD_GRAPHS")) m->use_graphs = std::atoi(e) != 0;
     if (const char* e = std::getenv("CHAD_STAGE_MODE")) m->stage_mode = !std::strcmp(e, "staged") ? 1 : !std::strcmp(e, "direct") ? 2 : 0;
     if (const char* e = std::getenv("CHAD_STAGE_DIRECT_KB")) m->stage_direct_from = size_t(std::max(0, std::atoi(e))) << 10;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
@@ -1284,12 +1341,19 @@ void chad_map_destroy(chad_map* m) {
     delete m;
 }
 
+struct InsertTimer {   // host time of one insert call into chad_map::host_insert_s
+    chad_map* m; std::chrono::steady_clock::time_point t0;
+    explicit InsertTimer(chad_map* map) : m(map), t0(std::chrono::steady_clock::now()) {}
+    ~InsertTimer() { if (m) { m->host_insert_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); m->host_inserts++; } }
+};
+
 // frame-sharded map: is insert number stream_frames (counted from the attach) this rank's?  Counts the insert.
 static bool owns_next_frame(chad_map* m) { return int32_t(m->stream_frames++ % uint64_t(m->comm->world)) == m->comm->rank; }
 
 chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t n, const float position[3]) {
     g_host_profile.begin();
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    InsertTimer timed(m);
     DeviceGuard guard(m->device);
     if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
     if (!n) return insert_nothing(m, position);
@@ -1301,6 +1365,7 @@ chad_status chad_map_insert_device(chad_map* m, const float* xyz_device, size_t 
 chad_status chad_map_insert_device_stream(chad_map* m, const float* xyz_device, size_t n, const float position[3], void* producer_stream) {
     g_host_profile.begin();
     if (!m || !position || (n && !xyz_device)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    InsertTimer timed(m);
     DeviceGuard guard(m->device);
     if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
     if (!n) return insert_nothing(m, position);
@@ -1318,6 +1383,7 @@ chad_status chad_map_insert_device_stream(chad_map* m, const float* xyz_device, 
 
 chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float position[3]) {
     if (!m || !position || (n && !xyz)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    InsertTimer timed(m);
     DeviceGuard guard(m->device);
     if (is_sharded(m) && !owns_next_frame(m)) n = 0;   // another rank integrates this frame; the pose is recorded here too
     if (!n) return insert_nothing(m, position);
@@ -1335,7 +1401,9 @@ chad_status chad_map_insert(chad_map* m, const float* xyz, size_t n, const float
     const bool direct = m->stage_mode == 2 || (m->stage_mode == 0 && n * 12 >= m->stage_direct_from);
     if (direct) {
         // f.d_xyz is free: the frame that used this slot before has read its input for the last time (prepare_slot waited for the device's word)
+        const auto t0 = std::chrono::steady_clock::now();
         HIP_TRY(hipMemcpy(f.d_xyz, xyz, n * 12, hipMemcpyHostToDevice));
+        m->host_copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } else {
         if (!f.h_stage) HIP_TRY(hipHostMalloc(&f.h_stage, f.cap_points * 12, hipHostMallocDefault));
         else HIP_TRY(hipEventSynchronize(f.stage_done));  // its previous frame (n_slots inserts ago) has left the buffer
@@ -1493,6 +1561,13 @@ chad_status chad_map_stats(chad_map* m, chad_stats* out) {
     out->sort_passes = last_empty ? 0 : m->h_hdr->sort_passes; out->overflow = overflow;
     out->ms_mc_calc = m->ms[T_CALC]; out->ms_mc_sort = m->ms[T_SORT]; out->ms_norm_est = m->ms[T_NORM];
     out->ms_oct_upd = m->ms[T_UPD]; out->ms_total = m->ms[T_BEGIN];
+    return CHAD_OK;
+}
+
+chad_status chad_map_host_times(chad_map* m, chad_host_times* out) {
+    if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    out->inserts = m->host_inserts; out->insert_s = m->host_insert_s; out->wait_s = m->host_wait_s; out->copy_s = m->host_copy_s;
+    m->host_inserts = 0; m->host_insert_s = m->host_wait_s = m->host_copy_s = 0;
     return CHAD_OK;
 }
 

@@ -17,6 +17,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include "frame_graph.hpp"
+
 namespace chadhip {
 
 constexpr int kRadixBits = 8;
@@ -415,8 +417,11 @@ k_radix_onesweep_rest(uint64_t* __restrict__ keys0, typename P::T* __restrict__ 
 template <class P>
 inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
                                   uint32_t hist_blocks, uint32_t launch_passes, const void* first_src,
-                                  const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits) {
+                                  const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits, FrameLauncher* recorder = nullptr) {
     if (n == 0) return;
+    FrameLauncher eager;   // (the launches go through `recorder` when the caller records or replays its chain as a graph: frame_graph.hpp)
+    eager.stream = stream;
+    FrameLauncher& L = recorder && !sig.pass_events ? *recorder : eager;
     const uint32_t tiles = radix_tiles(n);
     const bool all_resident = b.resident != 0u && tiles <= b.resident;
     uint32_t* ticket = b.tile_status + radix_status_words(tiles) - 64;
@@ -444,19 +449,19 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
                 hipExtLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, sig.pass_events[2 * p], sig.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
                                       to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
             else
-                hipLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                                   to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
+                L(kernel, dim3(tiles), dim3(kSortThreads), 0, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                  to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
         };
         if (digit_bits == uint32_t(kWideBits)) launch(k_radix_onesweep<P, kWideBits>); else launch(k_radix_onesweep<P, kRadixBits>);
     }
     if (with_rest) {
         const uint32_t grid = tiles < b.resident ? tiles : b.resident;
         if (digit_bits == uint32_t(kWideBits))
-            hipLaunchKernelGGL((k_radix_onesweep_rest<P, kWideBits>), dim3(grid), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
-                               base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
+            L(k_radix_onesweep_rest<P, kWideBits>, dim3(grid), dim3(kSortThreads), 0, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
+              base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
         else
-            hipLaunchKernelGGL((k_radix_onesweep_rest<P, kRadixBits>), dim3(grid), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
-                               base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
+            L(k_radix_onesweep_rest<P, kRadixBits>, dim3(grid), dim3(kSortThreads), 0, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
+              base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
     }
     if (sig.launches_out) *sig.launches_out = launches;
 }
@@ -465,8 +470,8 @@ inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t p
     radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr, sig);
 }
 inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                      uint32_t hist_blocks, uint32_t launch_passes, const RadixSortSignals& sig, uint32_t digit_bits) {
-    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, sig, digit_bits);
+                                      uint32_t hist_blocks, uint32_t launch_passes, const RadixSortSignals& sig, uint32_t digit_bits, FrameLauncher* recorder = nullptr) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, sig, digit_bits, recorder);
 }
 // Workgroups of a pass kernel the device holds at once: the kernel's real occupancy (registers, LDS) x CU count, with a quarter
 // held back (the runtime's answer can exceed what the hardware admits by one per CU -- MI355X_MICROARCH.md, Residency).

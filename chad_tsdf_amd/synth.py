@@ -152,3 +152,10 @@ def cfg5_frame_torch(k: int, n: int | None = None, device="cuda"):
     lo = (np.asarray(c["lo"]) + p).tolist()
     hi = (np.asarray(c["hi"]) + p).tolist()
     return box_scan_torch(c["n"] if n is None else n, lo, hi, p.tolist(), 5000 + k, device), p.astype(np.float32)
+
+
+def cfg3_frame_torch(k: int, n: int | None = None, device="cuda"):
+    """cfg3_frame(k) made on the device."""
+    c = CFG3
+    sensor = (-12.0 + 0.05 * k, 0.1, 0.0)
+    return box_scan_torch(c["n"] if n is None else n, list(c["lo"]), list(c["hi"]), list(sensor), 1000 + k, device), np.asarray(sensor, dtype=np.float32)

@@ -184,6 +184,15 @@ class TSDFMap:
         _lib.check(self._lib.chad_map_stats(self._h, C.byref(st)), "TSDFMap.stats")
         return {name: getattr(st, name) for name, _ in _lib.Stats._fields_}
 
+    def host_times(self) -> dict:
+        """Host time of the insert calls since the last call: per insert in microseconds -- all of it, the wait for a frame slot (the device's
+        pace), the H2D copy of host frames, and the rest (the host's own work: bookkeeping and launches)."""
+        t = _lib.HostTimes()
+        _lib.check(self._lib.chad_map_host_times(self._h, C.byref(t)), "TSDFMap.host_times")
+        n = max(1, int(t.inserts))
+        return {"inserts": int(t.inserts), "us_per_insert": t.insert_s / n * 1e6, "us_wait": t.wait_s / n * 1e6, "us_copy": t.copy_s / n * 1e6,
+                "us_host_work": (t.insert_s - t.wait_s - t.copy_s) / n * 1e6}
+
     def kernel_times(self) -> dict:
         """Mean duration (ms) and launch count of every kernel of the insert pipeline since the last call (time_kernels=True)."""
         kt = _lib.KernelTimes()

@@ -48,6 +48,15 @@ int main() {
         CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
         CK(hipEventElapsedTime(&ms, e0, e1));
         std::printf("spin %4d  graph:    host %.1f us per chain, device %.1f us per chain\n", spin, std::chrono::duration<double, std::micro>(t1 - t0).count() / reps, ms * 1e3 / reps);
+        // (c) every node's parameters updated before every launch (what a frame's chain needs without a parameter block: pointer, pose,
+        //     sequence number and table change from frame to frame)
+        t0 = std::chrono::steady_clock::now();
+        CK(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; r++) { add = float(r); for (int k = 0; k < chain; k++) CK(hipGraphExecKernelNodeSetParams(ge, nodes[k], &p)); CK(hipGraphLaunch(ge, s)); }
+        t1 = std::chrono::steady_clock::now();
+        CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::printf("spin %4d  graph, all %d nodes updated: host %.1f us per chain, device %.1f us per chain\n", spin, chain, std::chrono::duration<double, std::micro>(t1 - t0).count() / reps, ms * 1e3 / reps);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     return 0;

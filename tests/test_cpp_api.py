@@ -26,6 +26,28 @@ def test_reference_style_program_compiles_and_links(tmp_path):
     assert os.path.exists(_build(str(tmp_path)))
 
 
+def _build_overloads(out_dir):
+    """The glm / Eigen overloads (reference tsdf.hpp:68-115) against test-only stand-ins for the two headers (tests/cpp/shims)."""
+    if not os.path.exists(os.path.join(LIB_DIR, "libchad_hip.so")):
+        subprocess.check_call(["make", "-C", ROOT, "-s"])
+    cxx = shutil.which("g++") or "/opt/rocm/bin/hipcc"
+    exe = os.path.join(out_dir, "overloads_check")
+    subprocess.check_call([cxx, "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp", "shims"),
+                           os.path.join(ROOT, "tests", "cpp", "overloads_check.cpp"), "-o", exe, "-L", LIB_DIR, "-lchad_hip",
+                           "-L/opt/rocm/lib", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_glm_and_eigen_overloads_compile(tmp_path):
+    assert os.path.exists(_build_overloads(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_glm_and_eigen_overloads_build_the_same_map(tmp_path):
+    run = subprocess.run([_build_overloads(str(tmp_path)), "30000"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("ok"), run.stdout + run.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_class_builds_the_oracles_map(tmp_path):
     from chad_tsdf_amd import synth

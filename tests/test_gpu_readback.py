@@ -278,12 +278,17 @@ def test_mesh_grid_is_the_references_chad_grid(chad, oracle, scene):
     assert np.abs(corners2 - want_corners).max() <= trunc / 127 + 1e-6
     exact.close()
     # ... and against the oracle's OWN inserts: the same leaf set, hence the same cells; a byte may fall on the other side of a step
+    # (the signed distances agree to 1e-4 * trunc, not bit for bit).  On the sphere that is rare; the box room's walls lie exactly on
+    # voxel faces, so whole planes of voxels sit at signed distances of exactly -res / 2, 0, +res / 2 ..., i.e. on the half-way points
+    # of the byte code (-0.05 m -> 63.5): there a difference in the last bit decides the byte, and a quarter of the corners flip
     own = oracle.OracleMap(res, trunc)
     own.insert(pts, pos)
     own.close_submap()
     own_codes, own_corners, _ = own.chad_grid(0)
     assert np.array_equal(codes, own_codes)
-    assert np.abs(corners - own_corners).max() <= trunc / 127 + 1e-6 and (corners != own_corners).mean() < 2e-3
+    assert np.abs(corners - own_corners).max() <= trunc / 127 + 1e-6
+    if scene == "sphere":
+        assert (corners != own_corners).mean() < 2e-3
 
 
 def test_mesh_of_a_room_and_of_the_active_submap(chad):
