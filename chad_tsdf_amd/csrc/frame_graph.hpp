@@ -1,12 +1,10 @@
 // frame_graph.hpp -- one submit for a frame's chain of preparation kernels.
 //
 // An insert enqueues bounds -> keys -> two or three sort passes (-> a catch-all) -> gather -> normals on the frame slot's stream:
-// seven to nine launches at 3-4 us of host time each.  That is nothing beside a 1 M-point frame (0.09 ms), but a stream of small frames
-// is paced by it (cfg3: 0.05 ms per 200 k-point frame, all of it the host; a rank of eight in cfg4 has 54 us of host calls per eight
-// frames against 57 us of device time), and frames of a few ten thousand points are bound by it outright.  So the chain is
-// recorded once per frame slot as a hipGraph -- a linear chain of kernel nodes -- and replayed with every node's arguments replaced
-// (hipGraphExecKernelNodeSetParams: input pointer, pose, sequence number and table change from frame to frame; grids and kernels
-// do not, as long as the frame size, the sort's digit width and its pass count stay what they were).
+// seven to nine launches at about 3 us of host time each.  The idea: record the chain once per frame slot as a hipGraph -- a linear
+// chain of kernel nodes -- and replay it with every node's arguments replaced (hipGraphExecKernelNodeSetParams: input pointer,
+// pose, sequence number and table change from frame to frame; grids and kernels do not, as long as the frame size, the sort's digit
+// width and its pass count stay what they were).
 //
 // MEASURED (scripts/graph_ab.py, MI355X, ROCm 7.2): no gain, so the replay is opt-in (CHAD_GRAPHS=1).  A chain of eight trivial kernels
 // costs the host 24 us launched one by one, 9.3 us as a graph and 11.6 us with all eight nodes' arguments replaced
