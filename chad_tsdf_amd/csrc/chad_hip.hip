@@ -202,6 +202,14 @@ struct chad_map {
     Dag dag;                                      // tsdf.cpp:30 (_node_levels_p): one DAG for all submaps, built lazily (chad_map_finalize).  With the fold on the
                                                   // device (the default) this is the host's MIRROR of the level arrays, brought up to date by dag_host()
     DeviceDag ddag;                               // ... the stores and their look-up tables themselves (dag_device.hpp)
+    DagFold fold;                                 // the fold in flight (at most one): closed submap number dag_roots.size()
+    bool folding = false;
+    bool in_fold_setup = false;                   // close_into_dag is setting the fold up (it uses the auxiliary sorter itself)
+    hipStream_t fold_stream = nullptr;            // CHAD_FLAG_DAG_ONLY roll-overs: cluster words and the fold run here, beside the frames and beside the map's
+                                                  // stream (whose next roll-over must not queue behind a fold of several milliseconds)
+    hipEvent_t fold_t0 = nullptr, fold_t1 = nullptr;   // device time of the fold in flight
+    hipEvent_t spare_cleared = nullptr;           // recorded on fold_stream behind the clear of a table that was handed back as the spare
+    bool spare_cleared_pending = false;           // ... the map's stream has not waited for it yet
     bool dag_on_host = false;                     // CHAD_DEBUG_DAG_HOST: the sequential host fold of dag.hpp instead (what the tests hold the device fold against)
     bool dag_mirror_stale = false;
     std::vector<std::array<uint32_t, 2>> dag_roots;  // submap.hpp:108-109 of the closed submaps folded so far (a prefix of `closed`)
@@ -322,6 +330,7 @@ chad_status join_streams(chad_map* m) {
     }
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) HIP_TRY(hipStreamSynchronize(f.prep));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));
     return CHAD_OK;
 }
 
@@ -377,7 +386,11 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
 
 // The (key, index) sorter of exports and finalize: buffers of its own, so that no frame slot is ever borrowed (a slot's buffers
 // belong to a frame that may still be in flight, and growing them would free a frame's staged points).  Used on the map's stream only.
+chad_status fold_advance(chad_map* m, bool block);   // (with Submap::finalize, further down)
 chad_status ensure_aux_sort(chad_map* m, size_t n) {
+    if (m->folding && !m->in_fold_setup) {   // a fold in flight sorted with these buffers on its own stream: the map's stream may have them when it is done
+        while (m->folding) TRY(fold_advance(m, true));
+    }
     if (n <= m->aux_cap) return CHAD_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
     size_t cap = std::max<size_t>(n, m->aux_cap * 2);
@@ -515,6 +528,14 @@ chad_status release_finalized(chad_map* m) {
 // archive, compact the table into it and clear it -- all on the map's stream, beside the frames that already fill the new
 // active table -- and keep the cleared table as the next spare.
 chad_status merge_advance(chad_map* m, bool block);   // (below: the multi-GPU form of the same second half)
+chad_status fold_advance(chad_map* m, bool block);    // (with Submap::finalize, further down)
+chad_status fold_archived(chad_map* m);
+chad_status close_into_dag(chad_map* m, uint32_t blocks);
+// the map's stream is about to use the spare table: behind its clear, wherever that ran
+inline chad_status spare_ready(chad_map* m) {
+    if (m->spare_cleared_pending) { HIP_TRY(hipStreamWaitEvent(m->stream, m->spare_cleared, 0)); m->spare_cleared_pending = false; }
+    return CHAD_OK;
+}
 chad_status finish_closing(chad_map* m, bool block) {
     if (!m->closing) return CHAD_OK;
     if (m->closing_comm) return merge_advance(m, block);
@@ -522,6 +543,8 @@ chad_status finish_closing(chad_map* m, bool block) {
     else if (hipEventQuery(m->closing_counted) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
     uint32_t blocks = 0;
     for (uint32_t k = 0; k < kCountStripes; k++) blocks += m->closing_count[k * 16];
+    // CHAD_FLAG_DAG_ONLY: no dense copy at all -- cluster words straight from the table, folded into the DAG beside the next frames
+    if ((m->flags & CHAD_FLAG_DAG_ONLY) && !m->dag_on_host) return close_into_dag(m, blocks);
     Submap s;
     if (m->flags & CHAD_FLAG_DAG_ONLY) TRY(borrow_submap(m, s, blocks)); else TRY(alloc_submap(s, blocks));
     if (blocks) {
@@ -559,6 +582,7 @@ chad_status close_active(chad_map* m) {
         }
         m->has_spare = true;
     }
+    TRY(spare_ready(m));
     TRY(exclusive_begin(m));               // the map's stream waits for every update enqueued so far ...
     HIP_TRY(hipMemcpyAsync(m->closing_count, m->view.brick_count, kCountStripes * 64, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipEventRecord(m->closing_counted, m->stream));
@@ -594,6 +618,7 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
         }
         m->has_spare = true;
     }
+    TRY(spare_ready(m));
     TRY(exclusive_begin(m));               // the map's stream waits for every update enqueued so far ...
     HIP_TRY(hipMemcpyAsync(m->closing_count, m->view.brick_count, kCountStripes * 64, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipEventRecord(m->closing_counted, m->stream));
@@ -852,7 +877,10 @@ chad_status grow_if_needed(chad_map* m) {
     if (live < m->brick_capacity / 2) return CHAD_OK;
     TRY(finish_closing(m, true));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->has_spare) { free_map_storage(m, m->spare); m->has_spare = false; }   // the next roll-over allocates one of the new size
+    if (m->has_spare) {   // the next roll-over allocates one of the new size
+        if (m->spare_cleared_pending) { HIP_TRY(hipEventSynchronize(m->spare_cleared)); m->spare_cleared_pending = false; }
+        free_map_storage(m, m->spare); m->has_spare = false;
+    }
     MapView bigger;
     const uint64_t blocks = std::min<uint64_t>(uint64_t(m->brick_capacity) * 2, 1ull << 30);
     const chad_status s = alloc_map_storage(m, bigger, blocks, m->stream);
@@ -996,6 +1024,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     g_host_profile.mark(8);
     TRY(note_pose(m, position));
     TRY(finish_closing(m, false));   // a roll-over's archive, once its size is known (never waits)
+    if (m->folding) TRY(fold_advance(m, false));   // ... and its fold into the DAG, a stage at a time (CHAD_FLAG_DAG_ONLY)
     m->frames_empty_tail = 0;
 
     TRY(grow_if_needed(m));
@@ -1251,6 +1280,9 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_consumed), const_cast<uint32_t*>(m->h_consumed), 0));
     CREATE_TRY(hipEventCreateWithFlags(&m->producer_ready, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->merge_event, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&m->spare_cleared, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreate(&m->fold_t0)); CREATE_TRY(hipEventCreate(&m->fold_t1));
+    if (m->serial) m->fold_stream = nullptr; else CREATE_TRY(hipStreamCreateWithFlags(&m->fold_stream, hipStreamNonBlocking));
     CREATE_TRY(hipHostMalloc(&m->merge_host, 32 * 8));
     // what the look-back sort may assume about residency: the pass kernel's real occupancy, shared among the frames in flight
     m->sort_resident = radix_resident_workgroups<PointPayload>();
@@ -1278,6 +1310,7 @@ void chad_map_destroy(chad_map* m) {
     orphan_iterators(m);   // iterators that outlive the map report invalid instead of dangling
     DeviceGuard guard(m->device);
     if (m->closing_comm) (void)finish_closing(m, true);   // an exchange in flight is collective: this rank's remaining stages are issued before the map goes
+    if (m->fold_stream) (void)hipStreamSynchronize(m->fold_stream);
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     g_host_profile.report();
@@ -1324,6 +1357,11 @@ void chad_map_destroy(chad_map* m) {
     if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
     free_sort_buffers(m->aux_sort);
     m->ddag.release();
+    if (m->fold.ready) (void)hipEventDestroy(m->fold.ready);
+    if (m->fold_t0) (void)hipEventDestroy(m->fold_t0);
+    if (m->fold_t1) (void)hipEventDestroy(m->fold_t1);
+    if (m->spare_cleared) (void)hipEventDestroy(m->spare_cleared);
+    if (m->fold_stream) (void)hipStreamDestroy(m->fold_stream);
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
     if (m->closing_counted) (void)hipEventDestroy(m->closing_counted);
     if (m->closing_count) (void)hipHostFree(m->closing_count);
@@ -1449,6 +1487,7 @@ chad_status chad_map_sync(chad_map* m) {
     DeviceGuard guard(m->device);
     uint32_t overflow = 0;
     TRY(finish_closing(m, true));   // a roll-over's archive (or exchange: every rank syncs at the same point) is part of "all enqueued work"
+    while (m->folding) TRY(fold_advance(m, true));   // ... and so is its fold into the DAG (CHAD_FLAG_DAG_ONLY)
     TRY(read_back_header(m, &overflow));
     if (overflow & kSortFaultStalled) (void)hipMemset(m->d_overflow, 0, 4);   // reported once (every stream is idle here); capacity flags stay until a reset
     if (overflow & kSortFaultStalled) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors (workgroups not dispatched in index order?): at least one frame was sorted incompletely");
@@ -1461,6 +1500,7 @@ chad_status chad_map_reset(chad_map* m) {
     HostProfileScope profiled(7);
     DeviceGuard guard(m->device);
     TRY(finish_closing(m, true));
+    while (m->folding) TRY(fold_advance(m, true));
     if (!m->closed.empty()) {
         TRY(join_streams(m));
         for (auto& s : m->closed) free_submap(s);
@@ -1484,6 +1524,7 @@ chad_status chad_map_reset(chad_map* m) {
             else { free_map_storage(m, m->spare); m->spare_unaffordable = true; g_error.clear(); }
         }
         if (m->has_spare) {
+            TRY(spare_ready(m));
             HIP_TRY(hipMemsetAsync(m->spare.overflow, 0, 4, m->stream));   // the spare table's own flag (no frame is using that table)
             TRY(exclusive_end(m, m->stream));   // later updates wait for the map's stream up to HERE: the spare's own clear lies before this point
             TRY(exclusive_begin(m));            // ... and the old table's clear waits for every update enqueued so far, nobody waits for it
@@ -1801,8 +1842,85 @@ chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum,
 }
 
 // Fold the submaps closed since the last call into the DAG, in closing order (the order the reference finalizes them in).
+// The fold in flight, one stage further if its numbers have arrived (block: wait for them).  When it completes, the submap's roots join
+// dag_roots and the host's mirror of the level arrays is stale.
+chad_status fold_advance(chad_map* m, bool block) {
+    if (!m->folding) return CHAD_OK;
+    hipStream_t s = m->fold_stream ? m->fold_stream : m->stream;
+    bool done = false;
+    uint32_t root_tsdf = 0, root_weight = 0;
+    const int stage_before = m->fold.stage;
+    HIP_TRY(dag_fold_advance(m->ddag, m->fold, s, block, &done, &root_tsdf, &root_weight));
+    if (m->fold.stage == 3 && stage_before == 2) HIP_TRY(hipEventRecord(m->fold_t1, s));   // (behind the last stage's kernels)
+    if (!done) return CHAD_OK;
+    float t = 0;
+    if (hipEventElapsedTime(&t, m->fold_t0, m->fold_t1) == hipSuccess) m->dag_ms_device = t; else (void)hipGetLastError();
+    m->dag_roots.push_back({root_tsdf, root_weight});
+    m->dag_mirror_stale = true;
+    m->folding = false;
+    return CHAD_OK;
+}
+
+// CHAD_FLAG_DAG_ONLY, second half of a roll-over: the closing table's block count is on the host.  Its bricks become cluster words
+// straight from the table (k_table_clusters: no dense copy is ever made), the table is cleared and handed back as the spare, the
+// words are put in key order and the fold into the DAG is begun -- all on the fold's own stream, beside the frames and beside the
+// map's stream; the fold's later stages are enqueued by the inserts that follow (fold_advance).  Nothing here waits for the device
+// unless the previous submap's fold is still in flight (it shares the scratch).
+chad_status close_into_dag(chad_map* m, uint32_t blocks) {
+    TRY(fold_archived(m));   // the previous submap's fold, and submaps closed by other routes: the DAG takes them in closing order
+    hipStream_t s = m->fold_stream ? m->fold_stream : m->stream;
+    const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
+    const size_t nb = std::max<uint32_t>(blocks, 1);
+    const size_t words = nb * 8;
+    const size_t need = 2 * Arena::padded(nb * 8) + (saturate ? 4 : 2) * Arena::padded(words * 8);
+    if (need > m->cluster_arena.cap) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipStreamSynchronize(m->stream)); }   // (the arena is about to move)
+    HIP_TRY(m->cluster_arena.reserve(need));
+    uint64_t* raw_keys = m->cluster_arena.take<uint64_t>(nb);
+    uint64_t* raw_tsdf = m->cluster_arena.take<uint64_t>(words);
+    uint64_t* raw_weight = saturate ? m->cluster_arena.take<uint64_t>(words) : nullptr;
+    uint64_t* keys = m->cluster_arena.take<uint64_t>(nb);
+    uint64_t* tsdf = m->cluster_arena.take<uint64_t>(words);
+    uint64_t* weight = saturate ? m->cluster_arena.take<uint64_t>(words) : nullptr;
+    m->in_fold_setup = true;
+    const chad_status sorter = blocks ? ensure_aux_sort(m, blocks) : CHAD_OK;
+    m->in_fold_setup = false;
+    TRY(sorter);
+    if (s != m->stream) HIP_TRY(hipStreamWaitEvent(s, m->closing_counted, 0));   // behind the closing table's last update (the count was copied behind them)
+    HIP_TRY(hipEventRecord(m->fold_t0, s));
+    if (blocks) {
+        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
+        hipLaunchKernelGGL(k_table_clusters, dim3(512), dim3(256), 0, s, m->closing_view, m->d_cursor, blocks, m->trunc, 1.0f / m->trunc /* submap.hpp:23 */, raw_keys, raw_tsdf, raw_weight);
+    }
+    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, s, m->closing_view, 0u);
+    HIP_TRY(hipGetLastError());
+    if (s != m->stream) { HIP_TRY(hipEventRecord(m->spare_cleared, s)); m->spare_cleared_pending = true; }
+    m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: spare_ready() makes the map's stream wait for it
+    m->closing_view = MapView{}; m->closing = false;
+    if (blocks) {   // key order (all eight digits: full 63-bit codes), the rows gathered behind the keys
+        RadixSortSignals sig;
+        sig.fault = m->d_overflow;
+        hipLaunchKernelGGL(k_copy_u64, grid_for(blocks), dim3(256), 0, s, raw_keys, m->aux_sort.keys[0], blocks);
+        radix_sort_enqueue(m->aux_sort, blocks, kMaxPasses, nullptr, s, 0, 0, sig);
+        HIP_TRY(hipMemcpyAsync(keys, m->aux_sort.keys[0], size_t(blocks) * 8, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_gather_clusters, grid_for(size_t(blocks) * 8), dim3(256), 0, s, (const uint32_t*)m->aux_sort.idx[0], blocks, raw_tsdf, raw_weight, tsdf, weight);
+        HIP_TRY(hipGetLastError());
+    }
+    Submap gone;   // a closed submap without bricks: it is its DAG (read back with chad_map_dag_leaves, the iterator, the mesh from the DAG)
+    gone.blocks = blocks; gone.released = true;
+    m->closed.push_back(gone);
+    HIP_TRY(dag_fold_begin(m->ddag, m->fold, keys, tsdf, weight, blocks, s));
+    m->folding = true;
+    return CHAD_OK;
+}
+
+// Fold the submaps closed since the last call into the DAG, in closing order (the order the reference finalizes them in).
 chad_status finalize_closed(chad_map* m) {
     TRY(finish_closing(m, true));
+    return fold_archived(m);
+}
+// ... those that were archived as dense copies (the default; the exchange's result; a closing without a spare table), start to finish
+chad_status fold_archived(chad_map* m) {
+    while (m->folding) TRY(fold_advance(m, true));
     if (m->dag_roots.size() >= m->closed.size()) return CHAD_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
     const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
@@ -1823,7 +1941,7 @@ chad_status finalize_closed(chad_map* m) {
             HIP_TRY(hipEventRecord(ev.e0, m->stream));
             DeviceClusters dc;
             TRY(device_cluster_words(m, s.keys, s.sum, s.cnt, s.blocks, saturate, dc));
-            HIP_TRY(dag_device_add_submap(m->ddag, dc.keys, dc.tsdf, saturate ? dc.weight : nullptr, s.blocks, m->stream, &root_tsdf, &root_weight));
+            HIP_TRY(dag_device_add_submap(m->ddag, m->fold, dc.keys, dc.tsdf, saturate ? dc.weight : nullptr, s.blocks, m->stream, &root_tsdf, &root_weight));
             HIP_TRY(hipEventRecord(ev.e1, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
             float t = 0;

@@ -631,13 +631,27 @@ inline void dag_batch(DeviceDag& d, uint32_t l, const void* cand, uint32_t n, ui
 }
 
 // Fold one submap: keys[nb] ascending block keys, tsdf[8 nb] / weight[8 nb] (null: the reference's all-ones weights) cluster words, all
-// on the device.  Synchronises the stream twice (block totals + per-level node counts in the middle, roots + scalars at the end).
-inline hipError_t dag_device_add_submap(DeviceDag& d, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, uint32_t nb, hipStream_t s,
-                                        uint32_t* root_tsdf, uint32_t* root_weight) {
+// on the device and left alone until the fold is done.  The fold needs numbers on the host twice on its way (how many blocks hold
+// leaves; how many nodes every level gets) and once at its end (the roots, the levels' sizes): three stages, each enqueued when the
+// previous stage's numbers have arrived -- dag_fold_advance(block = false) never waits, so a roll-over's fold rides beside the next
+// frames (the insert path polls it); block = true waits for the stage's event.
+struct DagFold {
+    int stage = 0;   // 0: idle; 1: step 0 enqueued (block totals on their way); 2: cluster level + level histogram enqueued; 3: node levels enqueued
+    const uint64_t* keys = nullptr; const uint64_t* tsdf = nullptr; const uint64_t* weight = nullptr;
+    uint32_t nb = 0, saturate = 0, nbv = 0, octets = 0;
+    uint64_t* vkeys = nullptr; uint32_t* vblock = nullptr; uint32_t* oct_before = nullptr;
+    uint64_t* ccand = nullptr; uint32_t* cpos = nullptr; uint32_t* caddr = nullptr;
+    unsigned long long* sums = nullptr; uint8_t* new_words = nullptr;
+    struct LevelScratch { uint64_t* prefix; uint32_t* children; uint32_t* pos; uint32_t* addr; uint32_t* head_pos; } ls[2] = {};
+    hipEvent_t ready = nullptr;   // behind the device-to-host copy of the current stage's numbers
+};
+
+inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, uint32_t nb, hipStream_t s) {
     hipError_t e;
     if ((e = dag_device_init(d, s)) != hipSuccess) return e;
-    const uint32_t saturate = weight ? 1u : 0u;
-    const size_t cc_ub = saturate ? size_t(16) * nb : size_t(8) * nb + 2;       // cluster candidates at most
+    if (!f.ready && (e = hipEventCreateWithFlags(&f.ready, hipEventDisableTiming)) != hipSuccess) return e;
+    f.keys = keys; f.tsdf = tsdf; f.weight = weight; f.nb = nb; f.saturate = weight ? 1u : 0u; f.nbv = f.octets = 0;
+    const size_t cc_ub = f.saturate ? size_t(16) * nb : size_t(8) * nb + 2;       // cluster candidates at most
     const size_t chunks_ub = (std::max<size_t>(cc_ub, 2 * size_t(nb) + 2) + kDagChunk - 1) / kDagChunk + 1;
     auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
     const size_t nbp = size_t(nb) + 1;
@@ -651,96 +665,125 @@ inline hipError_t dag_device_add_submap(DeviceDag& d, const uint64_t* keys, cons
     }
     size_t used = 0;
     auto take = [&](size_t bytes) { void* p = d.arena + used; used += padded(bytes); return p; };
-    uint64_t* vkeys = static_cast<uint64_t*>(take(nbp * 8));
-    uint32_t* vblock = static_cast<uint32_t*>(take(nbp * 4));
-    uint32_t* oct_before = static_cast<uint32_t*>(take(nbp * 4));
-    uint64_t* ccand = static_cast<uint64_t*>(take(cc_ub * 8));
-    uint32_t* cpos = static_cast<uint32_t*>(take(cc_ub * 4));
-    uint32_t* caddr = static_cast<uint32_t*>(take(cc_ub * 4));
-    unsigned long long* sums = static_cast<unsigned long long*>(take(chunks_ub * 8));
-    uint8_t* new_words = static_cast<uint8_t*>(take(std::max<size_t>(cc_ub, 2 * nbp)));
-    struct LevelScratch { uint64_t* prefix; uint32_t* children; uint32_t* pos; uint32_t* addr; uint32_t* head_pos; } ls[2];
-    for (auto& x : ls) {
+    f.vkeys = static_cast<uint64_t*>(take(nbp * 8));
+    f.vblock = static_cast<uint32_t*>(take(nbp * 4));
+    f.oct_before = static_cast<uint32_t*>(take(nbp * 4));
+    f.ccand = static_cast<uint64_t*>(take(cc_ub * 8));
+    f.cpos = static_cast<uint32_t*>(take(cc_ub * 4));
+    f.caddr = static_cast<uint32_t*>(take(cc_ub * 4));
+    f.sums = static_cast<unsigned long long*>(take(chunks_ub * 8));
+    f.new_words = static_cast<uint8_t*>(take(std::max<size_t>(cc_ub, 2 * nbp)));
+    for (auto& x : f.ls) {
         x.prefix = static_cast<uint64_t*>(take(nbp * 8)); x.children = static_cast<uint32_t*>(take(nbp * 64));
         x.pos = static_cast<uint32_t*>(take(nbp * 8)); x.addr = static_cast<uint32_t*>(take(nbp * 8)); x.head_pos = static_cast<uint32_t*>(take((nbp + 1) * 4));
     }
-
-    // step 0: the blocks that hold leaves, the cluster candidates, the number of nodes per level
+    // step 0: the blocks that hold leaves, the cluster candidates
     const uint32_t bchunks = (nb + kDagChunk - 1) / kDagChunk;
-    uint32_t nbv = 0, octets = 0;
-    uint32_t level_nodes[kDagDepth] = {};
+    *reinterpret_cast<volatile unsigned long long*>(d.h_small) = 0ull;
     if (nb) {
-        hipLaunchKernelGGL(k_dag_block_sums, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, tsdf, nb, sums);
-        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, bchunks, d.d_total);
-        hipLaunchKernelGGL(k_dag_block_apply, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, keys, tsdf, weight, nb, saturate, sums, vkeys, vblock, oct_before, ccand);
+        hipLaunchKernelGGL(k_dag_block_sums, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, tsdf, nb, f.sums);
+        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, bchunks, d.d_total);
+        hipLaunchKernelGGL(k_dag_block_apply, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, keys, tsdf, weight, nb, f.saturate, f.sums, f.vkeys, f.vblock, f.oct_before, f.ccand);
         if ((e = hipMemsetAsync(d.d_hist, 0, 128, s)) != hipSuccess) return e;
-        // (the histogram needs the number of valid blocks: it is at most nb, and entries beyond it are never written -- so count over vkeys
-        //  only after the total is known: one small round trip, which also gives every later launch its exact size)
         if ((e = hipMemcpyAsync(d.h_small, d.d_total, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-        const unsigned long long t = *reinterpret_cast<unsigned long long*>(d.h_small);
-        nbv = uint32_t(t >> 32); octets = uint32_t(t);
     }
-    if (nbv) {
-        hipLaunchKernelGGL(k_dag_parted_histogram, dag_grid(nbv, 256, 1024), dim3(256), 0, s, vkeys, nbv, d.d_hist);
-        if ((e = hipMemcpyAsync(d.h_small + 16, d.d_hist, 128, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    }
-    // the cluster level meanwhile (its size is known)
-    const uint32_t ncc = octets ? (saturate ? 2u * octets : octets + 1u) : 0u;
-    if ((e = dag_level_reserve(d, kDagDepth, ncc, 1, s)) != hipSuccess) return e;
-    if (ncc) dag_batch(d, kDagDepth, ccand, ncc, cpos, caddr, new_words, sums, d.d_total + 1, saturate ? 0ull : (unsigned long long)(octets - 1u), s);
-    if (nbv) {
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-        uint32_t running = 1;   // n_d = 1 + #{blocks that part from their predecessor at a depth below d}
-        for (uint32_t dd = 0; dd < kDagDepth; dd++) { level_nodes[dd] = running; running += d.h_small[16 + dd]; }
-    }
-    // level 19, then upwards
-    uint32_t cur = 0;
-    if (nbv) {
-        hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, tsdf, vblock, oct_before, nbv, saturate, caddr, ls[cur].children);
-        hipLaunchKernelGGL(k_dag_block_prefix, dag_grid(nbv), dim3(256), 0, s, vkeys, nbv, ls[cur].prefix);
-        if ((e = dag_level_reserve(d, kDagDepth - 1, 2 * size_t(nbv), 9, s)) != hipSuccess) return e;
-        dag_batch(d, kDagDepth - 1, ls[cur].children, 2 * nbv, ls[cur].pos, ls[cur].addr, new_words, sums, d.d_total + 2, 0ull, s);
-    }
-    uint32_t n_below = nbv;
-    uint32_t* d_roots = d.d_hist + 24;   // (two spare words behind the histogram's twenty)
-    bool fused = false;
-    for (int dd = int(kDagDepth) - 2; dd >= 0; dd--) {
-        if (n_below <= kDagSmall) {   // this level and everything above it in one launch (node counts only shrink towards the root)
-            DagLevelsArg arg{};
-            for (int u = dd; u >= 0; u--) {
-                const uint32_t parents_u = nbv ? level_nodes[u] : (u == 0 ? 1u : 0u);
-                if ((e = dag_level_reserve(d, uint32_t(u), 2 * size_t(parents_u), 9, s)) != hipSuccess) return e;
-            }
-            for (uint32_t u = 0; u < kDagDepth; u++) {
-                arg.table[u] = d.level[u].table; arg.raw[u] = static_cast<uint32_t*>(d.level[u].raw);
-                arg.mask[u] = d.level[u].table_slots - 1; arg.capacity[u] = d.level[u].raw_capacity;
-            }
-            hipLaunchKernelGGL(k_dag_small_levels, dim3(1), dim3(1024), 0, s, arg, d.d_scalars, dd, n_below, ls[cur].prefix, ls[cur].addr, d_roots);
-            fused = true;
-            break;
-        }
-        const uint32_t parents = level_nodes[dd];   // (n_below > kDagSmall: the submap is not empty)
-        LevelScratch& below = ls[cur];
-        LevelScratch& here = ls[cur ^ 1];
-        const uint32_t chunks = (n_below + kDagChunk - 1) / kDagChunk;
-        hipLaunchKernelGGL(k_dag_head_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums);
-        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, d.d_total + 3);
-        hipLaunchKernelGGL(k_dag_head_apply, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, sums, here.head_pos, here.prefix, parents);
-        hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents, below.addr, here.children);
-        if ((e = dag_level_reserve(d, uint32_t(dd), 2 * size_t(parents), 9, s)) != hipSuccess) return e;
-        dag_batch(d, uint32_t(dd), here.children, 2 * parents, here.pos, here.addr, new_words, sums, d.d_total + 4, 0ull, s);
-        n_below = parents;
-        cur ^= 1;
-    }
-    // roots and the levels' scalars
-    if ((e = hipMemcpyAsync(d.h_small + 64, fused ? d_roots : ls[cur].addr, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(d.h_small + 128, d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    if ((e = hipEventRecord(f.ready, s)) != hipSuccess) return e;
+    f.stage = 1;
+    return hipSuccess;
+}
+
+// One stage further if its numbers are there (block: wait for them).  *done: the fold is complete, roots valid, d.h_scalars up to date.
+inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool block, bool* done, uint32_t* root_tsdf, uint32_t* root_weight) {
+    hipError_t e;
+    *done = false;
+    if (f.stage == 0) return hipSuccess;
+    if (block) { if ((e = hipEventSynchronize(f.ready)) != hipSuccess) return e; }
+    else if (hipEventQuery(f.ready) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
+    uint32_t* d_roots = d.d_hist + 24;   // (two spare words behind the histogram's twenty)
+    if (f.stage == 1) {
+        const unsigned long long t = *reinterpret_cast<volatile unsigned long long*>(d.h_small);
+        f.nbv = uint32_t(t >> 32); f.octets = uint32_t(t);
+        // how many nodes every level gets (a small round trip that gives every later launch its exact size), and the cluster level meanwhile
+        if (f.nbv) {
+            hipLaunchKernelGGL(k_dag_parted_histogram, dag_grid(f.nbv, 256, 1024), dim3(256), 0, s, f.vkeys, f.nbv, d.d_hist);
+            if ((e = hipMemcpyAsync(d.h_small + 16, d.d_hist, 128, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        }
+        const uint32_t ncc = f.octets ? (f.saturate ? 2u * f.octets : f.octets + 1u) : 0u;
+        if ((e = dag_level_reserve(d, kDagDepth, ncc, 1, s)) != hipSuccess) return e;
+        if (ncc) dag_batch(d, kDagDepth, f.ccand, ncc, f.cpos, f.caddr, f.new_words, f.sums, d.d_total + 1, f.saturate ? 0ull : (unsigned long long)(f.octets - 1u), s);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipEventRecord(f.ready, s)) != hipSuccess) return e;
+        f.stage = 2;
+        return hipSuccess;
+    }
+    if (f.stage == 2) {
+        uint32_t level_nodes[kDagDepth] = {};
+        const uint32_t nbv = f.nbv;
+        if (nbv) {
+            uint32_t running = 1;   // n_d = 1 + #{blocks that part from their predecessor at a depth below d}
+            for (uint32_t dd = 0; dd < kDagDepth; dd++) { level_nodes[dd] = running; running += d.h_small[16 + dd]; }
+        }
+        // level 19, then upwards
+        uint32_t cur = 0;
+        DagFold::LevelScratch* ls = f.ls;
+        if (nbv) {
+            hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, f.tsdf, f.vblock, f.oct_before, nbv, f.saturate, f.caddr, ls[cur].children);
+            hipLaunchKernelGGL(k_dag_block_prefix, dag_grid(nbv), dim3(256), 0, s, f.vkeys, nbv, ls[cur].prefix);
+            if ((e = dag_level_reserve(d, kDagDepth - 1, 2 * size_t(nbv), 9, s)) != hipSuccess) return e;
+            dag_batch(d, kDagDepth - 1, ls[cur].children, 2 * nbv, ls[cur].pos, ls[cur].addr, f.new_words, f.sums, d.d_total + 2, 0ull, s);
+        }
+        uint32_t n_below = nbv;
+        bool fused = false;
+        for (int dd = int(kDagDepth) - 2; dd >= 0; dd--) {
+            if (n_below <= kDagSmall) {   // this level and everything above it in one launch (node counts only shrink towards the root)
+                DagLevelsArg arg{};
+                for (int u = dd; u >= 0; u--) {
+                    const uint32_t parents_u = nbv ? level_nodes[u] : (u == 0 ? 1u : 0u);
+                    if ((e = dag_level_reserve(d, uint32_t(u), 2 * size_t(parents_u), 9, s)) != hipSuccess) return e;
+                }
+                for (uint32_t u = 0; u < kDagDepth; u++) {
+                    arg.table[u] = d.level[u].table; arg.raw[u] = static_cast<uint32_t*>(d.level[u].raw);
+                    arg.mask[u] = d.level[u].table_slots - 1; arg.capacity[u] = d.level[u].raw_capacity;
+                }
+                hipLaunchKernelGGL(k_dag_small_levels, dim3(1), dim3(1024), 0, s, arg, d.d_scalars, dd, n_below, ls[cur].prefix, ls[cur].addr, d_roots);
+                fused = true;
+                break;
+            }
+            const uint32_t parents = level_nodes[dd];   // (n_below > kDagSmall: the submap is not empty)
+            DagFold::LevelScratch& below = ls[cur];
+            DagFold::LevelScratch& here = ls[cur ^ 1];
+            const uint32_t chunks = (n_below + kDagChunk - 1) / kDagChunk;
+            hipLaunchKernelGGL(k_dag_head_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, f.sums);
+            hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, chunks, d.d_total + 3);
+            hipLaunchKernelGGL(k_dag_head_apply, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, f.sums, here.head_pos, here.prefix, parents);
+            hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents, below.addr, here.children);
+            if ((e = dag_level_reserve(d, uint32_t(dd), 2 * size_t(parents), 9, s)) != hipSuccess) return e;
+            dag_batch(d, uint32_t(dd), here.children, 2 * parents, here.pos, here.addr, f.new_words, f.sums, d.d_total + 4, 0ull, s);
+            n_below = parents;
+            cur ^= 1;
+        }
+        // roots and the levels' scalars
+        if ((e = hipMemcpyAsync(d.h_small + 64, fused ? d_roots : ls[cur].addr, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(d.h_small + 128, d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipEventRecord(f.ready, s)) != hipSuccess) return e;
+        f.stage = 3;
+        return hipSuccess;
+    }
     *root_tsdf = d.h_small[64]; *root_weight = d.h_small[65];
     std::memcpy(d.h_scalars, d.h_small + 128, sizeof(d.h_scalars));
+    f.stage = 0;
+    *done = true;
     return hipSuccess;
+}
+
+// ... start to finish
+inline hipError_t dag_device_add_submap(DeviceDag& d, DagFold& f, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, uint32_t nb, hipStream_t s,
+                                        uint32_t* root_tsdf, uint32_t* root_weight) {
+    hipError_t e = dag_fold_begin(d, f, keys, tsdf, weight, nb, s);
+    for (bool done = false; e == hipSuccess && !done;) e = dag_fold_advance(d, f, s, true, &done, root_tsdf, root_weight);
+    return e;
 }
 
 // The host's mirror of the stores (what dag_walk / DagCursor / chad_map_dag_level_copy read): the words added since the last call.

@@ -301,6 +301,30 @@ k_gather_bricks(const uint32_t* __restrict__ order, uint32_t count, const uint64
 // host.  Weight byte: min(count, 254), again 0xff for none; only written when out_weight is given (the reference
 // itself stores 0xff for every weight -- Q6, submap.hpp:93 -- which needs no array).
 // One wave per brick: lane = cell, 2 x 256 B read, 64 B (+ 64 B) written.  HBM-bound: 520 B in, 72-136 B out per brick.
+// the two bytes of one voxel (cluster.hpp:13-26 under -ffp-contract=off; 0xff: no leaf, cluster.hpp:28-31, 62-65)
+__device__ __forceinline__ void cluster_bytes(float sum, uint32_t n, float trunc_recip, uint32_t* sd_bits, uint32_t* w_bits) {
+    *sd_bits = 0xffu; *w_bits = 0xffu;
+    if (n) {
+        float sd = sum / float(n);                                      // the mean, as chad_map_export_leaves reports it
+        sd = fminf(fmaxf(sd * trunc_recip, -1.0f), 1.0f);
+        sd = sd * 127.0f + 127.0f;
+        *sd_bits = uint32_t(sd);
+        *w_bits = n < 254u ? n : 254u;
+    }
+}
+// lane 8o + i holds byte i of word o: the eight bytes OR-ed together within each group of eight lanes; valid in lanes 8o
+__device__ __forceinline__ void cluster_words(uint32_t lane, uint32_t sd_bits, uint32_t w_bits, uint64_t* tsdf, uint64_t* weight) {
+    const uint32_t shift = (lane & 3u) * 8u;
+    uint32_t t_lo = (lane & 4u) ? 0u : sd_bits << shift, t_hi = (lane & 4u) ? sd_bits << shift : 0u;
+    uint32_t w_lo = (lane & 4u) ? 0u : w_bits << shift, w_hi = (lane & 4u) ? w_bits << shift : 0u;
+#pragma unroll
+    for (uint32_t d = 1; d < 8; d <<= 1) {
+        t_lo |= __shfl_xor(t_lo, d); t_hi |= __shfl_xor(t_hi, d);
+        w_lo |= __shfl_xor(w_lo, d); w_hi |= __shfl_xor(w_hi, d);
+    }
+    *tsdf = uint64_t(t_hi) << 32 | t_lo; *weight = uint64_t(w_hi) << 32 | w_lo;
+}
+
 __global__ void __launch_bounds__(256)
 k_leaf_clusters(const uint32_t* __restrict__ order, uint32_t count, const uint64_t* __restrict__ brick_key,
                 const float* __restrict__ brick_sum, const uint32_t* __restrict__ brick_cnt, float trunc_recip,
@@ -310,28 +334,13 @@ k_leaf_clusters(const uint32_t* __restrict__ order, uint32_t count, const uint64
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t k = wave; k < count; k += waves) {
         const uint32_t b = order ? order[k] : k;
-        const float sum = brick_sum[size_t(b) * 64 + lane];
-        const uint32_t n = brick_cnt[size_t(b) * 64 + lane];
-        uint32_t sd_bits = 0xffu, w_bits = 0xffu;
-        if (n) {
-            float sd = sum / float(n);                                      // the mean, as chad_map_export_leaves reports it
-            sd = fminf(fmaxf(sd * trunc_recip, -1.0f), 1.0f);
-            sd = sd * 127.0f + 127.0f;
-            sd_bits = uint32_t(sd);
-            w_bits = n < 254u ? n : 254u;
-        }
-        // lane 8o + i holds byte i of word o: OR the eight bytes together within each group of eight lanes
-        const uint32_t shift = (lane & 3u) * 8u;
-        uint32_t t_lo = (lane & 4u) ? 0u : sd_bits << shift, t_hi = (lane & 4u) ? sd_bits << shift : 0u;
-        uint32_t w_lo = (lane & 4u) ? 0u : w_bits << shift, w_hi = (lane & 4u) ? w_bits << shift : 0u;
-#pragma unroll
-        for (uint32_t d = 1; d < 8; d <<= 1) {
-            t_lo |= __shfl_xor(t_lo, d); t_hi |= __shfl_xor(t_hi, d);
-            w_lo |= __shfl_xor(w_lo, d); w_hi |= __shfl_xor(w_hi, d);
-        }
+        uint32_t sd_bits, w_bits;
+        cluster_bytes(brick_sum[size_t(b) * 64 + lane], brick_cnt[size_t(b) * 64 + lane], trunc_recip, &sd_bits, &w_bits);
+        uint64_t t, w;
+        cluster_words(lane, sd_bits, w_bits, &t, &w);
         if ((lane & 7u) == 0) {
-            out_tsdf[size_t(k) * 8 + (lane >> 3)] = uint64_t(t_hi) << 32 | t_lo;
-            if (out_weight) out_weight[size_t(k) * 8 + (lane >> 3)] = uint64_t(w_hi) << 32 | w_lo;
+            out_tsdf[size_t(k) * 8 + (lane >> 3)] = t;
+            if (out_weight) out_weight[size_t(k) * 8 + (lane >> 3)] = w;
         }
         if (lane == 0) out_key[k] = brick_key[b];
     }
@@ -409,6 +418,78 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
             }
         }
         if (queued) copy_queued();
+    }
+}
+
+// CHAD_FLAG_DAG_ONLY: a closed submap is its DAG and nothing else, so its bricks go from the table straight to cluster words -- what
+// k_compact_bricks (f32 sum with one rounding, count) followed by k_leaf_clusters would deliver, bit for bit, without the dense copy in
+// between (0.85 GB written and read again per cfg5 submap).  In no particular order: the keys are sorted afterwards and the 64-byte
+// rows gathered (k_gather_clusters).
+__global__ void __launch_bounds__(256)
+k_table_clusters(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, float trunc, float trunc_recip, uint64_t* __restrict__ out_key,
+                 uint64_t* __restrict__ out_tsdf, uint64_t* __restrict__ out_weight) {
+    const double metres_per_unit = double(trunc) / double(kSumOne);
+    const bool pack_only = table_pack_only(m);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t words = (m.hash_mask >> 5) + 1u;
+    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u) {
+        const uint32_t word = w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
+        uint64_t holders = __ballot(word != 0u);
+        if (!holders) continue;
+        uint32_t total = uint32_t(__popc(word));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(cursor, total);
+        k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
+        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, queued = 0;
+        auto emit_queued = [&]() {   // four bricks' loads in flight together (as k_compact_bricks)
+            const uint32_t slot[4] = {q0, q1, q2, q3};
+            long long units[4]; uint32_t count[4]; uint64_t key[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (i < queued && k + i < capacity) {
+                    voxel_totals(m, size_t(slot[i]) * 64 + lane, &units[i], &count[i], pack_only);
+                    if (lane == 0) key[i] = m.hash_keys[slot[i]];
+                }
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (i < queued && k + i < capacity) {
+                    const float sum = (count[i] & kPoisonedCount) ? __int_as_float(0x7fc00000) : float(double(units[i]) * metres_per_unit);   // k_compact_bricks' archive value
+                    uint32_t sd_bits, w_bits;
+                    cluster_bytes(sum, count[i] & ~kPoisonedCount, trunc_recip, &sd_bits, &w_bits);
+                    uint64_t t, w;
+                    cluster_words(lane, sd_bits, w_bits, &t, &w);
+                    if ((lane & 7u) == 0) {
+                        out_tsdf[size_t(k + i) * 8 + (lane >> 3)] = t;
+                        if (out_weight) out_weight[size_t(k + i) * 8 + (lane >> 3)] = w;
+                    }
+                    if (lane == 0) out_key[k + i] = key[i];
+                }
+            k += queued;
+            queued = 0;
+        };
+        for (; holders; holders &= holders - 1ull) {
+            const uint32_t l = uint32_t(__ffsll((unsigned long long)holders)) - 1u;
+            for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u) {
+                const uint32_t slot = (w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u;
+                if (queued == 0) q0 = slot; else if (queued == 1) q1 = slot; else if (queued == 2) q2 = slot; else q3 = slot;
+                if (++queued == 4) emit_queued();
+            }
+        }
+        if (queued) emit_queued();
+    }
+}
+// rows of eight cluster words in the order given by `order` (one thread per word)
+__global__ void __launch_bounds__(256)
+k_gather_clusters(const uint32_t* __restrict__ order, uint32_t count, const uint64_t* __restrict__ in_tsdf, const uint64_t* __restrict__ in_weight,
+                  uint64_t* __restrict__ out_tsdf, uint64_t* __restrict__ out_weight) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < size_t(count) * 8; i += size_t(gridDim.x) * blockDim.x) {
+        const size_t from = size_t(order[i >> 3]) * 8 + (i & 7);
+        out_tsdf[i] = in_tsdf[from];
+        if (out_weight) out_weight[i] = in_weight[from];
     }
 }
 
