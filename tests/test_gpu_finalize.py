@@ -194,3 +194,38 @@ def test_dag_only_mode_releases_closed_bricks_and_keeps_the_dag(chad):
     a.sync()
     assert a.closed_submaps == 5 and a.dag_stats()["submaps"] == 5
     assert torch.cuda.mem_get_info()[0] >= free_before - (64 << 20)   # no archive copies pile up (they are ~10 MB each here)
+
+
+@pytest.mark.parametrize("saturate", [False, True])
+def test_device_fold_equals_the_host_fold(chad, monkeypatch, saturate):
+    """Submap::finalize runs on the device (dag_device.hpp: per level, probe / scan / commit / resolve against tables that live in
+    HBM; the upper levels in one launch).  The sequential host fold of dag.hpp (CHAD_DEBUG_DAG_HOST=1), which test_dag_host.py holds
+    against the oracle without a GPU, must give the same DAG word for word: all 21 level arrays, the roots of every submap, the
+    uniques / dupes counters -- over several submaps that share the DAG, an empty submap first and last, and a stream submap large
+    enough for four levels to take the general (many-workgroup) path."""
+    def build(host):
+        if host:
+            monkeypatch.setenv("CHAD_DEBUG_DAG_HOST", "1")
+        else:
+            monkeypatch.delenv("CHAD_DEBUG_DAG_HOST", raising=False)
+        m = chad.TSDFMap(0.05, 0.10, dag_saturate_weights=saturate)
+        zero = np.zeros(3, np.float32)
+        m.insert(np.zeros((0, 3), np.float32), zero); m.close_submap()            # an empty submap: a childless root pair (submap.hpp:29-44)
+        for f in range(2):
+            pts, pos = synth.cfg2_frame(250_000, seed=2 + f, sensor=(0.3 + 0.4 * f, -0.2, 0.1))
+            m.insert(pts, pos); m.close_submap()
+        for k in range(0, 60, 2):
+            m.insert(*synth.cfg3_frame(k, 50_000))
+        m.close_submap()
+        m.insert(np.zeros((0, 3), np.float32), zero); m.close_submap()
+        m.finalize()
+        out = ([m.dag_level(l) for l in range(21)], [m.dag_roots(s) for s in range(m.closed_submaps)], m.dag_stats())
+        m.close()
+        return out
+
+    (dl, dr, ds), (hl, hr, hs) = build(False), build(True)
+    assert dr == hr and len(dr) == 5
+    for l in range(21):
+        assert np.array_equal(dl[l], hl[l]), f"level {l}"
+    assert list(ds["uniques"]) == list(hs["uniques"]) and list(ds["dupes"]) == list(hs["dupes"])
+    assert ds["device_bytes"] > 0
