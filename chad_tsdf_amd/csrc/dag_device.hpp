@@ -114,14 +114,14 @@ __device__ __forceinline__ unsigned long long dag_block_value(const uint64_t* __
     for (uint32_t o = 0; o < 8; o++) octets += tsdf[size_t(b) * 8 + o] != kClusterEmpty ? 1u : 0u;
     return octets ? (1ull << 32) | octets : 0ull;   // a brick that was claimed but never written has no counterpart in the octree (dag.hpp)
 }
+constexpr uint32_t kDagBlockChunk = 256;   // blocks per workgroup step of the two block kernels: one block (64 bytes of cluster words) per thread
 __global__ void __launch_bounds__(256)
 k_dag_block_sums(const uint64_t* __restrict__ tsdf, uint32_t nb, unsigned long long* __restrict__ sums) {
-    const uint32_t chunks = (nb + kDagChunk - 1) / kDagChunk;
+    const uint32_t chunks = (nb + kDagBlockChunk - 1) / kDagBlockChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        unsigned long long mine = 0;
-        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t b = c * kDagChunk + threadIdx.x * kDagPer + j; if (b < nb) mine += dag_block_value(tsdf, b); }
+        const uint32_t b = c * kDagBlockChunk + threadIdx.x;
         unsigned long long total;
-        dag_block_scan(mine, &total);
+        dag_block_scan(b < nb ? dag_block_value(tsdf, b) : 0ull, &total);
         if (threadIdx.x == 0) sums[c] = total;
     }
 }
@@ -133,26 +133,26 @@ __global__ void __launch_bounds__(256)
 k_dag_block_apply(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tsdf, const uint64_t* __restrict__ weight, uint32_t nb, uint32_t saturate,
                   const unsigned long long* __restrict__ sums, uint64_t* __restrict__ vkeys, uint32_t* __restrict__ vblock, uint32_t* __restrict__ oct_before,
                   uint64_t* __restrict__ cand) {
-    const uint32_t chunks = (nb + kDagChunk - 1) / kDagChunk;
+    const uint32_t chunks = (nb + kDagBlockChunk - 1) / kDagBlockChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        unsigned long long v[kDagPer], mine = 0;
-        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t b = c * kDagChunk + threadIdx.x * kDagPer + j; v[j] = b < nb ? dag_block_value(tsdf, b) : 0ull; mine += v[j]; }
+        const uint32_t b = c * kDagBlockChunk + threadIdx.x;
+        uint64_t t[8];
+        uint32_t octets = 0;
+#pragma unroll
+        for (uint32_t o = 0; o < 8; o++) { t[o] = b < nb ? tsdf[size_t(b) * 8 + o] : kClusterEmpty; octets += t[o] != kClusterEmpty ? 1u : 0u; }
+        const unsigned long long v = octets ? (1ull << 32) | octets : 0ull;
         unsigned long long total;
-        unsigned long long at = sums[c] + dag_block_scan(mine, &total);
-        for (uint32_t j = 0; j < kDagPer; j++) {
-            if (!v[j]) continue;
-            const uint32_t b = c * kDagChunk + threadIdx.x * kDagPer + j;
-            const uint32_t rank = uint32_t(at >> 32);
-            uint32_t k = uint32_t(at);
-            vkeys[rank] = keys[b]; vblock[rank] = b; oct_before[rank] = k;
-            for (uint32_t o = 0; o < 8; o++) {
-                const uint64_t t = tsdf[size_t(b) * 8 + o];
-                if (t == kClusterEmpty) continue;
-                if (saturate) { cand[2 * size_t(k)] = t; cand[2 * size_t(k) + 1] = weight[size_t(b) * 8 + o]; }
-                else { cand[k ? k + 1 : 0] = t; if (!k) cand[1] = kClusterEmpty; }
-                k++;
-            }
-            at += v[j];
+        const unsigned long long at = sums[c] + dag_block_scan(v, &total);
+        if (!v) continue;
+        const uint32_t rank = uint32_t(at >> 32);
+        uint32_t k = uint32_t(at);
+        vkeys[rank] = keys[b]; vblock[rank] = b; oct_before[rank] = k;
+#pragma unroll
+        for (uint32_t o = 0; o < 8; o++) {
+            if (t[o] == kClusterEmpty) continue;
+            if (saturate) { cand[2 * size_t(k)] = t[o]; cand[2 * size_t(k) + 1] = weight[size_t(b) * 8 + o]; }
+            else { cand[k ? k + 1 : 0] = t[o]; if (!k) cand[1] = kClusterEmpty; }
+            k++;
         }
     }
 }
@@ -652,7 +652,7 @@ inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys,
     if (!f.ready && (e = hipEventCreateWithFlags(&f.ready, hipEventDisableTiming)) != hipSuccess) return e;
     f.keys = keys; f.tsdf = tsdf; f.weight = weight; f.nb = nb; f.saturate = weight ? 1u : 0u; f.nbv = f.octets = 0;
     const size_t cc_ub = f.saturate ? size_t(16) * nb : size_t(8) * nb + 2;       // cluster candidates at most
-    const size_t chunks_ub = (std::max<size_t>(cc_ub, 2 * size_t(nb) + 2) + kDagChunk - 1) / kDagChunk + 1;
+    const size_t chunks_ub = std::max<size_t>((std::max<size_t>(cc_ub, 2 * size_t(nb) + 2) + kDagChunk - 1) / kDagChunk, (size_t(nb) + kDagBlockChunk - 1) / kDagBlockChunk) + 1;
     auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
     const size_t nbp = size_t(nb) + 1;
     const size_t need = padded(nbp * 8) + 2 * padded(nbp * 4) + padded(cc_ub * 8) + 2 * padded(cc_ub * 4) + padded(chunks_ub * 8) + padded(std::max<size_t>(cc_ub, 2 * nbp)) +
@@ -678,7 +678,7 @@ inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys,
         x.pos = static_cast<uint32_t*>(take(nbp * 8)); x.addr = static_cast<uint32_t*>(take(nbp * 8)); x.head_pos = static_cast<uint32_t*>(take((nbp + 1) * 4));
     }
     // step 0: the blocks that hold leaves, the cluster candidates
-    const uint32_t bchunks = (nb + kDagChunk - 1) / kDagChunk;
+    const uint32_t bchunks = (nb + kDagBlockChunk - 1) / kDagBlockChunk;
     *reinterpret_cast<volatile unsigned long long*>(d.h_small) = 0ull;
     if (nb) {
         hipLaunchKernelGGL(k_dag_block_sums, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, tsdf, nb, f.sums);

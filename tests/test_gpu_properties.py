@@ -383,3 +383,33 @@ def test_scatter_staging_folds_at_the_default_threshold(chad, oracle, monkeypatc
     m.close()
     folds = [int(line.split()[-1]) for line in capfd.readouterr().err.splitlines() if line.startswith("chad: staging folds")]
     assert folds and folds[-1] >= 1
+
+
+def test_two_maps_on_two_threads(chad):
+    """A map is one host thread's at a time, but distinct maps are independent (the reference's contract): nothing in the library is
+    process-wide any more -- the update kernel's launch shape is the map's (resolution, truncation, device), not a static cache.  Two
+    threads, each with a map of its own (different voxel sizes, hence different tile shapes) inserting at the same time, must build
+    exactly the maps they build alone."""
+    import threading
+
+    frames = [synth.cfg2_frame(150_000, seed=30 + k, sensor=(0.2 * k, 0.0, 0.0)) for k in range(6)]
+    params = [(0.05, 0.10), (0.04, 0.12)]
+
+    def build(res, trunc, out, key):
+        m = chad.TSDFMap(res, trunc)
+        for pts, pos in frames:
+            m.insert(pts, pos)
+        out[key] = m.export_leaves()
+        m.close()
+
+    alone, together = {}, {}
+    for i, (res, trunc) in enumerate(params):
+        build(res, trunc, alone, i)
+    threads = [threading.Thread(target=build, args=(res, trunc, together, i)) for i, (res, trunc) in enumerate(params)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        for got, want in zip(together[i], alone[i]):   # codes, signed distances (bit for bit: the sums are integers), weights
+            assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"map {i}"
