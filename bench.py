@@ -202,11 +202,14 @@ def main():
     algo_bytes = 24 * args.points + 16 * n_voxels  # K7 = 24 B/point + 16 B/distinct voxel
     upd_ms = float(st["ms_oct_upd"])
     achieved = algo_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")  # written from a separate rocprofv3 --pmc run
+    traffic, traffic_source = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")  # written from separate rocprofv3 --pmc passes (scripts/collect_profiles.sh)
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_file))
+            traffic = pmc.get("hbm_bytes_per_launch")
+            traffic_source = {"file": "profiles/pmc_update_kernel.json", "tag": pmc.get("tag"), "measured_on_commit": pmc.get("measured_on_commit"),
+                              "reads": "request sizes (32/64/128 B)" if pmc.get("read_bytes_from_request_sizes") else "FETCH_SIZE doubled"}
         except Exception:
             traffic = None
 
@@ -242,6 +245,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": round(upd_ms, 4),
         },

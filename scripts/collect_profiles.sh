@@ -18,6 +18,14 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" --
 echo "write done"
 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/tcc" -- python3 bench.py --steps 6 --warmup 2 $B > "$out/bench_tcc.log" 2>&1
 echo "tcc done"
+# the L2's memory-side read requests by size: 32 x n32 + 64 x n64 + 128 x n128 are the bytes read, whatever the access pattern (FETCH_SIZE
+# tallies this chip's 128-byte requests at 64 bytes: MI355X_MICROARCH.md "HBM"; scripts/calib_fetch.hip holds both against a known byte count)
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$out/rdreq" -- python3 bench.py --steps 6 --warmup 2 $B > "$out/bench_rdreq.log" 2>&1
+echo "rdreq done"
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/calib_fetch scripts/calib_fetch.hip
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib_fetch" -- /tmp/calib_fetch > "$out/calib_fetch.log" 2>&1
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$out/calib_rdreq" -- /tmp/calib_fetch > "$out/calib_rdreq.log" 2>&1
+echo "calibration done"
 # cfg5 (outdoor shape, the scatter form of the update): kernel trace and the same counters for 40 frames of scripts/outdoor_bench.py
 O="scripts/outdoor_bench.py --frames 40"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cfg5_trace" -- python3 $O > "$out/cfg5_trace.log" 2>&1
@@ -25,4 +33,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/cfg5_fetc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/cfg5_write" -- python3 $O > "$out/cfg5_write.log" 2>&1
 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/cfg5_tcc" -- python3 $O > "$out/cfg5_tcc.log" 2>&1
 echo "cfg5 done"
+# ... and the same trajectory kept as its DAG only (CHAD_FLAG_DAG_ONLY: the closing table straight to cluster words, the fold on the device)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cfg5dag_trace" -- python3 scripts/cfg5_dagonly.py --frames 110 > "$out/cfg5dag_trace.log" 2>&1
+echo "cfg5 dag-only done"
 python3 scripts/summarise_profiles.py "$out" "$tag"

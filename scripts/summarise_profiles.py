@@ -23,8 +23,11 @@ stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), 
 shutil.copy(stats, os.path.join(prof, f"{tag}_kernel_stats.csv"))
 
 per_kernel = collections.defaultdict(dict)
-for group in ("fetch", "write", "tcc"):
-    f = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))[-1]
+for group in ("fetch", "write", "tcc", "rdreq"):
+    found = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
+    if not found:
+        continue
+    f = found[-1]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("chadhip::", "").replace("void ", "")
@@ -41,11 +44,41 @@ for r in csv.DictReader(open(stats)):
 upd = [k for k in per_kernel if k.startswith("k_update_tiled<false")][0]
 u = per_kernel[upd]
 traffic = (2.0 * u["FETCH_SIZE"] + u["WRITE_SIZE"]) * 1024.0
+# exact read bytes from the L2's memory-side read requests by size (32 / 64 / 128 bytes), where that pass was taken
+read_exact = None
+if "TCC_EA0_RDREQ_128B_sum" in u:
+    read_exact = 32.0 * u["TCC_EA0_RDREQ_32B_sum"] + 64.0 * u["TCC_EA0_RDREQ_64B_sum"] + 128.0 * u["TCC_EA0_RDREQ_128B_sum"]
+    traffic = read_exact + u["WRITE_SIZE"] * 1024.0
+try:
+    import subprocess
+    commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
+# the calibration of scripts/calib_fetch.hip (256 MiB read once per kernel): what FETCH_SIZE and the request counters report of it
+calib = {}
+for group, label in (("calib_fetch", "FETCH_SIZE"), ("calib_rdreq", "rdreq")):
+    found = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
+    if not found:
+        continue
+    acc = collections.defaultdict(dict)
+    for r in csv.DictReader(open(found[-1])):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[name][r["Counter_Name"]] = float(r["Counter_Value"])
+    for name, c in acc.items():
+        if not name.startswith("k_"):
+            continue
+        if label == "FETCH_SIZE":
+            calib.setdefault(name, {})["FETCH_SIZE_over_bytes"] = round(c.get("FETCH_SIZE", 0.0) * 1024.0 / (256 << 20), 4)
+        else:
+            b = 32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 64.0 * c.get("TCC_EA0_RDREQ_64B_sum", 0) + 128.0 * c.get("TCC_EA0_RDREQ_128B_sum", 0)
+            calib.setdefault(name, {})["request_bytes_over_bytes"] = round(b / (256 << 20), 4)
 json.dump({
-    "kernel": upd, "tag": tag,
+    "kernel": upd, "tag": tag, "measured_on_commit": commit, "calibration_256MiB_read_once": calib,
+    "read_bytes_from_request_sizes": read_exact,
     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum (separate passes) --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0",
     "fetch_size_kib_raw": u["FETCH_SIZE"], "write_size_kib": u["WRITE_SIZE"],
-    "correction": "reads doubled (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane streams); writes as reported",
+    "correction": "reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B where that pass was taken (exact: see calibration), else FETCH_SIZE doubled "
+                  "(gfx950 FETCH_SIZE counts 128-B requests as 64 B: right for coalesced 16 B/lane streams, an overestimate for this kernel's lane-strided loads); writes as reported",
     "hbm_bytes_per_launch": round(traffic),
     "atomic_requests_per_launch": u.get("TCC_EA0_ATOMIC_sum"),
     "l2_hit_rate": u["TCC_HIT_sum"] / (u["TCC_HIT_sum"] + u["TCC_MISS_sum"]),
