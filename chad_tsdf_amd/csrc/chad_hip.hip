@@ -210,6 +210,8 @@ struct chad_map {
     hipEvent_t fold_t0 = nullptr, fold_t1 = nullptr;   // device time of the fold in flight
     hipEvent_t spare_cleared = nullptr;           // recorded on fold_stream behind the clear of a table that was handed back as the spare
     bool spare_cleared_pending = false;           // ... the map's stream has not waited for it yet
+    int spare_flags = 0;                          // the spare's flag word still holds: 1 = its "exact rows" bit (cleared at a roll-over), 2 = everything (it was
+                                                  // the active table when the map was reset); spare_ready() resets it before the table is swapped in
     bool dag_on_host = false;                     // CHAD_DEBUG_DAG_HOST: the sequential host fold of dag.hpp instead (what the tests hold the device fold against)
     bool dag_mirror_stale = false;
     std::vector<std::array<uint32_t, 2>> dag_roots;  // submap.hpp:108-109 of the closed submaps folded so far (a prefix of `closed`)
@@ -444,10 +446,20 @@ chad_status alloc_map_storage(chad_map* m, MapView& v, uint64_t blocks, hipStrea
     return CHAD_OK;
 }
 
+// A table's bricks released and zeroed (k_clear_bricks), then its flag word: the "exact rows in use" bit always goes, the sticky
+// overflow bit only at a reset of the map.  The flag reset is a launch of its own BEHIND the clear (every workgroup of the clear reads
+// the exact-rows bit: it may not change under them); where the cleared table becomes the SPARE the reset is left to spare_ready(),
+// which runs when the table is swapped in -- off the path of the next frames' updates.
+inline void enqueue_clear(const MapView& v, hipStream_t s) { hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, s, v); }
+inline void enqueue_flag_reset(const MapView& v, hipStream_t s, bool overflow_too) {
+    hipLaunchKernelGGL(k_table_flags, dim3(1), dim3(1), 0, s, v.overflow, overflow_too ? 0u : uint32_t(kTableOverflowed));
+}
+
 // Octree::clear() (octree.hpp:22-29): forget every block of the active submap.  Fully asynchronous.
 chad_status clear_active(chad_map* m, bool clear_overflow = false) {
     TRY(exclusive_begin(m));
-    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, clear_overflow ? 1u : 0u);
+    enqueue_clear(m->view, m->stream);
+    enqueue_flag_reset(m->view, m->stream, clear_overflow);
     HIP_TRY(hipGetLastError());
     m->pending_clear = false; m->pending_clear_overflow = false;   // whatever was pending has just happened
     return exclusive_end(m, m->stream);
@@ -532,8 +544,13 @@ chad_status fold_advance(chad_map* m, bool block);    // (with Submap::finalize,
 chad_status fold_archived(chad_map* m);
 chad_status close_into_dag(chad_map* m, uint32_t blocks);
 // the map's stream is about to use the spare table: behind its clear, wherever that ran
-inline chad_status spare_ready(chad_map* m) {
+inline chad_status spare_ready(chad_map* m, bool at_reset = false) {
     if (m->spare_cleared_pending) { HIP_TRY(hipStreamWaitEvent(m->stream, m->spare_cleared, 0)); m->spare_cleared_pending = false; }
+    // the cleared table's flag word, behind its clear (stream order) and before it takes updates: at a reset everything goes (one
+    // memset), at a roll-over the sticky overflow bit stays unless the table was the active one when the map was last reset
+    if (at_reset || m->spare_flags == 2) HIP_TRY(hipMemsetAsync(m->spare.overflow, 0, 4, m->stream));
+    else if (m->spare_flags == 1) enqueue_flag_reset(m->spare, m->stream, false);
+    m->spare_flags = 0;
     return CHAD_OK;
 }
 chad_status finish_closing(chad_map* m, bool block) {
@@ -551,10 +568,11 @@ chad_status finish_closing(chad_map* m, bool block) {
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
         hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
     }
-    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, 0u);
+    enqueue_clear(m->closing_view, m->stream);
     HIP_TRY(hipGetLastError());
     m->closed.push_back(s);
     m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: whoever swaps it in does so on this stream
+    m->spare_flags = std::max(m->spare_flags, 1);
     m->closing_view = MapView{}; m->closing = false;
     return release_finalized(m);
 }
@@ -636,8 +654,9 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
 // watchdog, NCCL_TIMEOUT, ends that wait); a failed exchange is fatal for the sharded map as a whole.
 static void merge_abort(chad_map* m) {
     if (!m->closing) return;
-    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, 0u);
+    enqueue_clear(m->closing_view, m->stream);
     (void)hipGetLastError();
+    m->spare_flags = std::max(m->spare_flags, 1);
     Submap lost;
     if (alloc_submap(lost, 0) != CHAD_OK) { free_submap(lost); (void)hipGetLastError(); }
     m->closed.push_back(lost);
@@ -737,8 +756,9 @@ static chad_status merge_stages(chad_map* m, bool block) {
                 // the archive's format, converted exactly as the single-GPU archive converts (k_compact_bricks)
                 hipLaunchKernelGGL(k_dense_to_archive, grid_for(cells), dim3(256), 0, s, dense_sum, dense_cnt, cells, m->trunc, arch.sum, arch.cnt);
             }
-            hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, s, m->closing_view, 0u);
+            enqueue_clear(m->closing_view, s);
             HIP_TRY(hipGetLastError());
+            m->spare_flags = std::max(m->spare_flags, 1);
             m->closed.push_back(arch);
             m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: whoever swaps it in does so on this stream
             m->closing_view = MapView{}; m->closing = false; m->closing_comm = nullptr; m->merge_stage = 0;
@@ -1072,7 +1092,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                          points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
             record(m, T_SORT, prep);
             LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                         reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
+                         reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start, m->d_live_blocks);
         } else {
             // The chain of preparation kernels, every launch through the slot's FrameLauncher: launched one by one, or -- when the
             // frame has the shape of the one recorded for this slot (same size, digit width, pass count, buffers) -- replayed as a
@@ -1085,7 +1105,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                 L(k_frame_gather, gather_grid, dim3(256), 0, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1], points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start,
                   list_stride, sig.consumed, sig.seq, big_block);
                 L(k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                  reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
+                  reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start, m->d_live_blocks);
             };
             const FrameShape shape{count, digit_bits, hint, f.cap_points};
             FrameLauncher& L = f.chain;
@@ -1125,7 +1145,8 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             TRY(updates_done(o, &done));
             HIP_TRY(hipStreamWaitEvent(prep, done, 0));
         }
-        hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, prep, m->view, m->pending_clear_overflow ? 1u : 0u);
+        enqueue_clear(m->view, prep);
+        enqueue_flag_reset(m->view, prep, m->pending_clear_overflow);
         m->pending_clear = false; m->pending_clear_overflow = false;
         TRY(exclusive_end(m, prep));
         f.seen_epoch = m->excl_epoch;
@@ -1142,7 +1163,16 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         hipEvent_t* ev = m->ev[m->timed_end % chad_map::kTimingRing];
         hipEvent_t upd_pair[2] = {ev[T_NORM], ev[T_UPD]};
         if (hipEvent_t* ke = kernel_events(m, CHAD_KERNEL_UPDATE)) { upd_pair[0] = ke[0]; upd_pair[1] = ke[1]; }
-        if (m->update_mode == CHAD_UPDATE_SCATTER) {
+        static const bool no_sparse_kernel = std::getenv("CHAD_DEBUG_NO_SPARSE_KERNEL") != nullptr;   // A/B: the tiled kernel's own scatter branch instead
+        if (adaptive && m->h_live_blocks[4] != 0u && !no_sparse_kernel) {
+            // the frames before this one were sparse (about one point per block): the scatter form with its phases apart (k_update_sparse);
+            // should this frame be dense after all, that kernel is still right, merely slower than the tiled one
+            const dim3 grid = grid_for(count, 256, 4096);
+            if (time_kernel)
+                hipExtLaunchKernelGGL(k_update_sparse, grid, dim3(256), 0u, prep, upd_pair[0], upd_pair[1], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
+            else
+                hipLaunchKernelGGL(k_update_sparse, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
+        } else if (m->update_mode == CHAD_UPDATE_SCATTER) {
             const dim3 grid = grid_for(count);
             if (time_kernel)
                 hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, prep, upd_pair[0], upd_pair[1], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
@@ -1273,6 +1303,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->h_live_blocks[1] = kMaxPasses;  // sort pass hint: all passes as single launches until the first frame has reported
     m->h_live_blocks[2] = 0;           // key width hint: none yet (8-bit digits)
     m->h_live_blocks[3] = 0;           // launches that have used the scatter form's staging words (fold_if_due)
+    m->h_live_blocks[4] = 0;           // the last frame whose normals kernel has run was sparse (the next frame's update takes the sparse kernel)
     if (const char* e = std::getenv("CHAD_DEBUG_SORT_PASSES")) m->sort_passes_forced = uint32_t(std::atoi(e));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
     CREATE_TRY(hipHostMalloc(&m->h_consumed, chad_map::kMaxSlots * 64, hipHostMallocMapped));
@@ -1477,8 +1508,11 @@ chad_status read_back_header(chad_map* m, uint32_t* overflow) {
     HIP_TRY(hipMemcpy(m->h_hdr, m->slot[m->last_slot].d_hdr, offsetof(FrameHeader, first_item), hipMemcpyDeviceToHost));   // (the scalars and counters; not the update kernel's item table)
     uint32_t words[8];
     HIP_TRY(hipMemcpy(words, m->d_overflow, sizeof(words), hipMemcpyDeviceToHost));
+    // the sort's fault bits, and the overflow bit of the tables that hold data: the active one and one that is closing (a spare table's
+    // word is stale until the table is swapped in: spare_ready)
     *overflow = words[0];
-    for (uint32_t w = 1; w < 8; w++) if ((m->overflow_words_used >> w) & 1u) *overflow |= words[w] & kTableOverflowed;   // (bit 2 of a table's word: its exact rows are in use)
+    if (m->view.overflow) *overflow |= words[m->view.overflow - m->d_overflow] & kTableOverflowed;
+    if (m->closing && m->closing_view.overflow) *overflow |= words[m->closing_view.overflow - m->d_overflow] & kTableOverflowed;
     return CHAD_OK;
 }
 
@@ -1524,13 +1558,13 @@ chad_status chad_map_reset(chad_map* m) {
             else { free_map_storage(m, m->spare); m->spare_unaffordable = true; g_error.clear(); }
         }
         if (m->has_spare) {
-            TRY(spare_ready(m));
-            HIP_TRY(hipMemsetAsync(m->spare.overflow, 0, 4, m->stream));   // the spare table's own flag (no frame is using that table)
+            TRY(spare_ready(m, true));   // (incl. the spare table's flag word: no frame is using that table)
             TRY(exclusive_end(m, m->stream));   // later updates wait for the map's stream up to HERE: the spare's own clear lies before this point
             TRY(exclusive_begin(m));            // ... and the old table's clear waits for every update enqueued so far, nobody waits for it
-            hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, m->stream, m->view, 1u);   // (its flag with it: behind the frames that may still raise it)
+            enqueue_clear(m->view, m->stream);   // (its flag word is reset when the table is swapped in again: spare_ready / the memset above)
             HIP_TRY(hipGetLastError());
             std::swap(m->view, m->spare);
+            m->spare_flags = 2;
             *m->h_live_blocks = 0;
             staging_restart(m);
             return CHAD_OK;
@@ -1891,8 +1925,9 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
         hipLaunchKernelGGL(k_table_clusters, dim3(512), dim3(256), 0, s, m->closing_view, m->d_cursor, blocks, m->trunc, 1.0f / m->trunc /* submap.hpp:23 */, raw_keys, raw_tsdf, raw_weight);
     }
-    hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, s, m->closing_view, 0u);
+    enqueue_clear(m->closing_view, s);
     HIP_TRY(hipGetLastError());
+    m->spare_flags = std::max(m->spare_flags, 1);
     if (s != m->stream) { HIP_TRY(hipEventRecord(m->spare_cleared, s)); m->spare_cleared_pending = true; }
     m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: spare_ready() makes the map's stream wait for it
     m->closing_view = MapView{}; m->closing = false;

@@ -413,3 +413,35 @@ def test_two_maps_on_two_threads(chad):
     for i in range(2):
         for got, want in zip(together[i], alone[i]):   # codes, signed distances (bit for bit: the sums are integers), weights
             assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"map {i}"
+
+
+def test_sparse_and_dense_frames_interleaved(chad, oracle):
+    """In automatic mode the host launches the update kernel the PREVIOUS frame's verdict asks for (the device mirrors "this frame was
+    sparse" into host-mapped memory): k_update_sparse -- ray walk, batched block look-ups and transposed atomics in separate phases --
+    behind sparse frames, the tiled kernel (which takes its own scatter branch when it meets a sparse frame) otherwise.  Either kernel
+    is correct for either kind of frame; a stream that flips between the kinds puts every combination to the test: sparse after
+    sparse, dense after sparse (the sparse kernel on a dense frame), sparse after dense, dense after dense."""
+    res, trunc = 0.02, 0.06
+    rng = np.random.default_rng(5)
+
+    def dense_patch(k):   # 150 k points on a 1.5 m x 1 m patch of a wall 3 m away: ~50 points per 4x4x4 block
+        y = rng.uniform(-0.75, 0.75, 150_000) + 0.1 * k
+        z = rng.uniform(-0.5, 0.5, 150_000)
+        x = np.full_like(y, 3.0) + 0.013 * y
+        return np.stack([x, y, z], axis=1).astype(np.float32), np.zeros(3, np.float32)
+
+    def sparse_scan(k):
+        pts, _ = synth.cfg5_frame(k, 60_000)
+        return pts, np.array([0.5 * k, 0.0, 0.0], np.float32)
+
+    kinds = "ssdsddssd"
+    m = chad.TSDFMap(res, trunc, max_blocks=1 << 21)
+    o = oracle.OracleMap(res, trunc)
+    for k, kind in enumerate(kinds):
+        pts, pos = sparse_scan(k % 4) if kind == "s" else dense_patch(k)   # (poses within 5 m of the first: one submap)
+        m.insert(pts, pos)
+        o.insert(pts, pos)
+    assert m.closed_submaps == o.closed_submaps == 0
+    assert_leaves_match(m.export_leaves(), o.export_leaves(), trunc)
+    assert m.stats()["overflow"] == 0
+    m.close()
