@@ -181,6 +181,7 @@ struct chad_map {
                                      // alive (active, spare, closing: each table has a word of its own, so that clearing one table -- ordered behind ITS updates --
                                      // cannot wipe what a frame in flight reports about another); word 8: launches that have used the scatter form's staging words
     uint32_t overflow_words_used = 0;   // bit w: word w belongs to a table
+    uint32_t overflow_latched = 0;      // overflow bits of tables that have been closed since the last reset (sticky, like the active table's own)
     static constexpr uint32_t kRecentFrames = 2 * 8;   // two per frame slot at most (fold_if_due)
     size_t recent_points[kRecentFrames] = {};
     uint32_t recent_at = 0;
@@ -560,6 +561,7 @@ chad_status finish_closing(chad_map* m, bool block) {
     else if (hipEventQuery(m->closing_counted) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
     uint32_t blocks = 0;
     for (uint32_t k = 0; k < kCountStripes; k++) blocks += m->closing_count[k * 16];
+    m->overflow_latched |= m->closing_count[kCountStripes * 16] & kTableOverflowed;   // a submap that lost blocks stays reported after its table has gone back to the pool
     // CHAD_FLAG_DAG_ONLY: no dense copy at all -- cluster words straight from the table, folded into the DAG beside the next frames
     if ((m->flags & CHAD_FLAG_DAG_ONLY) && !m->dag_on_host) return close_into_dag(m, blocks);
     Submap s;
@@ -603,6 +605,7 @@ chad_status close_active(chad_map* m) {
     TRY(spare_ready(m));
     TRY(exclusive_begin(m));               // the map's stream waits for every update enqueued so far ...
     HIP_TRY(hipMemcpyAsync(m->closing_count, m->view.brick_count, kCountStripes * 64, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->closing_count + kCountStripes * 16, m->view.overflow, 4, hipMemcpyDeviceToHost, m->stream));   // ... and whether it overflowed (final: its updates are done)
     HIP_TRY(hipEventRecord(m->closing_counted, m->stream));
     m->closing_view = m->view; m->closing = true;
     m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
@@ -639,6 +642,7 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
     TRY(spare_ready(m));
     TRY(exclusive_begin(m));               // the map's stream waits for every update enqueued so far ...
     HIP_TRY(hipMemcpyAsync(m->closing_count, m->view.brick_count, kCountStripes * 64, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->closing_count + kCountStripes * 16, m->view.overflow, 4, hipMemcpyDeviceToHost, m->stream));   // ... and whether it overflowed (final: its updates are done)
     HIP_TRY(hipEventRecord(m->closing_counted, m->stream));
     m->closing_view = m->view; m->closing = true; m->closing_comm = c; m->merge_stage = 0;
     m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
@@ -682,6 +686,7 @@ static chad_status merge_stages(chad_map* m, bool block) {
         if (m->merge_stage == 0) {
             uint32_t nb = 0;
             for (uint32_t k = 0; k < kCountStripes; k++) nb += m->closing_count[k * 16];
+            m->overflow_latched |= m->closing_count[kCountStripes * 16] & kTableOverflowed;
             m->merge_blocks = nb;
             HIP_TRY(m->merge_a.reserve(Arena::padded(size_t(nb) * 8) + Arena::padded(size_t(nb) * 512) + Arena::padded(size_t(nb) * 256) + Arena::padded(8) + Arena::padded(8 * size_t(world))));
             m->merge_keys = m->merge_a.take<uint64_t>(nb); m->merge_sum = m->merge_a.take<long long>(size_t(nb) * 64); m->merge_cnt = m->merge_a.take<uint32_t>(size_t(nb) * 64);
@@ -1295,7 +1300,8 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     }
     CREATE_TRY(hipEventCreateWithFlags(&m->excl_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->closing_counted, hipEventDisableTiming));
-    CREATE_TRY(hipHostMalloc(&m->closing_count, kCountStripes * 64));
+    CREATE_TRY(hipHostMalloc(&m->closing_count, kCountStripes * 64 + 64));   // (the counter stripes, and behind them the closing table's flag word)
+    m->closing_count[kCountStripes * 16] = 0u;
     if (!m->own_stream) CREATE_TRY(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->h_hdr, sizeof(FrameHeader)));
     CREATE_TRY(hipHostMalloc(&m->h_live_blocks, 64, hipHostMallocMapped));
@@ -1510,7 +1516,7 @@ chad_status read_back_header(chad_map* m, uint32_t* overflow) {
     HIP_TRY(hipMemcpy(words, m->d_overflow, sizeof(words), hipMemcpyDeviceToHost));
     // the sort's fault bits, and the overflow bit of the tables that hold data: the active one and one that is closing (a spare table's
     // word is stale until the table is swapped in: spare_ready)
-    *overflow = words[0];
+    *overflow = words[0] | m->overflow_latched;
     if (m->view.overflow) *overflow |= words[m->view.overflow - m->d_overflow] & kTableOverflowed;
     if (m->closing && m->closing_view.overflow) *overflow |= words[m->closing_view.overflow - m->d_overflow] & kTableOverflowed;
     return CHAD_OK;
@@ -1540,6 +1546,7 @@ chad_status chad_map_reset(chad_map* m) {
         for (auto& s : m->closed) free_submap(s);
         m->closed.clear();
     }
+    m->overflow_latched = 0;
     m->dag = Dag();
     m->ddag.release();
     m->dag_mirror_stale = false;
