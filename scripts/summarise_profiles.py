@@ -109,3 +109,8 @@ if glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursi
         print(f'{r["Name"].split("(")[0][:60]:60s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"]) / 1e3:8.2f} us  {r["Percentage"]:>6s}%')
     u5 = [k for k in per5 if k.startswith("k_update_tiled<false")]
     if u5: print("cfg5 update kernel counters per launch:", json.dumps(per5[u5[0]]))
+
+# the same trajectory kept as its DAG only (scripts/cfg5_dagonly.py under the kernel trace)
+dag = sorted(glob.glob(os.path.join(src, "cfg5dag_trace", "**", "*kernel_stats.csv"), recursive=True))
+if dag:
+    shutil.copy(dag[-1], os.path.join(prof, f"{tag}_cfg5_dagonly_kernel_stats.csv"))
