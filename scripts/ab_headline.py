@@ -37,7 +37,28 @@ def child(root):
     m.sync()
     t3 = (time.perf_counter() - t0) / 300
     m.close()
-    print(json.dumps({"root": root, "cfg2_ms_per_frame": round(best * 1e3, 4), "cfg3_ms_per_frame": round(t3 * 1e3, 4)}), flush=True)
+    # cfg5's shape: the same eleven frames over and over (no roll-over), then 66 frames with roll-overs
+    frames = [synth.cfg5_frame(k) for k in range(66)]
+    dev = [torch.from_numpy(p).cuda() for p, _ in frames]
+    torch.cuda.synchronize()
+    out5 = {}
+    for mode in ("noroll", "roll"):
+        m = TSDFMap(0.02, 0.06, max_points=200_000, max_blocks=1 << 22)
+        for k in range(3):
+            m.insert(dev[k], frames[k][1], ready=True)
+        m.close_submap(); m.sync(); m.reset(); m.sync()
+        if mode == "noroll":
+            for k in range(11):
+                m.insert(dev[k], frames[k][1], ready=True)
+            m.sync()
+        t0 = time.perf_counter()
+        for k in range(66):
+            j = k % 11 if mode == "noroll" else k
+            m.insert(dev[j], frames[j][1], ready=True)
+        m.sync()
+        out5[mode] = round((time.perf_counter() - t0) / 66 * 1e3, 4)
+        m.close()
+    print(json.dumps({"root": root, "cfg2_ms_per_frame": round(best * 1e3, 4), "cfg3_ms_per_frame": round(t3 * 1e3, 4), "cfg5_noroll": out5["noroll"], "cfg5_roll": out5["roll"]}), flush=True)
 
 
 if __name__ == "__main__":
