@@ -120,16 +120,15 @@ __device__ __forceinline__ void voxel_totals(const MapView& m, size_t at, long l
     *sum = s; *count = c;
 }
 
-// Home slot of a block: the 2x2x2 group of blocks it belongs to (its Morton index without the low three bits) is hashed, the block's
-// place in the group kept -- the eight blocks of a group (an 8x8x8-voxel super block: the tiled kernel's work item, and what a ray's
-// two or three blocks mostly share) sit in eight consecutive slots: their keys in one 64-byte line, their rows of the brick arrays in
-// one 4 KB stretch (one DRAM page, one translation).  Keeping more of the Morton index (groups of 64 or 512 blocks, or all of it)
-// clusters: a surface fills its groups unevenly and far-apart regions fold onto each other -- simulated on a cfg5 submap (1.65 M
-// blocks in 2^23 slots, linear probing): mean / 99th percentile / longest probe sequence 1.10 / 3 / 13 for a plain hash, 1.39 / 11 / 51
-// for groups of 8, 3.5 / 60 / 216 for groups of 64, 2.2 / 32 / 510 with the whole index kept.
+// Home slot of a block: a multiplicative hash of its Morton index -- on purpose WITHOUT any locality.  Keeping the block's place in
+// its 2x2x2 group (eight neighbouring blocks in eight consecutive slots: their keys in one line, their rows in one 4 KB stretch)
+// looked attractive for the sparse update's 2.6 M random accesses per frame and was measured (round 4, scripts/ab_headline.py on one
+// box): the sparse update alone 97 -> 118 us, cfg5 0.138 -> 0.143 ms per frame, cfg3 erratic (0.051 -> 0.051-0.065), cfg2 1 % faster:
+// neighbouring rays' atomics then queue at the same memory channel instead of spreading over all of them, and linear probing
+// clusters (simulated on a cfg5 submap, 1.65 M blocks in 2^23 slots: mean / 99th percentile / longest probe sequence 1.10 / 3 / 13
+// for this hash, 1.39 / 11 / 51 for groups of 8, 3.5 / 60 / 216 for groups of 64, 2.2 / 32 / 510 with the whole index kept).
 __device__ __forceinline__ uint32_t hash_block(uint64_t key, uint32_t mask) {
-    const uint64_t index = key >> 6;
-    return ((uint32_t(((index >> 3) * 0x9E3779B97F4A7C15ull) >> 32) << 3) | (uint32_t(index) & 7u)) & mask;
+    return uint32_t(((key >> 6) * 0x9E3779B97F4A7C15ull) >> 32) & mask;
 }
 
 __device__ __forceinline__ uint32_t live_brick_count(const MapView& m) {
