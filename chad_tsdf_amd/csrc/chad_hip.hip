@@ -451,7 +451,7 @@ chad_status alloc_map_storage(chad_map* m, MapView& v, uint64_t blocks, hipStrea
 // overflow bit only at a reset of the map.  The flag reset is a launch of its own BEHIND the clear (every workgroup of the clear reads
 // the exact-rows bit: it may not change under them); where the cleared table becomes the SPARE the reset is left to spare_ready(),
 // which runs when the table is swapped in -- off the path of the next frames' updates.
-inline void enqueue_clear(const MapView& v, hipStream_t s) { hipLaunchKernelGGL(k_clear_bricks, dim3(512), dim3(256), 0, s, v); }
+inline void enqueue_clear(const MapView& v, hipStream_t s) { hipLaunchKernelGGL(k_clear_bricks, dim3(walk_grid(v.hash_mask)), dim3(256), 0, s, v); }
 inline void enqueue_flag_reset(const MapView& v, hipStream_t s, bool overflow_too) {
     hipLaunchKernelGGL(k_table_flags, dim3(1), dim3(1), 0, s, v.overflow, overflow_too ? 0u : uint32_t(kTableOverflowed));
 }
@@ -518,7 +518,7 @@ chad_status compact_active(chad_map* m, Submap& s, uint32_t blocks) {
     TRY(alloc_submap(s, blocks));
     if (!blocks) return CHAD_OK;
     HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
-    hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
+    hipLaunchKernelGGL(k_compact_bricks, dim3(walk_grid(m->view.hash_mask)), dim3(256), 0, m->stream, m->view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
 }
@@ -568,7 +568,7 @@ chad_status finish_closing(chad_map* m, bool block) {
     if (m->flags & CHAD_FLAG_DAG_ONLY) TRY(borrow_submap(m, s, blocks)); else TRY(alloc_submap(s, blocks));
     if (blocks) {
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
-        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->closing_view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
+        hipLaunchKernelGGL(k_compact_bricks, dim3(walk_grid(m->closing_view.hash_mask)), dim3(256), 0, m->stream, m->closing_view, m->d_cursor, blocks, s.keys, s.sum, s.cnt, m->trunc);
     }
     enqueue_clear(m->closing_view, m->stream);
     HIP_TRY(hipGetLastError());
@@ -694,7 +694,7 @@ static chad_status merge_stages(chad_map* m, bool block) {
             uint64_t* d_all_n = m->merge_a.take<uint64_t>(world);
             if (nb) {
                 HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
-                hipLaunchKernelGGL(k_compact_bricks_raw, dim3(512), dim3(256), 0, s, m->closing_view, m->d_cursor, nb, m->merge_keys, m->merge_sum, m->merge_cnt);
+                hipLaunchKernelGGL(k_compact_bricks_raw, dim3(walk_grid(m->closing_view.hash_mask)), dim3(256), 0, s, m->closing_view, m->d_cursor, nb, m->merge_keys, m->merge_sum, m->merge_cnt);
                 HIP_TRY(hipGetLastError());
             }
             m->merge_host[17] = nb;
@@ -910,7 +910,7 @@ chad_status grow_if_needed(chad_map* m) {
     const uint64_t blocks = std::min<uint64_t>(uint64_t(m->brick_capacity) * 2, 1ull << 30);
     const chad_status s = alloc_map_storage(m, bigger, blocks, m->stream);
     if (s != CHAD_OK) { free_map_storage(m, bigger); m->fixed_capacity = true; g_error.clear(); return CHAD_OK; }  // keep going at the old size
-    if (live) hipLaunchKernelGGL(k_rehash_bricks, dim3(512), dim3(256), 0, m->stream, m->view, bigger);
+    if (live) hipLaunchKernelGGL(k_rehash_bricks, dim3(walk_grid(m->view.hash_mask)), dim3(256), 0, m->stream, m->view, bigger);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(bigger.overflow, m->view.overflow, 4, hipMemcpyDeviceToDevice, m->stream));   // (what the old table has reported stays reported)
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1035,7 +1035,7 @@ void fold_if_due(chad_map* m, hipStream_t stream, size_t n) {
     if (m->pack_points < m->fold_due) return;
     const uint32_t seen = m->h_live_blocks[3];
     if (seen != m->pack_seen_folded) {
-        hipLaunchKernelGGL(k_fold_packed, dim3(512), dim3(256), 0, stream, m->view);
+        hipLaunchKernelGGL(k_fold_packed, dim3(walk_grid(m->view.hash_mask)), dim3(256), 0, stream, m->view);
         m->pack_seen_folded = seen;
         m->folds++;
     }
@@ -1698,7 +1698,7 @@ static chad_status export_blocks(chad_map* m, int32_t submap, uint64_t* keys_dev
         if (!nb) return CHAD_OK;
         if (!keys_device || !sum_device || !cnt_device) return fail(CHAD_ERR_INVALID_ARG, "null output");
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, m->stream));
-        hipLaunchKernelGGL(k_compact_bricks, dim3(512), dim3(256), 0, m->stream, m->view, m->d_cursor, nb, keys_device, sum_device, cnt_device, m->trunc);
+        hipLaunchKernelGGL(k_compact_bricks, dim3(walk_grid(m->view.hash_mask)), dim3(256), 0, m->stream, m->view, m->d_cursor, nb, keys_device, sum_device, cnt_device, m->trunc);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(m->stream));
         return CHAD_OK;
@@ -1930,7 +1930,7 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     HIP_TRY(hipEventRecord(m->fold_t0, s));
     if (blocks) {
         HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
-        hipLaunchKernelGGL(k_table_clusters, dim3(512), dim3(256), 0, s, m->closing_view, m->d_cursor, blocks, m->trunc, 1.0f / m->trunc /* submap.hpp:23 */, raw_keys, raw_tsdf, raw_weight);
+        hipLaunchKernelGGL(k_table_clusters, dim3(walk_grid(m->closing_view.hash_mask)), dim3(256), 0, s, m->closing_view, m->d_cursor, blocks, m->trunc, 1.0f / m->trunc /* submap.hpp:23 */, raw_keys, raw_tsdf, raw_weight);
     }
     enqueue_clear(m->closing_view, s);
     HIP_TRY(hipGetLastError());

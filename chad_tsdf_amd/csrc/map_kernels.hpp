@@ -470,16 +470,24 @@ k_leaf_clusters(const uint32_t* __restrict__ order, uint32_t count, const uint64
     }
 }
 
-// Walk the live bitmap: every wave takes 64 words at a time (lane = word) and calls visit(slot) -- wave-uniformly,
-// all 64 lanes active -- for each set bit.
+// Walk the live bitmap: every wave takes kWalkWords words at a time (lane = word) and calls visit(slot) -- wave-uniformly,
+// all 64 lanes active -- for each set bit.  Sixteen words = 512 slots per turn (64 until round 4): a wave works its bricks off one
+// after the other (a handful of 512-byte rows in flight), so what hides the latency of those scattered rows is the NUMBER of waves,
+// and a table of 2^23 slots now gives 16 384 turns to a grid of up to 4 096 workgroups instead of 4 096 turns to 512 (walk_grid).
+constexpr uint32_t kWalkWords = 16;
+inline uint32_t walk_grid(uint32_t hash_mask) {   // workgroups of four waves for a kernel that walks the bitmap of a table of hash_mask + 1 slots
+    const uint32_t turns = ((hash_mask >> 5) + kWalkWords) / kWalkWords;
+    const uint32_t groups = (turns + 3u) / 4u;
+    return groups < 256u ? 256u : (groups > 4096u ? 4096u : groups);
+}
 template <class Visit>
 __device__ __forceinline__ void for_each_live_brick(const MapView& m, Visit visit) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t words = (m.hash_mask >> 5) + 1u;
-    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u) {
-        const uint32_t word = w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
+    for (uint32_t w0 = wave * kWalkWords; w0 < words; w0 += waves * kWalkWords) {
+        const uint32_t word = lane < kWalkWords && w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
         for (uint64_t holders = __ballot(word != 0u); holders; holders &= holders - 1ull) {
             const uint32_t l = uint32_t(__ffsll((unsigned long long)holders)) - 1u;
             for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u)
@@ -500,8 +508,8 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t words = (m.hash_mask >> 5) + 1u;
-    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u) {
-        const uint32_t word = w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
+    for (uint32_t w0 = wave * kWalkWords; w0 < words; w0 += waves * kWalkWords) {
+        const uint32_t word = lane < kWalkWords && w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
         uint64_t holders = __ballot(word != 0u);
         if (!holders) continue;
         uint32_t total = uint32_t(__popc(word));
@@ -558,8 +566,8 @@ k_table_clusters(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, fl
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t words = (m.hash_mask >> 5) + 1u;
-    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u) {
-        const uint32_t word = w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
+    for (uint32_t w0 = wave * kWalkWords; w0 < words; w0 += waves * kWalkWords) {
+        const uint32_t word = lane < kWalkWords && w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
         uint64_t holders = __ballot(word != 0u);
         if (!holders) continue;
         uint32_t total = uint32_t(__popc(word));
@@ -635,8 +643,8 @@ k_clear_bricks(MapView m) {
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t words = (m.hash_mask >> 5) + 1u;
-    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u)
-        if (w0 + lane < words && m.live_bits[w0 + lane]) m.live_bits[w0 + lane] = 0u;
+    for (uint32_t w0 = wave * kWalkWords; w0 < words; w0 += waves * kWalkWords)
+        if (lane < kWalkWords && w0 + lane < words && m.live_bits[w0 + lane]) m.live_bits[w0 + lane] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < kCountStripes) m.brick_count[threadIdx.x * 16] = 0u;
     // (the table's flag word is NOT touched here: every workgroup reads its "exact rows" bit above, at its own time.  It is reset
     //  behind this kernel -- k_table_flags, or the memset of a reset -- before the table takes updates again: chad_hip.hip, table_cleared)

@@ -27,8 +27,8 @@ k_compact_bricks_raw(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t words = (m.hash_mask >> 5) + 1u;
-    for (uint32_t w0 = wave * 64u; w0 < words; w0 += waves * 64u) {
-        const uint32_t word = w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
+    for (uint32_t w0 = wave * kWalkWords; w0 < words; w0 += waves * kWalkWords) {
+        const uint32_t word = lane < kWalkWords && w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
         uint64_t holders = __ballot(word != 0u);
         if (!holders) continue;
         uint32_t total = uint32_t(__popc(word));
