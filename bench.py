@@ -252,6 +252,23 @@ def main():
     }
     m.close()
 
+    # ---- the box's achievable HBM rate (a device-to-device copy beside the 8 TB/s spec figure) ----------------
+    if rank == 0:
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")   # 1 GiB
+        b = torch.empty_like(a)
+        a.fill_(1.0)
+        for _ in range(2):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * a.numel() * 4 / (time.perf_counter() - t1) / 1e9
+        del a, b
+        out["roofline"]["hbm_copy_GBps_this_box"] = round(copy_gbs, 1)   # read + write bytes of a 1 GiB device-to-device copy: what a pure stream reaches here
+        out["roofline"]["frac_of_copy_rate"] = round(achieved / copy_gbs, 5) if copy_gbs > 0 else None
+
     # ---- per-kernel durations: a serial pass, every kernel launched with its own pair of dispatch time stamps --------------
     if rank == 0:
         mk = TSDFMap(res, trunc, time_kernels=True, update_mode=args.update_mode, max_points=args.points)

@@ -451,7 +451,7 @@ chad_status alloc_map_storage(chad_map* m, MapView& v, uint64_t blocks, hipStrea
 // overflow bit only at a reset of the map.  The flag reset is a launch of its own BEHIND the clear (every workgroup of the clear reads
 // the exact-rows bit: it may not change under them); where the cleared table becomes the SPARE the reset is left to spare_ready(),
 // which runs when the table is swapped in -- off the path of the next frames' updates.
-inline void enqueue_clear(const MapView& v, hipStream_t s) { hipLaunchKernelGGL(k_clear_bricks, dim3(walk_grid(v.hash_mask)), dim3(256), 0, s, v); }
+inline void enqueue_clear(const MapView& v, hipStream_t s, uint32_t live = ~0u) { hipLaunchKernelGGL(k_clear_bricks, dim3(walk_grid(v.hash_mask, live)), dim3(256), 0, s, v); }
 inline void enqueue_flag_reset(const MapView& v, hipStream_t s, bool overflow_too) {
     hipLaunchKernelGGL(k_table_flags, dim3(1), dim3(1), 0, s, v.overflow, overflow_too ? 0u : uint32_t(kTableOverflowed));
 }
@@ -1568,7 +1568,7 @@ chad_status chad_map_reset(chad_map* m) {
             TRY(spare_ready(m, true));   // (incl. the spare table's flag word: no frame is using that table)
             TRY(exclusive_end(m, m->stream));   // later updates wait for the map's stream up to HERE: the spare's own clear lies before this point
             TRY(exclusive_begin(m));            // ... and the old table's clear waits for every update enqueued so far, nobody waits for it
-            enqueue_clear(m->view, m->stream);   // (its flag word is reset when the table is swapped in again: spare_ready / the memset above)
+            enqueue_clear(m->view, m->stream, *m->h_live_blocks);   // (its flag word is reset when the table is swapped in again: spare_ready / the memset above)
             HIP_TRY(hipGetLastError());
             std::swap(m->view, m->spare);
             m->spare_flags = 2;

@@ -475,10 +475,15 @@ k_leaf_clusters(const uint32_t* __restrict__ order, uint32_t count, const uint64
 // after the other (a handful of 512-byte rows in flight), so what hides the latency of those scattered rows is the NUMBER of waves,
 // and a table of 2^23 slots now gives 16 384 turns to a grid of up to 4 096 workgroups instead of 4 096 turns to 512 (walk_grid).
 constexpr uint32_t kWalkWords = 16;
-inline uint32_t walk_grid(uint32_t hash_mask) {   // workgroups of four waves for a kernel that walks the bitmap of a table of hash_mask + 1 slots
+// workgroups of four waves for a kernel that walks the bitmap of a table of hash_mask + 1 slots holding about `live` bricks (the
+// host's mirror of the live count; ~0u = unknown): a turn per wave for a well-filled table, no more than 512 workgroups for a table
+// with few bricks (a cfg2 frame's 9 k: the walk is then a scan of empty words, and launching 2 048 workgroups for it costs the
+// headline's reset 1 %)
+inline uint32_t walk_grid(uint32_t hash_mask, uint32_t live = ~0u) {
     const uint32_t turns = ((hash_mask >> 5) + kWalkWords) / kWalkWords;
     const uint32_t groups = (turns + 3u) / 4u;
-    return groups < 256u ? 256u : (groups > 4096u ? 4096u : groups);
+    const uint32_t cap = live < (1u << 16) ? 512u : 4096u;
+    return groups < 256u ? 256u : (groups > cap ? cap : groups);
 }
 template <class Visit>
 __device__ __forceinline__ void for_each_live_brick(const MapView& m, Visit visit) {
