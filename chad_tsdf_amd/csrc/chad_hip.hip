@@ -1097,7 +1097,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                          points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
             record(m, T_SORT, prep);
             LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                         reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start, m->d_live_blocks);
+                         reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
         } else {
             // The chain of preparation kernels, every launch through the slot's FrameLauncher: launched one by one, or -- when the
             // frame has the shape of the one recorded for this slot (same size, digit width, pass count, buffers) -- replayed as a
@@ -1110,7 +1110,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                 L(k_frame_gather, gather_grid, dim3(256), 0, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1], points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start,
                   list_stride, sig.consumed, sig.seq, big_block);
                 L(k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                  reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start, m->d_live_blocks);
+                  reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
             };
             const FrameShape shape{count, digit_bits, hint, f.cap_points};
             FrameLauncher& L = f.chain;
@@ -1168,16 +1168,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         hipEvent_t* ev = m->ev[m->timed_end % chad_map::kTimingRing];
         hipEvent_t upd_pair[2] = {ev[T_NORM], ev[T_UPD]};
         if (hipEvent_t* ke = kernel_events(m, CHAD_KERNEL_UPDATE)) { upd_pair[0] = ke[0]; upd_pair[1] = ke[1]; }
-        static const bool no_sparse_kernel = std::getenv("CHAD_DEBUG_NO_SPARSE_KERNEL") != nullptr;   // A/B: the tiled kernel's own scatter branch instead
-        if (adaptive && m->h_live_blocks[4] != 0u && !no_sparse_kernel) {
-            // the frames before this one were sparse (about one point per block): the scatter form with its phases apart (k_update_sparse);
-            // should this frame be dense after all, that kernel is still right, merely slower than the tiled one
-            const dim3 grid = grid_for(count, 256, 4096);
-            if (time_kernel)
-                hipExtLaunchKernelGGL(k_update_sparse, grid, dim3(256), 0u, prep, upd_pair[0], upd_pair[1], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
-            else
-                hipLaunchKernelGGL(k_update_sparse, grid, dim3(256), 0, prep, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
-        } else if (m->update_mode == CHAD_UPDATE_SCATTER) {
+        if (m->update_mode == CHAD_UPDATE_SCATTER) {
             const dim3 grid = grid_for(count);
             if (time_kernel)
                 hipExtLaunchKernelGGL(k_update_scatter, grid, dim3(256), 0u, prep, upd_pair[0], upd_pair[1], 0u, points0, points1, f.d_normals, f.d_hdr, pos, m->res, m->recip, m->trunc, m->view, pack_counter, pack_seen);
@@ -1309,7 +1300,6 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->h_live_blocks[1] = kMaxPasses;  // sort pass hint: all passes as single launches until the first frame has reported
     m->h_live_blocks[2] = 0;           // key width hint: none yet (8-bit digits)
     m->h_live_blocks[3] = 0;           // launches that have used the scatter form's staging words (fold_if_due)
-    m->h_live_blocks[4] = 0;           // the last frame whose normals kernel has run was sparse (the next frame's update takes the sparse kernel)
     if (const char* e = std::getenv("CHAD_DEBUG_SORT_PASSES")) m->sort_passes_forced = uint32_t(std::atoi(e));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_live_blocks), const_cast<uint32_t*>(m->h_live_blocks), 0));
     CREATE_TRY(hipHostMalloc(&m->h_consumed, chad_map::kMaxSlots * 64, hipHostMallocMapped));

@@ -902,7 +902,7 @@ __global__ void __launch_bounds__(64 * kNormalWaves, 5)  // <= 96 VGPRs: 20 wave
 k_frame_normals(float4* __restrict__ points0, float4* __restrict__ points1, float recip,
                 const uint2* __restrict__ segments, uint32_t list_stride,
                 FrameHeader* __restrict__ h, F3 pos, float4* __restrict__ normals, uint32_t ablate, uint32_t big_block, uint32_t max_big_groups,
-                const uint4* __restrict__ items, uint32_t* __restrict__ hints_host /* host-mapped: [4] = this frame was sparse (the host picks the next frame's update kernel) */) {
+                const uint4* __restrict__ items) {
     __shared__ NormalScratch scratch[kNormalWaves];
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points1 : points0;   // where the sort's last pass left the points: by block, input order inside
     float4* __restrict__ ordered = (h->sort_passes & 1u) ? points0 : points1;     // the sort's other buffer: the same blocks, each in the reference's order
@@ -933,10 +933,7 @@ k_frame_normals(float4* __restrict__ points0, float4* __restrict__ points1, floa
         return segments[stripe * list_stride + index];
     };
     const bool sparse = n < kSparsePointsPerBlock * nseg;   // frame_is_sparse
-    if (blockIdx.x == gridDim.x - 1u) {   // (never one of the large blocks' workgroups)
-        publish_item_summary(h, items, list_stride, sparse);
-        if (threadIdx.x == 0 && hints_host) __hip_atomic_store(&hints_host[4], sparse ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (blockIdx.x == gridDim.x - 1u) publish_item_summary(h, items, list_stride, sparse);   // (never one of the large blocks' workgroups)
     // the large blocks' workgroups (none in a sparse frame or when there is no large block)
     uint32_t big_groups = 0;
     if (!sparse && !(ablate & 128u)) {

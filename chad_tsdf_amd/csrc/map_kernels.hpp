@@ -171,6 +171,9 @@ __device__ __forceinline__ uint32_t find_or_create_brick(const MapView& m, uint6
 // lanes are the steps of ONE ray, four neighbouring rays per instruction -- the two or three voxels a ray visits in an octant,
 // and what the neighbouring rays of a sorted frame add to the same octants, travel as one request.  Steps beyond the staged rows
 // (stage_rows, whatever LDS the caller has) and frames too large for the staging words go straight to memory as before.
+// (Round 4 also built this form with the walk, ALL block look-ups of a batch and then the atomics in separate phases -- three or four
+// dependent round trips per wave instead of a dozen: 97 us alone either way, the same frame rate in every cfg5 mode on one box.  The
+// kernel is bound by the memory side's rate of atomic requests, 1.6 M at ~20 G/s, not by a wave's chain of look-ups.)
 constexpr uint32_t kStageRow = 65;   // entries of a row: one per lane, and one of padding (the transposed reads stride over rows)
 __device__ __forceinline__ void scatter_update(const float4* __restrict__ pts, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
                                                F3 pos, float res, float recip, float trunc, const MapView& m, uint32_t* pack_counter, uint32_t* pack_seen_host,
@@ -243,123 +246,6 @@ k_update_scatter(const float4* __restrict__ points0, const float4* __restrict__ 
     const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order: k_frame_normals' output (the sort's other buffer)
     __shared__ unsigned long long stage[4][16 * kStageRow];
     scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host, stage[threadIdx.x >> 6], 16u);
-}
-
-// ---- update, sparse frames: the scatter form with the ray walk, the block look-ups and the atomics in separate phases ----------
-// In scatter_update a wave walks its sixty-four rays in lock step and looks a block up whenever ANY lane enters one: about one
-// dependent memory round trip per step, a dozen per batch, and a wave has one batch -- 62 of the kernel's 97 us per cfg5 frame
-// are that chain (scripts/cfg5_costs.py: the kernel without its atomics).  Here a lane first walks its whole ray without touching
-// memory, noting every observation as (which of the ray's blocks, voxel, distance) in LDS and the ray's distinct block keys -- a
-// straight line never re-enters a brick, so they are just the keys in the order met, at most kSparseKeys of them -- in registers;
-// then ALL look-ups of the batch go out together (plain loads; then the compare-and-swaps of the blocks that were not there, also
-// together), and the atomics are issued transposed as before (sixteen lanes = the steps of one ray).  Three or four round trips per
-// batch instead of a dozen.  Launched by the host when the previous frame was sparse (the device mirrors its verdict into
-// host-mapped memory); it is correct for any frame, the tiled kernel is merely faster for dense ones.
-constexpr uint32_t kSparseRows = 16;     // steps of a ray noted in LDS (a ray of trunc = 3 res has at most 14; later steps go straight to memory)
-constexpr uint32_t kSparseKeys = 8;      // distinct blocks of a ray resolved in the batched look-up (later ones are looked up on the spot)
-constexpr uint32_t kSparseNothing = 0xffffffffu;
-__global__ void __launch_bounds__(256)
-k_update_sparse(const float4* __restrict__ points0, const float4* __restrict__ points1, const float4* __restrict__ normals, FrameHeader* __restrict__ h,
-                F3 pos, float res, float recip, float trunc, MapView m, uint32_t* pack_counter, uint32_t* pack_seen_host) {
-    const float4* __restrict__ pts = (h->sort_passes & 1u) ? points0 : points1;   // the frame in processing order (k_frame_normals' output)
-    __shared__ uint32_t notes_all[4][kSparseRows * kStageRow];
-    __shared__ uint32_t bricks_all[4][kSparseKeys * 64];
-    const uint32_t n = h->n_usable;
-    if (n > kPackMaxPoints) {   // too many points for the staging words' count field between folds: two exact atomics per observation, the plain way
-        scatter_update(pts, normals, h, pos, res, recip, trunc, m, pack_counter, pack_seen_host, nullptr, 0u);
-        return;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pack_seen_host, atomicAdd(pack_counter, 1u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t* notes = notes_all[threadIdx.x >> 6];
-    uint32_t* bricks = bricks_all[threadIdx.x >> 6];
-    const float pack_units = kPackOne / trunc;
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long applied = 0;
-    for (size_t base = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) & ~size_t(63); base < n; base += size_t(gridDim.x) * blockDim.x) {
-        const size_t i = base + lane;
-        uint64_t key[kSparseKeys];
-#pragma unroll
-        for (uint32_t j = 0; j < kSparseKeys; j++) key[j] = kEmptyKey;
-        uint32_t nkeys = 0, k = 0;
-        if (i < n) {
-            const float4 q = pts[i], nq = normals[i];
-            const F3 p{q.x, q.y, q.z}, nrm{nq.x, nq.y, nq.z};
-            RayWalk w;
-            w.begin(p, pos, res, recip, trunc);
-            uint64_t last_key = kEmptyKey;
-            uint32_t late_brick = kNoBrick;   // blocks beyond the batched ones, and steps beyond the noted ones: looked up on the spot (rare)
-            do {
-                const uint64_t mc = morton_encode(w.cur.x, w.cur.y, w.cur.z);
-                const uint64_t block = mc & kBlockMask;
-                if (block != last_key) {
-                    last_key = block;
-#pragma unroll
-                    for (uint32_t j = 0; j < kSparseKeys; j++) key[j] = j == nkeys ? block : key[j];   // (no runtime-indexed registers)
-                    nkeys++;
-                    if (nkeys > kSparseKeys || k >= kSparseRows) {
-                        const uint32_t home = hash_block(block, m.hash_mask);
-                        late_brick = __hip_atomic_load(&m.hash_keys[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == block ? home : find_or_create_brick(m, block, home);
-                    }
-                }
-                const float d = observe(w.cur, p, nrm, res, trunc);
-                const bool finite = d == d;
-                if (k < kSparseRows && nkeys <= kSparseKeys) {
-                    // [not a number : 1 | - : 4 | which of the ray's blocks : 3 | voxel : 6 | distance in staging units, two's complement : 18]
-                    notes[k * kStageRow + lane] = (finite ? 0u : 0x80000000u) | ((nkeys - 1u) << 24) | ((uint32_t(mc) & 63u) << 18) | (uint32_t(finite ? int(rintf(d * pack_units)) : 0) & 0x3ffffu);
-                } else {
-                    if (k < kSparseRows) notes[k * kStageRow + lane] = kSparseNothing;
-                    if (nkeys <= kSparseKeys) {   // (a step beyond the noted rows inside a batched block: that block has no slot yet either)
-                        const uint32_t home = hash_block(block, m.hash_mask);
-                        late_brick = __hip_atomic_load(&m.hash_keys[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == block ? home : find_or_create_brick(m, block, home);
-                    }
-                    if (late_brick != kNoBrick) { add_observation_packed(m, size_t(late_brick) * 64 + (uint32_t(mc) & 63u), d, pack_units); applied++; }
-                }
-                k++;
-            } while (w.next());
-        }
-        for (; k < kSparseRows; k++) notes[k * kStageRow + lane] = kSparseNothing;
-        // all look-ups of the batch together: a plain load of every block's home slot ...
-        uint32_t home[kSparseKeys], slot[kSparseKeys];
-        uint64_t seen[kSparseKeys];
-#pragma unroll
-        for (uint32_t j = 0; j < kSparseKeys; j++) {
-            home[j] = hash_block(key[j], m.hash_mask);
-            seen[j] = j < nkeys ? __hip_atomic_load(&m.hash_keys[home[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : key[j];
-        }
-        // ... then one compare-and-swap for every block that was not there (most blocks of a frame are: the sensor moves a fraction of its range)
-#pragma unroll
-        for (uint32_t j = 0; j < kSparseKeys; j++)
-            if (j < nkeys && seen[j] != key[j]) seen[j] = atomicCAS((unsigned long long*)&m.hash_keys[home[j]], (unsigned long long)kEmptyKey, (unsigned long long)key[j]);
-#pragma unroll
-        for (uint32_t j = 0; j < kSparseKeys; j++) {
-            slot[j] = home[j];
-            if (j < nkeys && seen[j] != key[j]) {
-                if (seen[j] == kEmptyKey) {   // claimed (find_or_create_brick)
-                    atomicOr(&m.live_bits[home[j] >> 5], 1u << (home[j] & 31u));
-                    atomicAdd(&m.brick_count[(home[j] & (kCountStripes - 1)) * 16], 1u);
-                } else slot[j] = find_or_create_brick(m, key[j], (home[j] + 1u) & m.hash_mask);   // the home slot holds another block
-            }
-            bricks[j * 64u + lane] = slot[j];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a wave's LDS operations complete in order: notes and slots are there)
-        // the atomics, transposed: sixteen lanes are the steps of ONE ray, four neighbouring rays per instruction
-        const uint32_t step = lane & 15u, ray = lane >> 4;
-        for (uint32_t j = 0; j < 16u; j++) {
-            const uint32_t r = 4u * j + ray;
-            const uint32_t note = notes[step * kStageRow + r];
-            if (note == kSparseNothing) continue;
-            const uint32_t brick = bricks[((note >> 24) & 7u) * 64u + r];
-            if (brick == kNoBrick) continue;
-            const size_t at = size_t(brick) * 64 + ((note >> 18) & 63u);
-            if (note >> 31) { atomicOr(&m.brick_cnt[at], kPoisonedCount); mark_exact_rows(m); }   // NaN (Q4): counted, adds nothing, poisons
-            atomicAdd(&m.brick_pack[at], (1ull << kPackCountShift) + (unsigned long long)(long long)(int(note << 14) >> 14));
-            applied++;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next batch's notes overwrite them
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) applied += __shfl_xor(applied, o);
-    if ((threadIdx.x & 63) == 0 && applied) atomicAdd(&h->n_updates[(blockIdx.x % kUpdateStripes) * 16u], applied);
 }
 
 // ---- stage entries for parity tests ----------------------------------------------------------------------------

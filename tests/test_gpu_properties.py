@@ -416,11 +416,9 @@ def test_two_maps_on_two_threads(chad):
 
 
 def test_sparse_and_dense_frames_interleaved(chad, oracle):
-    """In automatic mode the host launches the update kernel the PREVIOUS frame's verdict asks for (the device mirrors "this frame was
-    sparse" into host-mapped memory): k_update_sparse -- ray walk, batched block look-ups and transposed atomics in separate phases --
-    behind sparse frames, the tiled kernel (which takes its own scatter branch when it meets a sparse frame) otherwise.  Either kernel
-    is correct for either kind of frame; a stream that flips between the kinds puts every combination to the test: sparse after
-    sparse, dense after sparse (the sparse kernel on a dense frame), sparse after dense, dense after dense."""
+    """In automatic mode the update kernel decides on the device which form a frame takes: tiles in LDS for dense frames, the scatter
+    form (staging words, pack-only tables) for sparse ones.  A stream that flips between the kinds puts the hand-overs to the test:
+    staged observations under exact sums and the other way round, a table that stops being pack-only in the middle of a submap."""
     res, trunc = 0.02, 0.06
     rng = np.random.default_rng(5)
 
