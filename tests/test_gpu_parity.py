@@ -292,3 +292,24 @@ def test_a_roll_over_on_every_frame(chad, oracle):
     for s in (0, 1, 2, 3, 4, -1):
         assert_leaves_match(m.export_leaves(s), o.export_leaves(s), 0.10)
     m.close()
+
+
+def test_overflow_of_a_closed_submap_stays_reported(chad):
+    """The capacity flag is per table (a table's clear may not wipe what a frame in flight reports about another table), and a table
+    goes back to the pool when its submap has been archived: what it reported is latched on the host at that point, so a sync at the
+    end of a stream still tells that some submap lost blocks -- until the map is reset."""
+    pts, pos = synth.cfg2_frame(50_000)
+    m = chad.TSDFMap(0.05, 0.10, max_blocks=1000, fixed_capacity=True)
+    m.insert(pts, pos)                                             # ~9 k blocks into 2 048 slots: overflows
+    far = pos + np.array([6.0, 0.0, 0.0], np.float32)
+    small = pts[:200] + np.array([6.0, 0.0, 0.0], np.float32)
+    m.insert(small, far)                                           # more than 5 m on: the overflowed submap is closed, its table cleared and pooled
+    m.insert(small, far)
+    with pytest.raises(chad._lib.ChadError) as err:
+        m.sync()
+    assert err.value.status == chad._lib.ERR_CAPACITY and m.closed_submaps == 1
+    assert m.stats()["blocks"] < 1000                              # the active submap itself is fine
+    m.reset()
+    m.insert(small, far)
+    m.sync()                                                       # nothing reported any more
+    m.close()
