@@ -91,9 +91,11 @@ __device__ __forceinline__ unsigned long long dag_block_scan(unsigned long long 
     *total = wave_sum_[0] + wave_sum_[1] + wave_sum_[2] + wave_sum_[3];
     return before + incl - v;
 }
-// exclusive scan of the chunk sums (one workgroup), total to *total_out
+// exclusive scan of the chunk sums (one workgroup), total to *total_out; with `account`: the batch's totals into the level's scalars
+// too (n candidates, of which the total's high field are new values of the low field's words)
 __global__ void __launch_bounds__(256)
-k_dag_scan_sums(unsigned long long* __restrict__ sums, uint32_t chunks, unsigned long long* __restrict__ total_out) {
+k_dag_scan_sums(unsigned long long* __restrict__ sums, uint32_t chunks, unsigned long long* __restrict__ total_out, DagScalars* __restrict__ account, uint32_t n,
+                unsigned long long extra_dupes) {
     unsigned long long carry = 0;
     for (uint32_t c0 = 0; c0 < chunks; c0 += 256) {
         const uint32_t c = c0 + threadIdx.x;
@@ -103,7 +105,17 @@ k_dag_scan_sums(unsigned long long* __restrict__ sums, uint32_t chunks, unsigned
         if (c < chunks) sums[c] = carry + excl;
         carry += total;
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (account) {
+            const uint32_t fresh = uint32_t(carry >> 32), words = uint32_t(carry);
+            account->batch_base = account->size;
+            account->size += words;
+            account->entries += fresh;
+            account->uniques += fresh;
+            account->dupes += (unsigned long long)(n - fresh) + extra_dupes;
+        }
+    }
 }
 
 // ---- step 0: the blocks that hold leaves, and the cluster level's candidates -------------------------------------------------
@@ -132,7 +144,8 @@ k_dag_block_sums(const uint64_t* __restrict__ tsdf, uint32_t nb, unsigned long l
 __global__ void __launch_bounds__(256)
 k_dag_block_apply(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tsdf, const uint64_t* __restrict__ weight, uint32_t nb, uint32_t saturate,
                   const unsigned long long* __restrict__ sums, uint64_t* __restrict__ vkeys, uint32_t* __restrict__ vblock, uint32_t* __restrict__ oct_before,
-                  uint64_t* __restrict__ cand) {
+                  uint64_t* __restrict__ cand, uint32_t* __restrict__ hist /* [32]: zeroed here for k_dag_parted_histogram */) {
+    if (blockIdx.x == 0 && threadIdx.x < 32) hist[threadIdx.x] = 0u;
     const uint32_t chunks = (nb + kDagBlockChunk - 1) / kDagBlockChunk;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t b = c * kDagBlockChunk + threadIdx.x;
@@ -241,15 +254,6 @@ k_dag_new_sums(const uint32_t* __restrict__ table, const uint32_t* __restrict__ 
         if (threadIdx.x == 0) sums[c] = total;
     }
 }
-// the batch's totals into the level's scalars (one thread, behind k_dag_scan_sums)
-__global__ void k_dag_account(DagScalars* __restrict__ s, const unsigned long long* __restrict__ total, uint32_t n, unsigned long long extra_dupes) {
-    const uint32_t fresh = uint32_t(*total >> 32), words = uint32_t(*total);
-    s->batch_base = s->size;
-    s->size += words;
-    s->entries += fresh;
-    s->uniques += fresh;
-    s->dupes += (unsigned long long)(n - fresh) + extra_dupes;
-}
 template <bool kNode>
 __global__ void __launch_bounds__(256)
 k_dag_commit(uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const void* __restrict__ cand_, uint32_t n, const uint8_t* __restrict__ new_words,
@@ -286,18 +290,19 @@ k_dag_commit(uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, con
         }
     }
 }
-__global__ void __launch_bounds__(256)
-k_dag_resolve(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, uint32_t n, uint32_t* __restrict__ result) {
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
-        if (!result[i]) result[i] = table[pos[i]];
-}
+// the address of candidate i's value behind a batch: its own if it was new (commit wrote it), else what its slot holds now
+struct DagResolved {
+    const uint32_t* result; const uint32_t* table; const uint32_t* pos;
+    __device__ __forceinline__ uint32_t operator[](size_t i) const { const uint32_t r = result[i]; return r ? r : table[pos[i]]; }
+};
 
 // ---- the node levels' candidates -------------------------------------------------------------------------------------------
 // level 19 (one node per block that holds leaves, submap.hpp:70-99): the eight cluster addresses of each tree
 __global__ void __launch_bounds__(256)
 k_dag_block_nodes(const uint64_t* __restrict__ tsdf, const uint32_t* __restrict__ vblock, const uint32_t* __restrict__ oct_before, uint32_t nbv, uint32_t saturate,
-                  const uint32_t* __restrict__ cluster_addr, uint32_t* __restrict__ children /* [2 nbv][8] */) {
+                  DagResolved cluster_addr, uint32_t* __restrict__ children /* [2 nbv][8] */, const uint64_t* __restrict__ vkeys, uint64_t* __restrict__ prefix) {
     for (size_t r = size_t(blockIdx.x) * blockDim.x + threadIdx.x; r < nbv; r += size_t(gridDim.x) * blockDim.x) {
+        prefix[r] = vkeys[r] >> 6;   // the block's digits 0..18: its node's Morton prefix
         const uint32_t b = vblock[r];
         uint32_t k = oct_before[r];
         uint32_t t[8], w[8];
@@ -350,7 +355,7 @@ k_dag_head_apply(const uint64_t* __restrict__ prefix, uint32_t n, const unsigned
     }
 }
 __global__ void __launch_bounds__(256)
-k_dag_parent_nodes(const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ head_pos, uint32_t parents, const uint32_t* __restrict__ child_addr /* [2 n] */,
+k_dag_parent_nodes(const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ head_pos, uint32_t parents, DagResolved child_addr /* [2 n] */,
                    uint32_t* __restrict__ children /* [2 parents][8] */) {
     for (size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x; p < parents; p += size_t(gridDim.x) * blockDim.x) {
         uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -366,10 +371,6 @@ k_dag_parent_nodes(const uint64_t* __restrict__ prefix, const uint32_t* __restri
         out[2] = make_uint4(w[0], w[1], w[2], w[3]); out[3] = make_uint4(w[4], w[5], w[6], w[7]);
     }
 }
-__global__ void k_dag_block_prefix(const uint64_t* __restrict__ vkeys, uint32_t nbv, uint64_t* __restrict__ prefix) {
-    for (size_t r = size_t(blockIdx.x) * blockDim.x + threadIdx.x; r < nbv; r += size_t(gridDim.x) * blockDim.x) prefix[r] = vkeys[r] >> 6;   // digits 0..18
-}
-
 
 // ---- the upper levels in ONE launch -------------------------------------------------------------------------------------------
 // Above the first few levels a submap has a handful of nodes per level (a cfg2 room: 9 409 blocks, 1 500 nodes one level up, 250,
@@ -395,7 +396,7 @@ __device__ __forceinline__ uint32_t dag_scan1024(uint32_t v, uint32_t* total, ui
 
 __global__ void __launch_bounds__(1024)
 k_dag_small_levels(DagLevelsArg L, DagScalars* __restrict__ scalars, int top /* first level to build */, uint32_t n_below,
-                   const uint64_t* __restrict__ prefix_below, const uint32_t* __restrict__ addr_below /* [2 n_below] */, uint32_t* __restrict__ roots_out) {
+                   const uint64_t* __restrict__ prefix_below, DagResolved addr_below /* [2 n_below] */, uint32_t* __restrict__ roots_out) {
     __shared__ uint64_t prefix[2][kDagSmall];
     __shared__ uint32_t addr[2][2 * kDagSmall];
     __shared__ uint32_t cand[2 * kDagSmall][8];
@@ -622,12 +623,11 @@ inline void dag_batch(DeviceDag& d, uint32_t l, const void* cand, uint32_t n, ui
         if (n) hipLaunchKernelGGL(k_dag_probe<true>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, d.d_scalars + l, pos);
         if (n) hipLaunchKernelGGL(k_dag_new_sums<true>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(cand), n, d.d_scalars + l, new_words, sums);
     }
-    hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, total);
-    hipLaunchKernelGGL(k_dag_account, dim3(1), dim3(1), 0, s, d.d_scalars + l, total, n, extra_dupes);
+    hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, total, d.d_scalars + l, n, extra_dupes);
     if (!n) return;
     if (l == kDagDepth) hipLaunchKernelGGL(k_dag_commit<false>, chunked, dim3(256), 0, s, L.table, pos, cand, n, new_words, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
     else hipLaunchKernelGGL(k_dag_commit<true>, chunked, dim3(256), 0, s, L.table, pos, cand, n, new_words, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
-    hipLaunchKernelGGL(k_dag_resolve, flat, dim3(256), 0, s, L.table, pos, n, result);
+    // (no resolve pass: whoever reads the addresses next looks a candidate that was not new up in its slot -- DagResolved)
 }
 
 // Fold one submap: keys[nb] ascending block keys, tsdf[8 nb] / weight[8 nb] (null: the reference's all-ones weights) cluster words, all
@@ -682,9 +682,8 @@ inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys,
     *reinterpret_cast<volatile unsigned long long*>(d.h_small) = 0ull;
     if (nb) {
         hipLaunchKernelGGL(k_dag_block_sums, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, tsdf, nb, f.sums);
-        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, bchunks, d.d_total);
-        hipLaunchKernelGGL(k_dag_block_apply, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, keys, tsdf, weight, nb, f.saturate, f.sums, f.vkeys, f.vblock, f.oct_before, f.ccand);
-        if ((e = hipMemsetAsync(d.d_hist, 0, 128, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, bchunks, d.d_total, static_cast<DagScalars*>(nullptr), 0u, 0ull);
+        hipLaunchKernelGGL(k_dag_block_apply, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, keys, tsdf, weight, nb, f.saturate, f.sums, f.vkeys, f.vblock, f.oct_before, f.ccand, d.d_hist);
         if ((e = hipMemcpyAsync(d.h_small, d.d_total, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -728,8 +727,8 @@ inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool
         uint32_t cur = 0;
         DagFold::LevelScratch* ls = f.ls;
         if (nbv) {
-            hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, f.tsdf, f.vblock, f.oct_before, nbv, f.saturate, f.caddr, ls[cur].children);
-            hipLaunchKernelGGL(k_dag_block_prefix, dag_grid(nbv), dim3(256), 0, s, f.vkeys, nbv, ls[cur].prefix);
+            hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, f.tsdf, f.vblock, f.oct_before, nbv, f.saturate,
+                               DagResolved{f.caddr, d.level[kDagDepth].table, f.cpos}, ls[cur].children, f.vkeys, ls[cur].prefix);
             if ((e = dag_level_reserve(d, kDagDepth - 1, 2 * size_t(nbv), 9, s)) != hipSuccess) return e;
             dag_batch(d, kDagDepth - 1, ls[cur].children, 2 * nbv, ls[cur].pos, ls[cur].addr, f.new_words, f.sums, d.d_total + 2, 0ull, s);
         }
@@ -746,7 +745,9 @@ inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool
                     arg.table[u] = d.level[u].table; arg.raw[u] = static_cast<uint32_t*>(d.level[u].raw);
                     arg.mask[u] = d.level[u].table_slots - 1; arg.capacity[u] = d.level[u].raw_capacity;
                 }
-                hipLaunchKernelGGL(k_dag_small_levels, dim3(1), dim3(1024), 0, s, arg, d.d_scalars, dd, n_below, ls[cur].prefix, ls[cur].addr, d_roots);
+                // (the level below is level dd + 1: its table resolves the candidates that were not new)
+                hipLaunchKernelGGL(k_dag_small_levels, dim3(1), dim3(1024), 0, s, arg, d.d_scalars, dd, n_below, ls[cur].prefix,
+                                   DagResolved{ls[cur].addr, d.level[dd + 1].table, ls[cur].pos}, d_roots);
                 fused = true;
                 break;
             }
@@ -755,16 +756,18 @@ inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool
             DagFold::LevelScratch& here = ls[cur ^ 1];
             const uint32_t chunks = (n_below + kDagChunk - 1) / kDagChunk;
             hipLaunchKernelGGL(k_dag_head_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, f.sums);
-            hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, chunks, d.d_total + 3);
+            hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, chunks, d.d_total + 3, static_cast<DagScalars*>(nullptr), 0u, 0ull);
             hipLaunchKernelGGL(k_dag_head_apply, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, f.sums, here.head_pos, here.prefix, parents);
-            hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents, below.addr, here.children);
+            hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents,
+                               DagResolved{below.addr, d.level[dd + 1].table, below.pos}, here.children);
             if ((e = dag_level_reserve(d, uint32_t(dd), 2 * size_t(parents), 9, s)) != hipSuccess) return e;
             dag_batch(d, uint32_t(dd), here.children, 2 * parents, here.pos, here.addr, f.new_words, f.sums, d.d_total + 4, 0ull, s);
             n_below = parents;
             cur ^= 1;
         }
         // roots and the levels' scalars
-        if ((e = hipMemcpyAsync(d.h_small + 64, fused ? d_roots : ls[cur].addr, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if (!fused) return hipErrorUnknown;   // (cannot happen: level 0 has one node, so the single-workgroup kernel always takes the top)
+        if ((e = hipMemcpyAsync(d.h_small + 64, d_roots, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(d.h_small + 128, d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipEventRecord(f.ready, s)) != hipSuccess) return e;
