@@ -961,8 +961,9 @@ chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
     static const bool no_throttle = std::getenv("CHAD_DEBUG_NO_THROTTLE") != nullptr;   // measurement of the host's own cost per insert only: voids the lifetime contract
     if (f.input_seq && m->h_consumed[turn * 16] != f.input_seq && !no_throttle) {
         const auto t0 = std::chrono::steady_clock::now();
-        while (m->h_consumed[turn * 16] != f.input_seq) {
+        for (uint32_t polls = 0; m->h_consumed[turn * 16] != f.input_seq; polls++) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { HIP_TRY(hipStreamSynchronize(f.prep)); break; }
+            if (m->folding && (polls & 63u) == 63u) TRY(fold_advance(m, false));   // a roll-over's fold waits for the host once on its way: not for as long as the host waits here
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -1309,7 +1310,16 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipEventCreateWithFlags(&m->merge_event, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->spare_cleared, hipEventDisableTiming));
     CREATE_TRY(hipEventCreate(&m->fold_t0)); CREATE_TRY(hipEventCreate(&m->fold_t1));
-    if (m->serial) m->fold_stream = nullptr; else CREATE_TRY(hipStreamCreateWithFlags(&m->fold_stream, hipStreamNonBlocking));
+    if (m->serial) m->fold_stream = nullptr;
+    else if (std::getenv("CHAD_DEBUG_FOLD_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&m->fold_stream, hipStreamNonBlocking));
+    else {
+        // Streams of one priority share a few hardware queues: at the default priority the fold's chain of fifty launches sat in the
+        // queue of one of the frame slots, behind every frame that slot took (two 0.3 ms chains inside one 3.5 ms fold, rocprofv3
+        // --kernel-trace), and the next roll-over waits for the fold.  At the highest priority it shares with the map's stream only.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        CREATE_TRY(hipStreamCreateWithPriority(&m->fold_stream, hipStreamNonBlocking, greatest));
+    }
     CREATE_TRY(hipHostMalloc(&m->merge_host, 32 * 8));
     // what the look-back sort may assume about residency: the pass kernel's real occupancy, shared among the frames in flight
     m->sort_resident = radix_resident_workgroups<PointPayload>();
@@ -1826,23 +1836,24 @@ struct HostClusters { std::vector<uint64_t> keys, tsdf, weight; };
 // Device half: the bricks of a dense submap, ordered by block key, as eight cluster words each -- left on the device in `out`
 // (keys [nb], then tsdf [8 nb], then weight [8 nb] if wanted); `ms`: device time from here to `done` being recorded.
 struct DeviceClusters {   // (in chad_map::cluster_arena: valid until the next call)
-    uint64_t* keys = nullptr; uint64_t* tsdf = nullptr; uint64_t* weight = nullptr;
+    uint64_t* keys = nullptr; uint64_t* tsdf = nullptr; uint64_t* weight = nullptr; uint8_t* mask = nullptr;   // mask[b]: which of block b's eight words hold leaves
 };
 chad_status device_cluster_words(chad_map* m, const uint64_t* keys, const float* sum, const uint32_t* cnt, uint32_t nb, bool want_weights, DeviceClusters& dc) {
     if (!nb) return CHAD_OK;
     TRY(ensure_aux_sort(m, nb));
-    const size_t need = Arena::padded(size_t(nb) * (8 + 64 + (want_weights ? 64 : 0)));
+    const size_t rows = Arena::padded(size_t(nb) * (8 + 64 + (want_weights ? 64 : 0))), need = rows + Arena::padded(nb);
     if (need > m->cluster_arena.cap) HIP_TRY(hipStreamSynchronize(m->stream));   // (the arena is about to move: nobody may still be reading the old one)
     HIP_TRY(m->cluster_arena.reserve(need));
-    uint64_t* d_out = m->cluster_arena.take<uint64_t>(need / 8 - 32);
+    uint64_t* d_out = m->cluster_arena.take<uint64_t>(rows / 8 - 32);
     dc.keys = d_out; dc.tsdf = d_out + nb; dc.weight = want_weights ? dc.tsdf + size_t(nb) * 8 : nullptr;
+    dc.mask = m->cluster_arena.take<uint8_t>(nb);
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
     RadixSortSignals sig;
     sig.fault = m->d_overflow;
     hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
     radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
     hipLaunchKernelGGL(k_leaf_clusters, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, 1.0f / m->trunc /* submap.hpp:23 */,
-                       dc.keys, dc.tsdf, dc.weight);
+                       dc.keys, dc.tsdf, dc.weight, dc.mask);
     HIP_TRY(hipGetLastError());
     return CHAD_OK;
 }
@@ -1882,7 +1893,7 @@ chad_status fold_advance(chad_map* m, bool block) {
     uint32_t root_tsdf = 0, root_weight = 0;
     const int stage_before = m->fold.stage;
     HIP_TRY(dag_fold_advance(m->ddag, m->fold, s, block, &done, &root_tsdf, &root_weight));
-    if (m->fold.stage == 3 && stage_before == 2) HIP_TRY(hipEventRecord(m->fold_t1, s));   // (behind the last stage's kernels)
+    if (m->fold.stage == 2 && stage_before == 1) HIP_TRY(hipEventRecord(m->fold_t1, s));   // (behind the last stage's kernels)
     if (!done) return CHAD_OK;
     float t = 0;
     if (hipEventElapsedTime(&t, m->fold_t0, m->fold_t1) == hipSuccess) m->dag_ms_device = t; else (void)hipGetLastError();
@@ -1893,8 +1904,8 @@ chad_status fold_advance(chad_map* m, bool block) {
 }
 
 // CHAD_FLAG_DAG_ONLY, second half of a roll-over: the closing table's block count is on the host.  Its bricks become cluster words
-// straight from the table (k_table_clusters: no dense copy is ever made), the table is cleared and handed back as the spare, the
-// words are put in key order and the fold into the DAG is begun -- all on the fold's own stream, beside the frames and beside the
+// straight from the table, in key order (k_table_keys, the sort, k_sorted_clusters: no dense copy is ever made), the table is
+// cleared and handed back as the spare and the fold into the DAG is begun -- all on the fold's own stream, beside the frames and beside the
 // map's stream; the fold's later stages are enqueued by the inserts that follow (fold_advance).  Nothing here waits for the device
 // unless the previous submap's fold is still in flight (it shares the scratch).
 chad_status close_into_dag(chad_map* m, uint32_t blocks) {
@@ -1903,44 +1914,44 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
     const size_t nb = std::max<uint32_t>(blocks, 1);
     const size_t words = nb * 8;
-    const size_t need = 2 * Arena::padded(nb * 8) + (saturate ? 4 : 2) * Arena::padded(words * 8);
+    const size_t need = Arena::padded(nb * 8) + Arena::padded(nb * 4) + (saturate ? 2 : 1) * Arena::padded(words * 8) + Arena::padded(nb);
     if (need > m->cluster_arena.cap) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipStreamSynchronize(m->stream)); }   // (the arena is about to move)
     HIP_TRY(m->cluster_arena.reserve(need));
-    uint64_t* raw_keys = m->cluster_arena.take<uint64_t>(nb);
-    uint64_t* raw_tsdf = m->cluster_arena.take<uint64_t>(words);
-    uint64_t* raw_weight = saturate ? m->cluster_arena.take<uint64_t>(words) : nullptr;
     uint64_t* keys = m->cluster_arena.take<uint64_t>(nb);
+    uint32_t* slots = m->cluster_arena.take<uint32_t>(nb);
     uint64_t* tsdf = m->cluster_arena.take<uint64_t>(words);
     uint64_t* weight = saturate ? m->cluster_arena.take<uint64_t>(words) : nullptr;
+    uint8_t* mask = m->cluster_arena.take<uint8_t>(nb);
     m->in_fold_setup = true;
     const chad_status sorter = blocks ? ensure_aux_sort(m, blocks) : CHAD_OK;
     m->in_fold_setup = false;
     TRY(sorter);
     if (s != m->stream) HIP_TRY(hipStreamWaitEvent(s, m->closing_counted, 0));   // behind the closing table's last update (the count was copied behind them)
     HIP_TRY(hipEventRecord(m->fold_t0, s));
-    if (blocks) {
-        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
-        hipLaunchKernelGGL(k_table_clusters, dim3(walk_grid(m->closing_view.hash_mask)), dim3(256), 0, s, m->closing_view, m->d_cursor, blocks, m->trunc, 1.0f / m->trunc /* submap.hpp:23 */, raw_keys, raw_tsdf, raw_weight);
-    }
-    enqueue_clear(m->closing_view, s);
-    HIP_TRY(hipGetLastError());
-    m->spare_flags = std::max(m->spare_flags, 1);
-    if (s != m->stream) { HIP_TRY(hipEventRecord(m->spare_cleared, s)); m->spare_cleared_pending = true; }
-    m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: spare_ready() makes the map's stream wait for it
-    m->closing_view = MapView{}; m->closing = false;
-    if (blocks) {   // key order (all eight digits: full 63-bit codes), the rows gathered behind the keys
+    if (blocks) {   // the live slots' keys, their order (all eight digits: full 63-bit codes), then the bricks in that order
         RadixSortSignals sig;
         sig.fault = m->d_overflow;
-        hipLaunchKernelGGL(k_copy_u64, grid_for(blocks), dim3(256), 0, s, raw_keys, m->aux_sort.keys[0], blocks);
+        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
+        hipLaunchKernelGGL(k_table_keys, dim3(std::max(1u, std::min(2048u, ((m->closing_view.hash_mask >> 5) + 256u) / 256u))), dim3(256), 0, s, m->closing_view, m->d_cursor, blocks, m->aux_sort.keys[0], slots);
         radix_sort_enqueue(m->aux_sort, blocks, kMaxPasses, nullptr, s, 0, 0, sig);
         HIP_TRY(hipMemcpyAsync(keys, m->aux_sort.keys[0], size_t(blocks) * 8, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_gather_clusters, grid_for(size_t(blocks) * 8), dim3(256), 0, s, (const uint32_t*)m->aux_sort.idx[0], blocks, raw_tsdf, raw_weight, tsdf, weight);
+        hipLaunchKernelGGL(k_sorted_clusters, grid_for(size_t(blocks) * 16, 256, 4096), dim3(256), 0, s, m->closing_view, (const uint32_t*)m->aux_sort.idx[0], (const uint32_t*)slots, blocks, m->trunc,
+                           1.0f / m->trunc /* submap.hpp:23 */, tsdf, weight, mask);
         HIP_TRY(hipGetLastError());
     }
+    // the table's clear: off the fold's chain (the next roll-over waits for the fold, and for the spare only then) -- on the map's stream,
+    // behind the kernel that read the bricks; nothing the frames wait for is enqueued there before the next roll-over
+    if (s != m->stream) { HIP_TRY(hipEventRecord(m->spare_cleared, s)); HIP_TRY(hipStreamWaitEvent(m->stream, m->spare_cleared, 0)); }
+    enqueue_clear(m->closing_view, m->stream);
+    HIP_TRY(hipGetLastError());
+    m->spare_flags = std::max(m->spare_flags, 1);
+    m->spare_cleared_pending = false;   // (spare_ready: the map's stream is where the table is swapped in)
+    m->spare = m->closing_view; m->has_spare = true;
+    m->closing_view = MapView{}; m->closing = false;
     Submap gone;   // a closed submap without bricks: it is its DAG (read back with chad_map_dag_leaves, the iterator, the mesh from the DAG)
     gone.blocks = blocks; gone.released = true;
     m->closed.push_back(gone);
-    HIP_TRY(dag_fold_begin(m->ddag, m->fold, keys, tsdf, weight, blocks, s));
+    HIP_TRY(dag_fold_begin(m->ddag, m->fold, keys, tsdf, weight, mask, blocks, s));
     m->folding = true;
     return CHAD_OK;
 }
@@ -1955,6 +1966,7 @@ chad_status fold_archived(chad_map* m) {
     while (m->folding) TRY(fold_advance(m, true));
     if (m->dag_roots.size() >= m->closed.size()) return CHAD_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));   // (the folds below run on the map's stream: behind whatever a level's growth left on the other one)
     const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
     float ms_device = 0;
     double ms_host = 0;
@@ -1973,7 +1985,7 @@ chad_status fold_archived(chad_map* m) {
             HIP_TRY(hipEventRecord(ev.e0, m->stream));
             DeviceClusters dc;
             TRY(device_cluster_words(m, s.keys, s.sum, s.cnt, s.blocks, saturate, dc));
-            HIP_TRY(dag_device_add_submap(m->ddag, m->fold, dc.keys, dc.tsdf, saturate ? dc.weight : nullptr, s.blocks, m->stream, &root_tsdf, &root_weight));
+            HIP_TRY(dag_device_add_submap(m->ddag, m->fold, dc.keys, dc.tsdf, saturate ? dc.weight : nullptr, dc.mask, s.blocks, m->stream, &root_tsdf, &root_weight));
             HIP_TRY(hipEventRecord(ev.e1, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
             float t = 0;
@@ -1991,6 +2003,7 @@ chad_status fold_archived(chad_map* m) {
 chad_status dag_host(chad_map* m) {
     if (!m->dag_mirror_stale) return CHAD_OK;
     const auto t0 = std::chrono::steady_clock::now();
+    if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));   // (a level that grew behind the last fold is being copied there)
     HIP_TRY(dag_device_mirror(m->ddag, m->dag, m->stream));
     m->dag_ms_host += float(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     m->dag_mirror_stale = false;
@@ -2049,7 +2062,7 @@ chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
         out->uniques[kDagDepth] = m->dag.clusters.uniques; out->dupes[kDagDepth] = m->dag.clusters.dupes;
     }
     out->ms_device = m->dag_ms_device; out->ms_host = m->dag_ms_host;
-    out->device_bytes = m->ddag.arena_cap;
+    out->device_bytes = m->ddag.arena_cap + m->ddag.outgrown_bytes;
     for (uint32_t l = 0; l <= kDagDepth && m->ddag.ready; l++) out->device_bytes += size_t(m->ddag.level[l].table_slots) * 4 + size_t(m->ddag.level[l].raw_capacity) * (l == kDagDepth ? 8 : 4);
     return CHAD_OK;
 }

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "dag.hpp"
@@ -91,111 +92,131 @@ __device__ __forceinline__ unsigned long long dag_block_scan(unsigned long long 
     *total = wave_sum_[0] + wave_sum_[1] + wave_sum_[2] + wave_sum_[3];
     return before + incl - v;
 }
-// exclusive scan of the chunk sums (one workgroup), total to *total_out; with `account`: the batch's totals into the level's scalars
-// too (n candidates, of which the total's high field are new values of the low field's words)
-__global__ void __launch_bounds__(256)
-k_dag_scan_sums(unsigned long long* __restrict__ sums, uint32_t chunks, unsigned long long* __restrict__ total_out, DagScalars* __restrict__ account, uint32_t n,
-                unsigned long long extra_dupes) {
-    unsigned long long carry = 0;
-    for (uint32_t c0 = 0; c0 < chunks; c0 += 256) {
-        const uint32_t c = c0 + threadIdx.x;
-        const unsigned long long v = c < chunks ? sums[c] : 0ull;
-        unsigned long long total;
-        const unsigned long long excl = dag_block_scan(v, &total);
-        if (c < chunks) sums[c] = carry + excl;
-        carry += total;
-    }
-    if (threadIdx.x == 0) {
-        *total_out = carry;
-        if (account) {
-            const uint32_t fresh = uint32_t(carry >> 32), words = uint32_t(carry);
-            account->batch_base = account->size;
-            account->size += words;
-            account->entries += fresh;
-            account->uniques += fresh;
-            account->dupes += (unsigned long long)(n - fresh) + extra_dupes;
-        }
-    }
+// ---- steps over chunks in sequence order ------------------------------------------------------------------------------------------
+// A step over chunks in sequence order: workgroup b takes a CONTIGUOUS run of chunks, so what lies before its first chunk is a plain sum
+// of the chunk totals before it (no scan step, no barrier for one).
+struct DagRun { uint32_t lo, hi; };
+__device__ __forceinline__ DagRun dag_my_chunks(uint32_t chunks) {
+    const uint32_t per = (chunks + gridDim.x - 1) / gridDim.x, lo = min(blockIdx.x * per, chunks);
+    return DagRun{lo, min(lo + per, chunks)};
+}
+__device__ __forceinline__ unsigned long long dag_sum_of(const unsigned long long* sums, uint32_t n) {   // every thread of the workgroup calls it
+    unsigned long long mine = 0, total;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) mine += sums[i];
+    dag_block_scan(mine, &total);
+    return total;
 }
 
 // ---- step 0: the blocks that hold leaves, and the cluster level's candidates -------------------------------------------------
 // per block: [valid : 32 | non-empty octets : 32]
-__device__ __forceinline__ unsigned long long dag_block_value(const uint64_t* __restrict__ tsdf, uint32_t b) {
-    uint32_t octets = 0;
-#pragma unroll
-    for (uint32_t o = 0; o < 8; o++) octets += tsdf[size_t(b) * 8 + o] != kClusterEmpty ? 1u : 0u;
-    return octets ? (1ull << 32) | octets : 0ull;   // a brick that was claimed but never written has no counterpart in the octree (dag.hpp)
-}
-constexpr uint32_t kDagBlockChunk = 256;   // blocks per workgroup step of the two block kernels: one block (64 bytes of cluster words) per thread
-__global__ void __launch_bounds__(256)
-k_dag_block_sums(const uint64_t* __restrict__ tsdf, uint32_t nb, unsigned long long* __restrict__ sums) {
-    const uint32_t chunks = (nb + kDagBlockChunk - 1) / kDagBlockChunk;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+constexpr uint32_t kDagStepGrid = 2048;   // workgroups of a chunked step at most (each sums the chunk totals before its run)
+constexpr uint32_t kDagBlockChunk = 256;   // blocks per chunk of the two block steps: one block (64 bytes of cluster words) per thread
+// (omask[b]: which of block b's eight words hold leaves -- written by the kernels that make the words, so that counting the blocks
+// does not read their 64-byte rows again)
+__device__ __forceinline__ void dag_step_block_sums(const uint8_t* __restrict__ omask, uint32_t nb, unsigned long long* sums) {
+    const DagRun run = dag_my_chunks((nb + kDagBlockChunk - 1) / kDagBlockChunk);
+    for (uint32_t c = run.lo; c < run.hi; c++) {
         const uint32_t b = c * kDagBlockChunk + threadIdx.x;
+        const uint32_t octets = b < nb ? uint32_t(__popc(uint32_t(omask[b]))) : 0u;
         unsigned long long total;
-        dag_block_scan(b < nb ? dag_block_value(tsdf, b) : 0ull, &total);
+        dag_block_scan(octets ? (1ull << 32) | octets : 0ull, &total);   // a brick that was claimed but never written has no counterpart in the octree (dag.hpp)
         if (threadIdx.x == 0) sums[c] = total;
     }
 }
 // The cluster level's sequence of additions (submap.hpp:70-99): for every non-empty octet, in block and octet order, the
 // signed-distance word and then the weight word.  saturate == 0 (the reference's own behaviour, Q6): every weight word is all
 // ones, so the sequence is [t0, ones, t1, t2, ...] -- the constant is looked up once, as the second candidate, and the other
-// additions of it are counted as duplicates by the host.  saturate != 0: [t0, w0, t1, w1, ...].
-__global__ void __launch_bounds__(256)
-k_dag_block_apply(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tsdf, const uint64_t* __restrict__ weight, uint32_t nb, uint32_t saturate,
-                  const unsigned long long* __restrict__ sums, uint64_t* __restrict__ vkeys, uint32_t* __restrict__ vblock, uint32_t* __restrict__ oct_before,
-                  uint64_t* __restrict__ cand, uint32_t* __restrict__ hist /* [32]: zeroed here for k_dag_parted_histogram */) {
-    if (blockIdx.x == 0 && threadIdx.x < 32) hist[threadIdx.x] = 0u;
-    const uint32_t chunks = (nb + kDagBlockChunk - 1) / kDagBlockChunk;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+// additions of it are counted as duplicates.  saturate != 0: [t0, w0, t1, w1, ...].
+__device__ __forceinline__ void dag_step_block_apply(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tsdf, const uint64_t* __restrict__ weight, const uint8_t* __restrict__ omask,
+                                                     uint32_t nb, uint32_t saturate, const unsigned long long* sums, uint64_t* vkeys, uint32_t* vblock, uint32_t* oct_before, uint64_t* cand) {
+    __shared__ uint32_t first_octet[kDagBlockChunk];
+    __shared__ uint8_t mask_of[kDagBlockChunk];
+    const DagRun run = dag_my_chunks((nb + kDagBlockChunk - 1) / kDagBlockChunk);
+    unsigned long long before = dag_sum_of(sums, run.lo);
+    for (uint32_t c = run.lo; c < run.hi; c++) {
         const uint32_t b = c * kDagBlockChunk + threadIdx.x;
-        uint64_t t[8];
-        uint32_t octets = 0;
-#pragma unroll
-        for (uint32_t o = 0; o < 8; o++) { t[o] = b < nb ? tsdf[size_t(b) * 8 + o] : kClusterEmpty; octets += t[o] != kClusterEmpty ? 1u : 0u; }
+        const uint32_t mask = b < nb ? uint32_t(omask[b]) : 0u, octets = uint32_t(__popc(mask));
         const unsigned long long v = octets ? (1ull << 32) | octets : 0ull;
         unsigned long long total;
-        const unsigned long long at = sums[c] + dag_block_scan(v, &total);
-        if (!v) continue;
-        const uint32_t rank = uint32_t(at >> 32);
-        uint32_t k = uint32_t(at);
-        vkeys[rank] = keys[b]; vblock[rank] = b; oct_before[rank] = k;
+        const unsigned long long at = before + dag_block_scan(v, &total);
+        before += total;
+        first_octet[threadIdx.x] = uint32_t(at); mask_of[threadIdx.x] = uint8_t(mask);
+        if (v) { const uint32_t rank = uint32_t(at >> 32); vkeys[rank] = keys[b]; vblock[rank] = b; oct_before[rank] = uint32_t(at); }
+        __syncthreads();
+        // the chunk's words, a word per thread and turn (a block's row of eight is one line): a thread per block read its row in a chain
+        uint64_t word[8], wword[8];
+        uint32_t at_k[8];
 #pragma unroll
-        for (uint32_t o = 0; o < 8; o++) {
-            if (t[o] == kClusterEmpty) continue;
-            if (saturate) { cand[2 * size_t(k)] = t[o]; cand[2 * size_t(k) + 1] = weight[size_t(b) * 8 + o]; }
-            else { cand[k ? k + 1 : 0] = t[o]; if (!k) cand[1] = kClusterEmpty; }
-            k++;
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t w = j * kDagBlockChunk + threadIdx.x, lb = w >> 3, o = w & 7u, m = mask_of[lb];
+            const bool on = (m >> o) & 1u;
+            at_k[j] = on ? first_octet[lb] + uint32_t(__popc(m & ((1u << o) - 1u))) : 0xffffffffu;
+            const size_t from = (size_t(c) * kDagBlockChunk + lb) * 8 + o;
+            word[j] = on ? tsdf[from] : 0ull;
+            wword[j] = on && saturate ? weight[from] : 0ull;
         }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t k = at_k[j];
+            if (k == 0xffffffffu) continue;
+            if (saturate) { cand[2 * size_t(k)] = word[j]; cand[2 * size_t(k) + 1] = wword[j]; }
+            else { cand[k ? k + 1 : 0] = word[j]; if (!k) cand[1] = kClusterEmpty; }
+        }
+        __syncthreads();
     }
 }
 // candidate index of the k-th non-empty octet's signed-distance word / weight word
 __device__ __forceinline__ uint32_t dag_cluster_cand_t(uint32_t k, uint32_t saturate) { return saturate ? 2u * k : (k ? k + 1u : 0u); }
 __device__ __forceinline__ uint32_t dag_cluster_cand_w(uint32_t k, uint32_t saturate) { return saturate ? 2u * k + 1u : 1u; }
 
-// how many nodes every level gets from this submap: block b > 0 opens a new node at every level below the first digit in which its
-// key parts from its predecessor's (digits 0..18 name a block: three bits per level, root first -- octree.hpp:45-47)
+// Step 0 in three launches: chunk totals | the valid blocks' keys and candidates | how many nodes every level gets from this submap:
+// block b > 0 opens a new node at every level below the first digit in which its key parts from its predecessor's (digits 0..18
+// name a block: three bits per level, root first -- octree.hpp:45-47).
 __global__ void __launch_bounds__(256)
-k_dag_parted_histogram(const uint64_t* __restrict__ vkeys, uint32_t nbv, uint32_t* __restrict__ hist /* [32], zeroed */) {
+k_dag_block_sums(const uint8_t* __restrict__ omask, uint32_t nb, unsigned long long* __restrict__ sums, uint32_t* __restrict__ hist /* [32]: zeroed for k_dag_parted_histogram */) {
+    if (blockIdx.x == 0 && threadIdx.x < 32) hist[threadIdx.x] = 0u;
+    dag_step_block_sums(omask, nb, sums);
+}
+__global__ void __launch_bounds__(256)
+k_dag_block_apply(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tsdf, const uint64_t* __restrict__ weight, const uint8_t* __restrict__ omask, uint32_t nb, uint32_t saturate,
+                  const unsigned long long* __restrict__ sums, uint64_t* __restrict__ vkeys, uint32_t* __restrict__ vblock, uint32_t* __restrict__ oct_before,
+                  uint64_t* __restrict__ cand, unsigned long long* __restrict__ total /* [valid blocks : 32 | non-empty octets : 32] */) {
+    dag_step_block_apply(keys, tsdf, weight, omask, nb, saturate, sums, vkeys, vblock, oct_before, cand);
+    if (blockIdx.x == 0) {
+        const unsigned long long all = dag_sum_of(sums, (nb + kDagBlockChunk - 1) / kDagBlockChunk);
+        if (threadIdx.x == 0) *total = all;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_dag_parted_histogram(const uint64_t* __restrict__ vkeys, const unsigned long long* __restrict__ total, uint32_t* __restrict__ hist /* [32], zeroed */) {
     __shared__ uint32_t local[32];
+    const uint32_t nbv = uint32_t(*total >> 32);   // (the host does not know it yet: the grid is sized for all blocks)
     if (threadIdx.x < 32) local[threadIdx.x] = 0;
     __syncthreads();
     for (size_t b = size_t(blockIdx.x) * blockDim.x + threadIdx.x + 1; b < nbv; b += size_t(gridDim.x) * blockDim.x) {
         const uint64_t x = vkeys[b] ^ vkeys[b - 1];
-        const uint32_t parted = (62u - (63u - uint32_t(__clzll((long long)x)))) / 3u;   // dag.hpp: first depth at which the two paths part
-        atomicAdd(&local[parted & 31u], 1u);
+        const uint32_t parted = ((62u - (63u - uint32_t(__clzll((long long)x)))) / 3u) & 31u;   // dag.hpp: first depth at which the two paths part
+        // (neighbouring blocks part at the deepest levels nearly always: one LDS atomic per value the wave holds, not per lane)
+        for (uint64_t left = __ballot(true); left;) {
+            const uint32_t d0 = uint32_t(__builtin_amdgcn_readlane(int(parted), int(__ffsll((unsigned long long)left)) - 1));
+            const uint64_t peers = __ballot(parted == d0) & left;
+            if (parted == d0 && (peers & ((1ull << (threadIdx.x & 63u)) - 1ull)) == 0ull) atomicAdd(&local[d0], uint32_t(__popcll(peers)));
+            left &= ~peers;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 32 && local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
 }
 
-// ---- the batch: probe / count / commit / resolve -----------------------------------------------------------------------------
+// ---- a level's batch: probe | count | commit -----------------------------------------------------------------------------------
 // kNode: candidates are rows of eight child addresses (0 = no child); else 64-bit cluster words.
+struct DagLevelRef { uint32_t* table; void* raw; uint32_t mask, capacity; };
+
 template <bool kNode>
-__global__ void __launch_bounds__(256)
-k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict__ raw_, const void* __restrict__ cand_, uint32_t n, const DagScalars* __restrict__ scalars,
-            uint32_t* __restrict__ pos) {
-    const uint32_t base = scalars->size;   // addresses below it are stored values; base + i marks a slot claimed by candidate i of this batch
+__device__ __forceinline__ void dag_step_probe(const DagLevelRef& L, const void* cand_, uint32_t n, uint32_t base, uint32_t* pos) {
+    // addresses below `base` are stored values; base + i marks a slot claimed by candidate i of this batch
+    uint32_t* table = L.table;
+    const uint32_t mask = L.mask;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         uint32_t mine[8];
         uint64_t value = 0;
@@ -220,7 +241,7 @@ k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict_
                     for (int k = 0; k < 8; k++) same = same && other[k] == mine[k];
                 } else same = static_cast<const uint64_t*>(cand_)[j] == value;
                 if (same && v > me) atomicMin(&table[p], me);   // the first candidate of a value owns its slot
-            } else same = kNode ? dag_node_equals(static_cast<const uint32_t*>(raw_), v, mine) : static_cast<const uint64_t*>(raw_)[v] == value;
+            } else same = kNode ? dag_node_equals(static_cast<const uint32_t*>(L.raw), v, mine) : static_cast<const uint64_t*>(L.raw)[v] == value;
             if (same) break;
         }
         pos[i] = p;
@@ -228,24 +249,21 @@ k_dag_probe(uint32_t* __restrict__ table, uint32_t mask, const void* __restrict_
 }
 // words candidate i adds to the store: 0 unless it owns its slot (the first candidate of a value the store does not hold yet)
 template <bool kNode>
-__device__ __forceinline__ uint32_t dag_new_words(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t base, uint32_t i) {
-    if (table[pos[i]] != base + i) return 0u;
+__device__ __forceinline__ uint32_t dag_new_words(const uint32_t* table, const uint32_t* pos, const uint32_t* cand, uint32_t base, uint32_t i) {
+    if (__hip_atomic_load(&table[pos[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != base + i) return 0u;
     uint32_t words = 1;
     if (kNode) { uint32_t c[8]; dag_load8(cand + size_t(i) * 8, c); for (int k = 0; k < 8; k++) words += c[k] ? 1u : 0u; }
     return words;
 }
 template <bool kNode>
-__global__ void __launch_bounds__(256)
-k_dag_new_sums(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cand, uint32_t n, const DagScalars* __restrict__ scalars,
-               uint8_t* __restrict__ new_words, unsigned long long* __restrict__ sums) {
-    const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
-    const uint32_t base = scalars->size;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+__device__ __forceinline__ void dag_step_count(const DagLevelRef& L, const uint32_t* pos, const void* cand, uint32_t n, uint32_t base, uint8_t* new_words, unsigned long long* sums) {
+    const DagRun run = dag_my_chunks((n + kDagChunk - 1) / kDagChunk);
+    for (uint32_t c = run.lo; c < run.hi; c++) {
         unsigned long long mine = 0;   // [new values : 32 | their words : 32]
         for (uint32_t j = 0; j < kDagPer; j++) {
             const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
             if (i >= n) break;
-            const uint32_t w = dag_new_words<kNode>(table, pos, cand, base, i);
+            const uint32_t w = dag_new_words<kNode>(L.table, pos, static_cast<const uint32_t*>(cand), base, i);
             new_words[i] = uint8_t(w);   // (kept: once values are committed a slot no longer tells who owned it)
             mine += w ? (1ull << 32) | w : 0ull;
         }
@@ -254,13 +272,15 @@ k_dag_new_sums(const uint32_t* __restrict__ table, const uint32_t* __restrict__ 
         if (threadIdx.x == 0) sums[c] = total;
     }
 }
+// the new values get their addresses behind the store's end in sequence order -- the order of first occurrence, as the reference
+// hands them out -- append their words and put the address into their slot; result[i] = 0 for a candidate that was not new
 template <bool kNode>
-__global__ void __launch_bounds__(256)
-k_dag_commit(uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, const void* __restrict__ cand_, uint32_t n, const uint8_t* __restrict__ new_words,
-             const unsigned long long* __restrict__ sums, const DagScalars* __restrict__ s, void* __restrict__ raw_, uint32_t raw_capacity, uint32_t* __restrict__ result) {
+__device__ __forceinline__ void dag_step_commit(const DagLevelRef& L, const uint32_t* pos, const void* cand_, uint32_t n, const uint8_t* new_words, const unsigned long long* sums,
+                                                uint32_t base, DagScalars* s, unsigned long long extra_dupes, uint32_t* result) {
     const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
-    const uint32_t base = s->batch_base;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const DagRun run = dag_my_chunks(chunks);
+    unsigned long long before = dag_sum_of(sums, run.lo);
+    for (uint32_t c = run.lo; c < run.hi; c++) {
         unsigned long long v[kDagPer], mine = 0;
         for (uint32_t j = 0; j < kDagPer; j++) {
             const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
@@ -268,47 +288,58 @@ k_dag_commit(uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, con
             mine += v[j];
         }
         unsigned long long total;
-        uint32_t at = base + uint32_t(sums[c] + dag_block_scan(mine, &total));   // (low field: words before this candidate among the batch's new values)
+        uint32_t at = base + uint32_t(before + dag_block_scan(mine, &total));   // (low field: words before this candidate among the batch's new values)
+        before += total;
         for (uint32_t j = 0; j < kDagPer; j++) {
             const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
             if (i >= n) break;
             if (!v[j]) { result[i] = 0u; continue; }
             const uint32_t words = uint32_t(v[j]);
-            if (at + words <= raw_capacity) {   // (the host sizes the store for the worst case: always true)
+            if (at + words <= L.capacity) {   // (the host sizes the store for the worst case: always true)
                 if (kNode) {
                     uint32_t ch[8];
                     dag_load8(static_cast<const uint32_t*>(cand_) + size_t(i) * 8, ch);
-                    uint32_t* raw = static_cast<uint32_t*>(raw_);
+                    uint32_t* raw = static_cast<uint32_t*>(L.raw);
                     uint32_t mask = 0, w = at + 1;
                     for (int k = 0; k < 8; k++) if (ch[k]) { mask |= 1u << k; raw[w++] = ch[k]; }
                     raw[at] = mask;
-                } else static_cast<uint64_t*>(raw_)[at] = static_cast<const uint64_t*>(cand_)[i];
+                } else static_cast<uint64_t*>(L.raw)[at] = static_cast<const uint64_t*>(cand_)[i];
             }
-            table[pos[i]] = at;
+            L.table[pos[i]] = at;
             result[i] = at;
             at += words;
         }
     }
+    if (blockIdx.x == 0) {   // the batch's totals into the level's scalars (nobody reads `size` inside this launch: the count step left the batch's base in batch_base)
+        const unsigned long long all = dag_sum_of(sums, chunks);
+        if (threadIdx.x == 0) {
+            const uint32_t fresh = uint32_t(all >> 32), words = uint32_t(all);
+            s->size = base + words;
+            s->entries += fresh;
+            s->uniques += fresh;
+            s->dupes += (unsigned long long)(n - fresh) + extra_dupes;
+        }
+    }
 }
-// the address of candidate i's value behind a batch: its own if it was new (commit wrote it), else what its slot holds now
-struct DagResolved {
-    const uint32_t* result; const uint32_t* table; const uint32_t* pos;
-    __device__ __forceinline__ uint32_t operator[](size_t i) const { const uint32_t r = result[i]; return r ? r : table[pos[i]]; }
-};
+// the address of candidate i's value behind a batch: its own if it was new (commit wrote it), else what its slot holds now.  (Read
+// where it is needed instead -- two dependent loads inside the consumers' per-node loops -- the launch saved costs 0.2 ms per cfg5 fold.)
+__device__ __forceinline__ void dag_step_resolve(const uint32_t* table, const uint32_t* pos, uint32_t n, uint32_t* result) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+        if (!result[i]) result[i] = table[pos[i]];
+}
 
 // ---- the node levels' candidates -------------------------------------------------------------------------------------------
 // level 19 (one node per block that holds leaves, submap.hpp:70-99): the eight cluster addresses of each tree
-__global__ void __launch_bounds__(256)
-k_dag_block_nodes(const uint64_t* __restrict__ tsdf, const uint32_t* __restrict__ vblock, const uint32_t* __restrict__ oct_before, uint32_t nbv, uint32_t saturate,
-                  DagResolved cluster_addr, uint32_t* __restrict__ children /* [2 nbv][8] */, const uint64_t* __restrict__ vkeys, uint64_t* __restrict__ prefix) {
+__device__ __forceinline__ void dag_step_block_nodes(const uint8_t* __restrict__ omask, const uint32_t* __restrict__ vblock, const uint32_t* __restrict__ oct_before, uint32_t nbv,
+                                                     uint32_t saturate, const uint32_t* cluster_addr /* resolved */, uint32_t* children /* [2 nbv][8] */, const uint64_t* __restrict__ vkeys, uint64_t* prefix) {
     for (size_t r = size_t(blockIdx.x) * blockDim.x + threadIdx.x; r < nbv; r += size_t(gridDim.x) * blockDim.x) {
         prefix[r] = vkeys[r] >> 6;   // the block's digits 0..18: its node's Morton prefix
-        const uint32_t b = vblock[r];
+        const uint32_t mask = omask[vblock[r]];
         uint32_t k = oct_before[r];
         uint32_t t[8], w[8];
 #pragma unroll
         for (uint32_t o = 0; o < 8; o++) {
-            const bool there = tsdf[size_t(b) * 8 + o] != kClusterEmpty;
+            const bool there = (mask >> o) & 1u;
             t[o] = there ? cluster_addr[dag_cluster_cand_t(k, saturate)] : 0u;
             w[o] = there ? cluster_addr[dag_cluster_cand_w(k, saturate)] : 0u;
             k += there ? 1u : 0u;
@@ -319,52 +350,54 @@ k_dag_block_nodes(const uint64_t* __restrict__ tsdf, const uint32_t* __restrict_
     }
 }
 // level d from level d + 1: node j of the level below (prefix[j] = its digits 0..d, i.e. its Morton prefix) belongs to the parent
-// prefix[j] >> 3 and sits in child slot prefix[j] & 7.  Heads (first child of a parent) per chunk, then their ranks.
-__global__ void __launch_bounds__(256)
-k_dag_head_sums(const uint64_t* __restrict__ prefix, uint32_t n, unsigned long long* __restrict__ sums) {
-    const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+// prefix[j] >> 3 and sits in child slot prefix[j] & 7.  Heads (first child of a parent) per chunk; then every head, at its rank,
+// leaves its position and its parent's prefix.  (Letting the head gather its parent's rows as well saves a launch and costs three
+// times the two steps' time: a thread then walks up to eight heads of up to eight children in a dependent chain.)
+__device__ __forceinline__ bool dag_is_head(const uint64_t* prefix, uint32_t i) { return i == 0 || (prefix[i] >> 3) != (prefix[i - 1] >> 3); }
+__device__ __forceinline__ void dag_step_head_sums(const uint64_t* prefix, uint32_t n, unsigned long long* sums) {
+    const DagRun run = dag_my_chunks((n + kDagChunk - 1) / kDagChunk);
+    for (uint32_t c = run.lo; c < run.hi; c++) {
         unsigned long long mine = 0;
-        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j; if (i < n && (i == 0 || (prefix[i] >> 3) != (prefix[i - 1] >> 3))) mine++; }
+        for (uint32_t j = 0; j < kDagPer; j++) { const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j; if (i < n && dag_is_head(prefix, i)) mine++; }
         unsigned long long total;
         dag_block_scan(mine, &total);
         if (threadIdx.x == 0) sums[c] = total;
     }
 }
-__global__ void __launch_bounds__(256)
-k_dag_head_apply(const uint64_t* __restrict__ prefix, uint32_t n, const unsigned long long* __restrict__ sums, uint32_t* __restrict__ head_pos /* [parents + 1] */,
-                 uint64_t* __restrict__ parent_prefix, uint32_t parents) {
-    const uint32_t chunks = (n + kDagChunk - 1) / kDagChunk;
+__device__ __forceinline__ void dag_step_heads(const uint64_t* prefix, uint32_t n, const unsigned long long* sums, uint32_t parents, uint32_t* head_pos /* [parents + 1] */,
+                                               uint64_t* parent_prefix) {
+    const DagRun run = dag_my_chunks((n + kDagChunk - 1) / kDagChunk);
+    unsigned long long before = dag_sum_of(sums, run.lo);
     if (blockIdx.x == 0 && threadIdx.x == 0) head_pos[parents] = n;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    for (uint32_t c = run.lo; c < run.hi; c++) {
         unsigned long long mine = 0;
-        bool head[kDagPer];
+        uint32_t heads = 0;
         for (uint32_t j = 0; j < kDagPer; j++) {
             const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
-            head[j] = i < n && (i == 0 || (prefix[i] >> 3) != (prefix[i - 1] >> 3));
-            mine += head[j] ? 1u : 0u;
+            if (i < n && dag_is_head(prefix, i)) { heads |= 1u << j; mine++; }
         }
         unsigned long long total;
-        uint32_t at = uint32_t(sums[c] + dag_block_scan(mine, &total));
-        for (uint32_t j = 0; j < kDagPer; j++)
-            if (head[j]) {
-                const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
-                if (at < parents) { head_pos[at] = i; parent_prefix[at] = prefix[i] >> 3; }
-                at++;
-            }
+        uint32_t at = uint32_t(before + dag_block_scan(mine, &total));
+        before += total;
+        for (uint32_t j = 0; j < kDagPer; j++) {
+            if (!((heads >> j) & 1u)) continue;
+            const uint32_t i = c * kDagChunk + threadIdx.x * kDagPer + j;
+            if (at < parents) { head_pos[at] = i; parent_prefix[at] = prefix[i] >> 3; }
+            at++;
+        }
     }
 }
-__global__ void __launch_bounds__(256)
-k_dag_parent_nodes(const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ head_pos, uint32_t parents, DagResolved child_addr /* [2 n] */,
-                   uint32_t* __restrict__ children /* [2 parents][8] */) {
+// a parent's two rows of child addresses: its children are the nodes [head_pos[p], head_pos[p + 1]) of the level below (at most eight)
+__device__ __forceinline__ void dag_step_parents(const uint64_t* prefix, const uint32_t* head_pos, uint32_t parents, const uint32_t* child_addr /* [2 n], resolved */,
+                                                 uint32_t* children /* [2 parents][8] */) {
     for (size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x; p < parents; p += size_t(gridDim.x) * blockDim.x) {
         uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const uint32_t first = head_pos[p], end = head_pos[p + 1];
         for (uint32_t j = first; j < end && j < first + 8u; j++) {
             const uint32_t digit = uint32_t(prefix[j]) & 7u;
-            const uint32_t a = child_addr[2 * size_t(j)], b = child_addr[2 * size_t(j) + 1];
+            const uint2 ab = reinterpret_cast<const uint2*>(child_addr)[j];
 #pragma unroll
-            for (uint32_t o = 0; o < 8; o++) { t[o] = o == digit ? a : t[o]; w[o] = o == digit ? b : w[o]; }   // (no runtime-indexed registers)
+            for (uint32_t o = 0; o < 8; o++) { t[o] = o == digit ? ab.x : t[o]; w[o] = o == digit ? ab.y : w[o]; }   // (no runtime-indexed registers)
         }
         uint4* out = reinterpret_cast<uint4*>(children + p * 16);
         out[0] = make_uint4(t[0], t[1], t[2], t[3]); out[1] = make_uint4(t[4], t[5], t[6], t[7]);
@@ -372,12 +405,54 @@ k_dag_parent_nodes(const uint64_t* __restrict__ prefix, const uint32_t* __restri
     }
 }
 
+// ---- the steps as launches --------------------------------------------------------------------------------------------------------
+// probe (and, beside it, the head count of the level's own nodes for the parents' step of the level above) | count | commit
+template <bool kNode>
+__global__ void __launch_bounds__(256)
+k_dag_probe(DagLevelRef L, const DagScalars* __restrict__ s, const void* __restrict__ cand, uint32_t n, uint32_t* __restrict__ pos,
+            const uint64_t* __restrict__ heads_of, uint32_t heads_n, unsigned long long* __restrict__ head_sums) {
+    dag_step_probe<kNode>(L, cand, n, s->size, pos);
+    if (heads_of) dag_step_head_sums(heads_of, heads_n, head_sums);
+}
+template <bool kNode>
+__global__ void __launch_bounds__(256)
+k_dag_count(DagLevelRef L, DagScalars* __restrict__ s, const uint32_t* __restrict__ pos, const void* __restrict__ cand, uint32_t n, uint8_t* __restrict__ new_words,
+            unsigned long long* __restrict__ sums) {
+    const uint32_t base = s->size;
+    if (blockIdx.x == 0 && threadIdx.x == 0) s->batch_base = base;
+    dag_step_count<kNode>(L, pos, cand, n, base, new_words, sums);
+}
+template <bool kNode>
+__global__ void __launch_bounds__(256)
+k_dag_commit(DagLevelRef L, DagScalars* s, const uint32_t* __restrict__ pos, const void* __restrict__ cand, uint32_t n, const uint8_t* __restrict__ new_words,
+             const unsigned long long* __restrict__ sums, unsigned long long extra_dupes, uint32_t* __restrict__ result) {
+    dag_step_commit<kNode>(L, pos, cand, n, new_words, sums, s->batch_base, s, extra_dupes, result);
+}
+__global__ void __launch_bounds__(256)
+k_dag_resolve(const uint32_t* __restrict__ table, const uint32_t* __restrict__ pos, uint32_t n, uint32_t* __restrict__ result) { dag_step_resolve(table, pos, n, result); }
+__global__ void __launch_bounds__(256)
+k_dag_block_nodes(const uint8_t* __restrict__ omask, const uint32_t* __restrict__ vblock, const uint32_t* __restrict__ oct_before, uint32_t nbv, uint32_t saturate,
+                  const uint32_t* __restrict__ cluster_addr, uint32_t* __restrict__ children, const uint64_t* __restrict__ vkeys, uint64_t* __restrict__ prefix) {
+    dag_step_block_nodes(omask, vblock, oct_before, nbv, saturate, cluster_addr, children, vkeys, prefix);
+}
+__global__ void __launch_bounds__(256)
+k_dag_heads(const uint64_t* __restrict__ prefix, uint32_t n, const unsigned long long* __restrict__ sums, uint32_t parents, uint32_t* __restrict__ head_pos,
+            uint64_t* __restrict__ parent_prefix) {
+    dag_step_heads(prefix, n, sums, parents, head_pos, parent_prefix);
+}
+__global__ void __launch_bounds__(256)
+k_dag_parents(const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ head_pos, uint32_t parents, const uint32_t* __restrict__ child_addr, uint32_t* __restrict__ children) {
+    dag_step_parents(prefix, head_pos, parents, child_addr, children);
+}
+
+constexpr uint32_t kDagSmall = 1024;   // nodes of a level below which one workgroup builds everything above it (k_dag_small_levels)
+struct DagFoldScratch { uint64_t* prefix; uint32_t* children; uint32_t* pos; uint32_t* addr; uint32_t* head_pos; };
+
 // ---- the upper levels in ONE launch -------------------------------------------------------------------------------------------
 // Above the first few levels a submap has a handful of nodes per level (a cfg2 room: 9 409 blocks, 1 500 nodes one level up, 250,
-// 50, ... 1), and a level costs ten dependent launches in the generic form above: nineteen levels are two hundred launches, 1-2 ms
-// for work of microseconds.  One workgroup of 1 024 threads runs the same four steps for every level from `top` down to the root,
-// as long as the level below has at most kDagSmall nodes: candidates in LDS, the tables and stores in global memory as before.
-constexpr uint32_t kDagSmall = 1024;
+// 50, ... 1), and a level costs four dependent launches in the generic form above.  One workgroup of 1 024 threads runs the same
+// steps for every level from `top` down to the root, as long as the level below has at most kDagSmall nodes: candidates in LDS,
+// the tables and stores in global memory as before.
 struct DagLevelsArg { uint32_t* table[kDagDepth]; uint32_t* raw[kDagDepth]; uint32_t mask[kDagDepth]; uint32_t capacity[kDagDepth]; };
 
 __device__ __forceinline__ uint32_t dag_scan1024(uint32_t v, uint32_t* total, uint32_t* scratch /* 17 words of LDS */) {   // exclusive, 1 024 threads
@@ -396,7 +471,7 @@ __device__ __forceinline__ uint32_t dag_scan1024(uint32_t v, uint32_t* total, ui
 
 __global__ void __launch_bounds__(1024)
 k_dag_small_levels(DagLevelsArg L, DagScalars* __restrict__ scalars, int top /* first level to build */, uint32_t n_below,
-                   const uint64_t* __restrict__ prefix_below, DagResolved addr_below /* [2 n_below] */, uint32_t* __restrict__ roots_out) {
+                   const uint64_t* __restrict__ prefix_below, const uint32_t* __restrict__ addr_below /* [2 n_below], resolved */, uint32_t* __restrict__ roots_out) {
     __shared__ uint64_t prefix[2][kDagSmall];
     __shared__ uint32_t addr[2][2 * kDagSmall];
     __shared__ uint32_t cand[2 * kDagSmall][8];
@@ -533,14 +608,18 @@ struct DeviceDag {
     DagLevelDev level[kDagDepth + 1];          // [0..19] node levels, [20] the cluster level
     DagScalars* d_scalars = nullptr;           // [21]
     DagScalars h_scalars[kDagDepth + 1] = {};  // as of the last fold
-    unsigned long long* d_total = nullptr;     // scan totals: [0] blocks, [1..] per batch
-    uint32_t* d_hist = nullptr;                // [32]
-    uint32_t* h_small = nullptr;               // pinned: what a fold reads back in the middle (block totals, level histogram) and at its end (roots)
+    unsigned long long* d_total = nullptr;     // [0]: the blocks' totals
+    uint32_t* d_hist = nullptr;                // [32]: nodes opened per depth, then two words for the roots
+    uint32_t* h_small = nullptr;               // pinned: what a fold reads back in the middle (block totals, level histogram) and at its end (roots, scalars)
     char* arena = nullptr; size_t arena_cap = 0;
+    std::vector<void*> outgrown;               // tables and stores a level has grown out of: freed with the DAG (hipFree waits for the whole device -- the frames in flight too)
+    size_t outgrown_bytes = 0;
     bool ready = false;
 
     void release() {
         for (auto& l : level) { (void)hipFree(l.table); (void)hipFree(l.raw); l = DagLevelDev{}; }
+        for (void* p : outgrown) (void)hipFree(p);
+        outgrown.clear(); outgrown_bytes = 0;
         (void)hipFree(d_scalars); (void)hipFree(d_total); (void)hipFree(d_hist); (void)hipFree(arena);
         if (h_small) (void)hipHostFree(h_small);
         d_scalars = nullptr; d_total = nullptr; d_hist = nullptr; arena = nullptr; h_small = nullptr; arena_cap = 0; ready = false;
@@ -581,7 +660,7 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
     hipError_t e;
     if (need_slots > L.table_slots) {
         size_t slots = L.table_slots;
-        while (slots < 2 * need_slots) slots <<= 1;   // (room for as much again: growth is a device-wide stall)
+        while (slots < 4 * need_slots) slots <<= 1;   // (room for three times as much again: growth stalls the fold -- an allocation, a rehash and a wait on the host's side, 0.2 ms and more)
         slots = std::min<size_t>(slots, size_t(1) << 31);
         if (need_slots > (size_t(1) << 31)) return hipErrorOutOfMemory;   // (a table of 2^31 slots: a billion values in one level)
         uint32_t* bigger = nullptr;
@@ -589,74 +668,55 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
         if ((e = hipMemsetAsync(bigger, 0, slots * 4, s)) != hipSuccess) { (void)hipFree(bigger); return e; }
         if (cluster) hipLaunchKernelGGL(k_dag_rehash<false>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
         else hipLaunchKernelGGL(k_dag_rehash<true>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipFree(bigger); return e; }
-        (void)hipFree(L.table);
+        // (no wait, no hipFree: what follows on this stream comes behind the rehash, and nothing else reads a level while a fold is in flight)
+        d.outgrown.push_back(L.table); d.outgrown_bytes += size_t(L.table_slots) * 4;
         L.table = bigger; L.table_slots = uint32_t(slots);
     }
     const size_t need_words = size_t(d.h_scalars[l].size) + n * words_each + 16;
     if (need_words > L.raw_capacity) {
         size_t words = L.raw_capacity;
-        while (words < need_words + need_words / 2) words += words / 2 + 1024;
+        while (words < 2 * need_words) words += words / 2 + 1024;
         if (need_words + n >= (size_t(1) << 32)) return hipErrorOutOfMemory;   // addresses are 32 bits, as in the reference (levels.hpp:50, :117); the batch's pending marks lie above them
         words = std::min<size_t>(words, (size_t(1) << 32) - 1 - n);
         const size_t unit = cluster ? 8 : 4;
         void* bigger = nullptr;
         if ((e = hipMalloc(&bigger, words * unit)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(bigger, L.raw, size_t(d.h_scalars[l].size) * unit, hipMemcpyDeviceToDevice, s)) != hipSuccess) { (void)hipFree(bigger); return e; }
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipFree(bigger); return e; }
-        (void)hipFree(L.raw);
+        d.outgrown.push_back(L.raw); d.outgrown_bytes += size_t(L.raw_capacity) * unit;
         L.raw = bigger; L.raw_capacity = uint32_t(words);
     }
     return hipSuccess;
 }
 
-// One batch on level l: candidates `cand` (n rows of eight child addresses, or n cluster words) -> result[i] = address of candidate i's value.
-inline void dag_batch(DeviceDag& d, uint32_t l, const void* cand, uint32_t n, uint32_t* pos, uint32_t* result, uint8_t* new_words, unsigned long long* sums, unsigned long long* total,
-                      unsigned long long extra_dupes, hipStream_t s) {
-    DagLevelDev& L = d.level[l];
-    const uint32_t mask = L.table_slots - 1, chunks = (n + kDagChunk - 1) / kDagChunk;
-    const dim3 flat = dag_grid(n), chunked = dim3(std::max(1u, std::min(chunks, 2048u)));
-    if (l == kDagDepth) {
-        if (n) hipLaunchKernelGGL(k_dag_probe<false>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, d.d_scalars + l, pos);
-        if (n) hipLaunchKernelGGL(k_dag_new_sums<false>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(nullptr), n, d.d_scalars + l, new_words, sums);
-    } else {
-        if (n) hipLaunchKernelGGL(k_dag_probe<true>, flat, dim3(256), 0, s, L.table, mask, L.raw, cand, n, d.d_scalars + l, pos);
-        if (n) hipLaunchKernelGGL(k_dag_new_sums<true>, chunked, dim3(256), 0, s, L.table, pos, static_cast<const uint32_t*>(cand), n, d.d_scalars + l, new_words, sums);
-    }
-    hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, sums, chunks, total, d.d_scalars + l, n, extra_dupes);
-    if (!n) return;
-    if (l == kDagDepth) hipLaunchKernelGGL(k_dag_commit<false>, chunked, dim3(256), 0, s, L.table, pos, cand, n, new_words, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
-    else hipLaunchKernelGGL(k_dag_commit<true>, chunked, dim3(256), 0, s, L.table, pos, cand, n, new_words, sums, d.d_scalars + l, L.raw, L.raw_capacity, result);
-    // (no resolve pass: whoever reads the addresses next looks a candidate that was not new up in its slot -- DagResolved)
-}
-
-// Fold one submap: keys[nb] ascending block keys, tsdf[8 nb] / weight[8 nb] (null: the reference's all-ones weights) cluster words, all
-// on the device and left alone until the fold is done.  The fold needs numbers on the host twice on its way (how many blocks hold
-// leaves; how many nodes every level gets) and once at its end (the roots, the levels' sizes): three stages, each enqueued when the
-// previous stage's numbers have arrived -- dag_fold_advance(block = false) never waits, so a roll-over's fold rides beside the next
-// frames (the insert path polls it); block = true waits for the stage's event.
+// Fold one submap: keys[nb] ascending block keys, tsdf[8 nb] / weight[8 nb] (null: the reference's all-ones weights) cluster words,
+// omask[nb] which of a block's eight words hold leaves (tsdf word != kClusterEmpty), all
+// on the device and left alone until the fold is done.  The fold needs numbers on the host once on its way (how many blocks hold
+// leaves and how many nodes every level gets: the stores are sized for exactly that) and once at its end (the roots, the levels'
+// sizes): two stages, the second enqueued when the first stage's numbers have arrived -- dag_fold_advance(block = false) never
+// waits, so a roll-over's fold rides beside the next frames (the insert path polls it); block = true waits for the stage's event.
 struct DagFold {
-    int stage = 0;   // 0: idle; 1: step 0 enqueued (block totals on their way); 2: cluster level + level histogram enqueued; 3: node levels enqueued
-    const uint64_t* keys = nullptr; const uint64_t* tsdf = nullptr; const uint64_t* weight = nullptr;
+    int stage = 0;   // 0: idle; 1: step 0 enqueued (block totals and level histogram on their way); 2: the levels enqueued (roots on their way)
+    const uint64_t* keys = nullptr; const uint64_t* tsdf = nullptr; const uint64_t* weight = nullptr; const uint8_t* omask = nullptr;
     uint32_t nb = 0, saturate = 0, nbv = 0, octets = 0;
     uint64_t* vkeys = nullptr; uint32_t* vblock = nullptr; uint32_t* oct_before = nullptr;
     uint64_t* ccand = nullptr; uint32_t* cpos = nullptr; uint32_t* caddr = nullptr;
-    unsigned long long* sums = nullptr; uint8_t* new_words = nullptr;
-    struct LevelScratch { uint64_t* prefix; uint32_t* children; uint32_t* pos; uint32_t* addr; uint32_t* head_pos; } ls[2] = {};
+    unsigned long long* sums = nullptr; unsigned long long* head_sums = nullptr; uint8_t* new_words = nullptr;
+    DagFoldScratch ls[2] = {};
     hipEvent_t ready = nullptr;   // behind the device-to-host copy of the current stage's numbers
 };
 
-inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, uint32_t nb, hipStream_t s) {
+inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, const uint8_t* omask, uint32_t nb, hipStream_t s) {
     hipError_t e;
     if ((e = dag_device_init(d, s)) != hipSuccess) return e;
     if (!f.ready && (e = hipEventCreateWithFlags(&f.ready, hipEventDisableTiming)) != hipSuccess) return e;
-    f.keys = keys; f.tsdf = tsdf; f.weight = weight; f.nb = nb; f.saturate = weight ? 1u : 0u; f.nbv = f.octets = 0;
+    f.keys = keys; f.tsdf = tsdf; f.weight = weight; f.omask = omask; f.nb = nb; f.saturate = weight ? 1u : 0u; f.nbv = f.octets = 0;
     const size_t cc_ub = f.saturate ? size_t(16) * nb : size_t(8) * nb + 2;       // cluster candidates at most
     const size_t chunks_ub = std::max<size_t>((std::max<size_t>(cc_ub, 2 * size_t(nb) + 2) + kDagChunk - 1) / kDagChunk, (size_t(nb) + kDagBlockChunk - 1) / kDagBlockChunk) + 1;
+    const size_t head_chunks_ub = (size_t(nb) + kDagChunk) / kDagChunk + 1;
     auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
     const size_t nbp = size_t(nb) + 1;
-    const size_t need = padded(nbp * 8) + 2 * padded(nbp * 4) + padded(cc_ub * 8) + 2 * padded(cc_ub * 4) + padded(chunks_ub * 8) + padded(std::max<size_t>(cc_ub, 2 * nbp)) +
-                        2 * (padded(nbp * 8) + padded(nbp * 64) + 2 * padded(nbp * 8) + padded((nbp + 1) * 4));
+    const size_t need = padded(nbp * 8) + 2 * padded(nbp * 4) + padded(cc_ub * 8) + 2 * padded(cc_ub * 4) + padded(chunks_ub * 8) + padded(head_chunks_ub * 8) +
+                        padded(std::max<size_t>(cc_ub, 2 * nbp)) + 2 * (padded(nbp * 8) + padded(nbp * 64) + 2 * padded(nbp * 8) + padded((nbp + 1) * 4));
     if (need > d.arena_cap) {
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         (void)hipFree(d.arena); d.arena = nullptr; d.arena_cap = 0;
@@ -672,19 +732,21 @@ inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys,
     f.cpos = static_cast<uint32_t*>(take(cc_ub * 4));
     f.caddr = static_cast<uint32_t*>(take(cc_ub * 4));
     f.sums = static_cast<unsigned long long*>(take(chunks_ub * 8));
+    f.head_sums = static_cast<unsigned long long*>(take(head_chunks_ub * 8));
     f.new_words = static_cast<uint8_t*>(take(std::max<size_t>(cc_ub, 2 * nbp)));
     for (auto& x : f.ls) {
         x.prefix = static_cast<uint64_t*>(take(nbp * 8)); x.children = static_cast<uint32_t*>(take(nbp * 64));
         x.pos = static_cast<uint32_t*>(take(nbp * 8)); x.addr = static_cast<uint32_t*>(take(nbp * 8)); x.head_pos = static_cast<uint32_t*>(take((nbp + 1) * 4));
     }
-    // step 0: the blocks that hold leaves, the cluster candidates
-    const uint32_t bchunks = (nb + kDagBlockChunk - 1) / kDagBlockChunk;
+    // step 0: the blocks that hold leaves, the cluster candidates, the nodes every level gets
     *reinterpret_cast<volatile unsigned long long*>(d.h_small) = 0ull;
     if (nb) {
-        hipLaunchKernelGGL(k_dag_block_sums, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, tsdf, nb, f.sums);
-        hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, bchunks, d.d_total, static_cast<DagScalars*>(nullptr), 0u, 0ull);
-        hipLaunchKernelGGL(k_dag_block_apply, dim3(std::min(bchunks, 2048u)), dim3(256), 0, s, keys, tsdf, weight, nb, f.saturate, f.sums, f.vkeys, f.vblock, f.oct_before, f.ccand, d.d_hist);
+        const dim3 bgrid(std::min((nb + kDagBlockChunk - 1) / kDagBlockChunk, kDagStepGrid));
+        hipLaunchKernelGGL(k_dag_block_sums, bgrid, dim3(256), 0, s, omask, nb, f.sums, d.d_hist);
+        hipLaunchKernelGGL(k_dag_block_apply, bgrid, dim3(256), 0, s, keys, tsdf, weight, omask, nb, f.saturate, f.sums, f.vkeys, f.vblock, f.oct_before, f.ccand, d.d_total);
+        hipLaunchKernelGGL(k_dag_parted_histogram, dag_grid(nb, 256, 1024), dim3(256), 0, s, f.vkeys, d.d_total, d.d_hist);
         if ((e = hipMemcpyAsync(d.h_small, d.d_total, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(d.h_small + 16, d.d_hist, 128, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipEventRecord(f.ready, s)) != hipSuccess) return e;
@@ -702,89 +764,90 @@ inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool
     uint32_t* d_roots = d.d_hist + 24;   // (two spare words behind the histogram's twenty)
     if (f.stage == 1) {
         const unsigned long long t = *reinterpret_cast<volatile unsigned long long*>(d.h_small);
-        f.nbv = uint32_t(t >> 32); f.octets = uint32_t(t);
-        // how many nodes every level gets (a small round trip that gives every later launch its exact size), and the cluster level meanwhile
-        if (f.nbv) {
-            hipLaunchKernelGGL(k_dag_parted_histogram, dag_grid(f.nbv, 256, 1024), dim3(256), 0, s, f.vkeys, f.nbv, d.d_hist);
-            if ((e = hipMemcpyAsync(d.h_small + 16, d.d_hist, 128, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-        }
+        const uint32_t nbv = f.nbv = uint32_t(t >> 32);
+        f.octets = uint32_t(t);
+        // every store sized for what this submap can add at most: its candidates are counted (n_d = 1 + #{blocks that part from their predecessor at a depth below d})
         const uint32_t ncc = f.octets ? (f.saturate ? 2u * f.octets : f.octets + 1u) : 0u;
         if ((e = dag_level_reserve(d, kDagDepth, ncc, 1, s)) != hipSuccess) return e;
-        if (ncc) dag_batch(d, kDagDepth, f.ccand, ncc, f.cpos, f.caddr, f.new_words, f.sums, d.d_total + 1, f.saturate ? 0ull : (unsigned long long)(f.octets - 1u), s);
+        uint32_t level_nodes[kDagDepth] = {}, running = 1;
+        for (uint32_t dd = 0; dd < kDagDepth; dd++) {
+            level_nodes[dd] = nbv ? running : 0u;
+            running += nbv ? d.h_small[16 + dd] : 0u;
+            const uint32_t nodes = nbv ? level_nodes[dd] : (dd == 0 ? 1u : 0u);   // (an empty octree still yields a childless root pair)
+            if ((e = dag_level_reserve(d, dd, 2 * size_t(nodes), 9, s)) != hipSuccess) return e;
+        }
+        auto ref = [&](uint32_t l) { return DagLevelRef{d.level[l].table, d.level[l].raw, d.level[l].table_slots - 1, d.level[l].raw_capacity}; };
+        // probe | count | commit | resolve of level l over n candidates; beside the probe, the heads among the level's own nodes for the level above
+        auto batch = [&](uint32_t l, const void* cand, uint32_t n, uint32_t* pos, uint32_t* result, unsigned long long extra_dupes, const uint64_t* heads_of, uint32_t heads_n) {
+            const dim3 flat = dag_grid(n), chunked(std::max(1u, std::min((n + kDagChunk - 1) / kDagChunk, kDagStepGrid)));
+            DagScalars* sc = d.d_scalars + l;
+            if (l == kDagDepth) {
+                hipLaunchKernelGGL(k_dag_probe<false>, flat, dim3(256), 0, s, ref(l), sc, cand, n, pos, heads_of, heads_n, f.head_sums);
+                hipLaunchKernelGGL(k_dag_count<false>, chunked, dim3(256), 0, s, ref(l), sc, pos, cand, n, f.new_words, f.sums);
+                hipLaunchKernelGGL(k_dag_commit<false>, chunked, dim3(256), 0, s, ref(l), sc, pos, cand, n, f.new_words, f.sums, extra_dupes, result);
+            } else {
+                hipLaunchKernelGGL(k_dag_probe<true>, flat, dim3(256), 0, s, ref(l), sc, cand, n, pos, heads_of, heads_n, f.head_sums);
+                hipLaunchKernelGGL(k_dag_count<true>, chunked, dim3(256), 0, s, ref(l), sc, pos, cand, n, f.new_words, f.sums);
+                hipLaunchKernelGGL(k_dag_commit<true>, chunked, dim3(256), 0, s, ref(l), sc, pos, cand, n, f.new_words, f.sums, extra_dupes, result);
+            }
+            hipLaunchKernelGGL(k_dag_resolve, flat, dim3(256), 0, s, static_cast<const uint32_t*>(d.level[l].table), static_cast<const uint32_t*>(pos), n, result);
+        };
+        if (ncc) batch(kDagDepth, f.ccand, ncc, f.cpos, f.caddr, f.saturate ? 0ull : (unsigned long long)(f.octets - 1u), nullptr, 0u);
+        // level 19 from the blocks, then upwards until one workgroup can finish
+        uint32_t cur = 0, n_here = nbv;
+        int d_at = int(kDagDepth) - 1;
+        for (; nbv; d_at--) {
+            const DagFoldScratch& here = f.ls[cur];
+            const DagFoldScratch& below = f.ls[cur ^ 1];
+            if (d_at == int(kDagDepth) - 1)
+                hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, f.omask, static_cast<const uint32_t*>(f.vblock), f.oct_before, nbv, f.saturate,
+                                   static_cast<const uint32_t*>(f.caddr), here.children, f.vkeys, here.prefix);
+            else {
+                const uint32_t n_below = level_nodes[d_at + 1];
+                hipLaunchKernelGGL(k_dag_heads, dim3(std::max(1u, std::min((n_below + kDagChunk - 1) / kDagChunk, kDagStepGrid))), dim3(256), 0, s, below.prefix, n_below, f.head_sums, n_here,
+                                   here.head_pos, here.prefix);
+                hipLaunchKernelGGL(k_dag_parents, dag_grid(n_here), dim3(256), 0, s, below.prefix, static_cast<const uint32_t*>(here.head_pos), n_here, static_cast<const uint32_t*>(below.addr), here.children);
+            }
+            const bool more = n_here > kDagSmall;   // (level 0 has one node: the loop ends)
+            batch(uint32_t(d_at), here.children, 2u * n_here, here.pos, here.addr, 0ull, more ? here.prefix : nullptr, n_here);
+            if (!more) break;
+            n_here = level_nodes[d_at - 1];
+            cur ^= 1u;
+        }
+        // ... which builds level d_at - 1 and everything above it from the n_here nodes of level d_at (an empty octree: its childless root pair)
+        DagLevelsArg small{};
+        for (uint32_t l = 0; l < kDagDepth; l++) { small.table[l] = d.level[l].table; small.raw[l] = static_cast<uint32_t*>(d.level[l].raw); small.mask[l] = d.level[l].table_slots - 1; small.capacity[l] = d.level[l].raw_capacity; }
+        const int top = nbv ? d_at - 1 : int(kDagDepth) - 2;
+        hipLaunchKernelGGL(k_dag_small_levels, dim3(1), dim3(1024), 0, s, small, d.d_scalars, top, nbv ? n_here : 0u, static_cast<const uint64_t*>(f.ls[cur].prefix),
+                           static_cast<const uint32_t*>(f.ls[cur].addr), d_roots);
+        if ((e = hipMemcpyAsync(d.h_small + 64, d_roots, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(d.h_small + 128, d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipEventRecord(f.ready, s)) != hipSuccess) return e;
         f.stage = 2;
         return hipSuccess;
     }
-    if (f.stage == 2) {
-        uint32_t level_nodes[kDagDepth] = {};
-        const uint32_t nbv = f.nbv;
-        if (nbv) {
-            uint32_t running = 1;   // n_d = 1 + #{blocks that part from their predecessor at a depth below d}
-            for (uint32_t dd = 0; dd < kDagDepth; dd++) { level_nodes[dd] = running; running += d.h_small[16 + dd]; }
-        }
-        // level 19, then upwards
-        uint32_t cur = 0;
-        DagFold::LevelScratch* ls = f.ls;
-        if (nbv) {
-            hipLaunchKernelGGL(k_dag_block_nodes, dag_grid(nbv), dim3(256), 0, s, f.tsdf, f.vblock, f.oct_before, nbv, f.saturate,
-                               DagResolved{f.caddr, d.level[kDagDepth].table, f.cpos}, ls[cur].children, f.vkeys, ls[cur].prefix);
-            if ((e = dag_level_reserve(d, kDagDepth - 1, 2 * size_t(nbv), 9, s)) != hipSuccess) return e;
-            dag_batch(d, kDagDepth - 1, ls[cur].children, 2 * nbv, ls[cur].pos, ls[cur].addr, f.new_words, f.sums, d.d_total + 2, 0ull, s);
-        }
-        uint32_t n_below = nbv;
-        bool fused = false;
-        for (int dd = int(kDagDepth) - 2; dd >= 0; dd--) {
-            if (n_below <= kDagSmall) {   // this level and everything above it in one launch (node counts only shrink towards the root)
-                DagLevelsArg arg{};
-                for (int u = dd; u >= 0; u--) {
-                    const uint32_t parents_u = nbv ? level_nodes[u] : (u == 0 ? 1u : 0u);
-                    if ((e = dag_level_reserve(d, uint32_t(u), 2 * size_t(parents_u), 9, s)) != hipSuccess) return e;
-                }
-                for (uint32_t u = 0; u < kDagDepth; u++) {
-                    arg.table[u] = d.level[u].table; arg.raw[u] = static_cast<uint32_t*>(d.level[u].raw);
-                    arg.mask[u] = d.level[u].table_slots - 1; arg.capacity[u] = d.level[u].raw_capacity;
-                }
-                // (the level below is level dd + 1: its table resolves the candidates that were not new)
-                hipLaunchKernelGGL(k_dag_small_levels, dim3(1), dim3(1024), 0, s, arg, d.d_scalars, dd, n_below, ls[cur].prefix,
-                                   DagResolved{ls[cur].addr, d.level[dd + 1].table, ls[cur].pos}, d_roots);
-                fused = true;
-                break;
-            }
-            const uint32_t parents = level_nodes[dd];   // (n_below > kDagSmall: the submap is not empty)
-            DagFold::LevelScratch& below = ls[cur];
-            DagFold::LevelScratch& here = ls[cur ^ 1];
-            const uint32_t chunks = (n_below + kDagChunk - 1) / kDagChunk;
-            hipLaunchKernelGGL(k_dag_head_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, f.sums);
-            hipLaunchKernelGGL(k_dag_scan_sums, dim3(1), dim3(256), 0, s, f.sums, chunks, d.d_total + 3, static_cast<DagScalars*>(nullptr), 0u, 0ull);
-            hipLaunchKernelGGL(k_dag_head_apply, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, below.prefix, n_below, f.sums, here.head_pos, here.prefix, parents);
-            hipLaunchKernelGGL(k_dag_parent_nodes, dag_grid(parents), dim3(256), 0, s, below.prefix, here.head_pos, parents,
-                               DagResolved{below.addr, d.level[dd + 1].table, below.pos}, here.children);
-            if ((e = dag_level_reserve(d, uint32_t(dd), 2 * size_t(parents), 9, s)) != hipSuccess) return e;
-            dag_batch(d, uint32_t(dd), here.children, 2 * parents, here.pos, here.addr, f.new_words, f.sums, d.d_total + 4, 0ull, s);
-            n_below = parents;
-            cur ^= 1;
-        }
-        // roots and the levels' scalars
-        if (!fused) return hipErrorUnknown;   // (cannot happen: level 0 has one node, so the single-workgroup kernel always takes the top)
-        if ((e = hipMemcpyAsync(d.h_small + 64, d_roots, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(d.h_small + 128, d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipEventRecord(f.ready, s)) != hipSuccess) return e;
-        f.stage = 3;
-        return hipSuccess;
-    }
-    *root_tsdf = d.h_small[64]; *root_weight = d.h_small[65];
-    std::memcpy(d.h_scalars, d.h_small + 128, sizeof(d.h_scalars));
     f.stage = 0;
+    *root_tsdf = d.h_small[64]; *root_weight = d.h_small[65];
+    DagScalars before[kDagDepth + 1];
+    std::memcpy(before, d.h_scalars, sizeof(before));
+    std::memcpy(d.h_scalars, d.h_small + 128, sizeof(d.h_scalars));
     *done = true;
+    // Growth off the next fold's path: a level that would not take this submap's additions once more grows NOW, behind this fold on its
+    // stream and while the frames of the next submap run (found in the middle of a fold -- between its two stages -- an allocation and
+    // a rehash held the fold up for 0.2-0.5 ms, in most folds of a map's first hundreds of frames).
+    for (uint32_t l = 0; l <= kDagDepth; l++) {
+        const size_t entries = d.h_scalars[l].entries - before[l].entries, words = d.h_scalars[l].size - before[l].size;
+        if (!entries) continue;
+        if ((e = dag_level_reserve(d, l, entries + entries / 2, uint32_t((words + entries - 1) / entries) + 1u, s)) != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 
 // ... start to finish
-inline hipError_t dag_device_add_submap(DeviceDag& d, DagFold& f, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, uint32_t nb, hipStream_t s,
+inline hipError_t dag_device_add_submap(DeviceDag& d, DagFold& f, const uint64_t* keys, const uint64_t* tsdf, const uint64_t* weight, const uint8_t* omask, uint32_t nb, hipStream_t s,
                                         uint32_t* root_tsdf, uint32_t* root_weight) {
-    hipError_t e = dag_fold_begin(d, f, keys, tsdf, weight, nb, s);
+    hipError_t e = dag_fold_begin(d, f, keys, tsdf, weight, omask, nb, s);
     for (bool done = false; e == hipSuccess && !done;) e = dag_fold_advance(d, f, s, true, &done, root_tsdf, root_weight);
     return e;
 }
@@ -809,3 +872,4 @@ inline hipError_t dag_device_mirror(DeviceDag& d, Dag& host, hipStream_t s) {
 }
 
 }  // namespace chadhip
+

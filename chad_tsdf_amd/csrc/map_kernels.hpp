@@ -322,36 +322,34 @@ __device__ __forceinline__ void cluster_bytes(float sum, uint32_t n, float trunc
         *w_bits = n < 254u ? n : 254u;
     }
 }
-// lane 8o + i holds byte i of word o: the eight bytes OR-ed together within each group of eight lanes; valid in lanes 8o
-__device__ __forceinline__ void cluster_words(uint32_t lane, uint32_t sd_bits, uint32_t w_bits, uint64_t* tsdf, uint64_t* weight) {
-    const uint32_t shift = (lane & 3u) * 8u;
-    uint32_t t_lo = (lane & 4u) ? 0u : sd_bits << shift, t_hi = (lane & 4u) ? sd_bits << shift : 0u;
-    uint32_t w_lo = (lane & 4u) ? 0u : w_bits << shift, w_hi = (lane & 4u) ? w_bits << shift : 0u;
+// lane 8o + i holds byte i of word o of row `row`: byte row * 64 + lane of the words' array -- the wave stores the row's 64 bytes as
+// one line (assembling the words in registers first took twelve cross-lane moves per voxel); out_mask[row]: which of the eight
+// words hold a leaf (a voxel with observations has a distance byte below 0xff: such a word differs from kClusterEmpty)
+__device__ __forceinline__ void cluster_store(uint32_t lane, size_t row, uint32_t sd_bits, uint32_t w_bits, bool leaf, uint64_t* out_tsdf, uint64_t* out_weight, uint8_t* out_mask) {
+    reinterpret_cast<uint8_t*>(out_tsdf)[row * 64 + lane] = uint8_t(sd_bits);
+    if (out_weight) reinterpret_cast<uint8_t*>(out_weight)[row * 64 + lane] = uint8_t(w_bits);
+    if (out_mask) {
+        const uint64_t leaves = __ballot(leaf);
+        uint32_t mask = 0;
 #pragma unroll
-    for (uint32_t d = 1; d < 8; d <<= 1) {
-        t_lo |= __shfl_xor(t_lo, d); t_hi |= __shfl_xor(t_hi, d);
-        w_lo |= __shfl_xor(w_lo, d); w_hi |= __shfl_xor(w_hi, d);
+        for (uint32_t o = 0; o < 8; o++) mask |= ((leaves >> (8u * o)) & 0xffull) ? 1u << o : 0u;
+        if (lane == 0) out_mask[row] = uint8_t(mask);
     }
-    *tsdf = uint64_t(t_hi) << 32 | t_lo; *weight = uint64_t(w_hi) << 32 | w_lo;
 }
 
 __global__ void __launch_bounds__(256)
 k_leaf_clusters(const uint32_t* __restrict__ order, uint32_t count, const uint64_t* __restrict__ brick_key,
                 const float* __restrict__ brick_sum, const uint32_t* __restrict__ brick_cnt, float trunc_recip,
-                uint64_t* __restrict__ out_key, uint64_t* __restrict__ out_tsdf, uint64_t* __restrict__ out_weight) {
+                uint64_t* __restrict__ out_key, uint64_t* __restrict__ out_tsdf, uint64_t* __restrict__ out_weight, uint8_t* __restrict__ out_mask) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t k = wave; k < count; k += waves) {
         const uint32_t b = order ? order[k] : k;
+        const uint32_t n = brick_cnt[size_t(b) * 64 + lane];
         uint32_t sd_bits, w_bits;
-        cluster_bytes(brick_sum[size_t(b) * 64 + lane], brick_cnt[size_t(b) * 64 + lane], trunc_recip, &sd_bits, &w_bits);
-        uint64_t t, w;
-        cluster_words(lane, sd_bits, w_bits, &t, &w);
-        if ((lane & 7u) == 0) {
-            out_tsdf[size_t(k) * 8 + (lane >> 3)] = t;
-            if (out_weight) out_weight[size_t(k) * 8 + (lane >> 3)] = w;
-        }
+        cluster_bytes(brick_sum[size_t(b) * 64 + lane], n, trunc_recip, &sd_bits, &w_bits);
+        cluster_store(lane, k, sd_bits, w_bits, n != 0u, out_tsdf, out_weight, out_mask);
         if (lane == 0) out_key[k] = brick_key[b];
     }
 }
@@ -446,73 +444,72 @@ k_compact_bricks(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, ui
 
 // CHAD_FLAG_DAG_ONLY: a closed submap is its DAG and nothing else, so its bricks go from the table straight to cluster words -- what
 // k_compact_bricks (f32 sum with one rounding, count) followed by k_leaf_clusters would deliver, bit for bit, without the dense copy in
-// between (0.85 GB written and read again per cfg5 submap).  In no particular order: the keys are sorted afterwards and the 64-byte
-// rows gathered (k_gather_clusters).
+// between (0.85 GB written and read again per cfg5 submap).  The fold wants the blocks in key order, so the ORDER comes first: the
+// live slots' keys and slot numbers (k_table_keys: 12 bytes per block, in no particular order), a sort of the keys with their
+// position as payload, and only then the bricks, read once in that order, each cluster row written where it belongs
+// (k_sorted_clusters).  (Cluster words in table order first, then sorted and gathered: 0.53 + 0.11 ms instead of 0.03 + 0.25.)
 __global__ void __launch_bounds__(256)
-k_table_clusters(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, float trunc, float trunc_recip, uint64_t* __restrict__ out_key,
-                 uint64_t* __restrict__ out_tsdf, uint64_t* __restrict__ out_weight) {
+k_table_keys(MapView m, uint32_t* __restrict__ cursor, uint32_t capacity, uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_slot) {
+    __shared__ uint32_t wave_total[4], group_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t words = (m.hash_mask >> 5) + 1u;
+    // 256 bitmap words = 8 192 slots per workgroup step and ONE returning atomic on the cursor for them (per wave and sixteen words
+    // it was 8 192 atomics for a table of 2^22 slots, queueing on one address for 25 ns each: 0.2 ms)
+    for (uint32_t g0 = blockIdx.x * 256u; g0 < words; g0 += gridDim.x * 256u) {
+        const uint32_t w = g0 + threadIdx.x;
+        const uint32_t word = w < words ? m.live_bits[w] : 0u;
+        uint32_t mine = uint32_t(__popc(word)), before = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(before, o); if (int(lane) >= o) before += t; }
+        __syncthreads();   // (the previous step's readers of group_base are through)
+        if (lane == 63u) wave_total[wave] = before;
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t all = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3]; group_base = all ? atomicAdd(cursor, all) : 0u; }
+        __syncthreads();
+        uint32_t k = group_base + before - mine;
+        for (uint32_t v = 0; v < wave; v++) k += wave_total[v];
+        // the words' bits, a byte of the bitmap per lane and turn (a word per lane would leave a lane up to 32 dependent rounds)
+        for (uint32_t part = 0; part < 4; part++) {
+            const uint32_t src = 16u * part + (lane >> 2);   // lane of this wave that holds the word
+            const uint32_t src_word = uint32_t(__shfl(int(word), int(src))), src_k = uint32_t(__shfl(int(k), int(src)));
+            const uint32_t shift = 8u * (lane & 3u);
+            uint32_t bits = (src_word >> shift) & 0xffu;
+            uint32_t at = src_k + uint32_t(__popc(src_word & ((1u << shift) - 1u)));
+            for (; bits; bits &= bits - 1u, at++) {
+                const uint32_t slot = (g0 + 64u * wave + src) * 32u + shift + uint32_t(__ffs(int(bits))) - 1u;
+                if (at < capacity) { out_key[at] = m.hash_keys[slot]; out_slot[at] = slot; }
+            }
+        }
+    }
+}
+// rank r of the sorted keys is entry order[r] of k_table_keys' list: its brick -> the eight cluster words of row r (a wave per brick, a lane per voxel)
+__global__ void __launch_bounds__(256)
+k_sorted_clusters(MapView m, const uint32_t* __restrict__ order, const uint32_t* __restrict__ slots, uint32_t count, float trunc, float trunc_recip,
+                  uint64_t* __restrict__ out_tsdf, uint64_t* __restrict__ out_weight, uint8_t* __restrict__ out_mask) {
     const double metres_per_unit = double(trunc) / double(kSumOne);
     const bool pack_only = table_pack_only(m);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t words = (m.hash_mask >> 5) + 1u;
-    for (uint32_t w0 = wave * kWalkWords; w0 < words; w0 += waves * kWalkWords) {
-        const uint32_t word = lane < kWalkWords && w0 + lane < words ? m.live_bits[w0 + lane] : 0u;
-        uint64_t holders = __ballot(word != 0u);
-        if (!holders) continue;
-        uint32_t total = uint32_t(__popc(word));
+    uint32_t ahead[4];   // the slots of the step after this one: two dependent loads that would otherwise stand in front of every step's bricks
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        uint32_t k = 0;
-        if (lane == 0) k = atomicAdd(cursor, total);
-        k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
-        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, queued = 0;
-        auto emit_queued = [&]() {   // four bricks' loads in flight together (as k_compact_bricks)
-            const uint32_t slot[4] = {q0, q1, q2, q3};
-            long long units[4]; uint32_t count[4]; uint64_t key[4];
+    for (uint32_t i = 0; i < 4; i++) ahead[i] = wave * 4u + i < count ? slots[order[wave * 4u + i]] : 0u;
+    for (uint32_t r0 = wave * 4u; r0 < count; r0 += waves * 4u) {   // four bricks' loads in flight together
+        uint32_t slot[4];
+        long long units[4]; uint32_t cnt[4];
+        const uint32_t r1 = r0 + waves * 4u;
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++)
-                if (i < queued && k + i < capacity) {
-                    voxel_totals(m, size_t(slot[i]) * 64 + lane, &units[i], &count[i], pack_only);
-                    if (lane == 0) key[i] = m.hash_keys[slot[i]];
-                }
+        for (uint32_t i = 0; i < 4; i++) { slot[i] = ahead[i]; ahead[i] = r1 + i < count ? slots[order[r1 + i]] : 0u; }
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++)
-                if (i < queued && k + i < capacity) {
-                    const float sum = (count[i] & kPoisonedCount) ? __int_as_float(0x7fc00000) : float(double(units[i]) * metres_per_unit);   // k_compact_bricks' archive value
-                    uint32_t sd_bits, w_bits;
-                    cluster_bytes(sum, count[i] & ~kPoisonedCount, trunc_recip, &sd_bits, &w_bits);
-                    uint64_t t, w;
-                    cluster_words(lane, sd_bits, w_bits, &t, &w);
-                    if ((lane & 7u) == 0) {
-                        out_tsdf[size_t(k + i) * 8 + (lane >> 3)] = t;
-                        if (out_weight) out_weight[size_t(k + i) * 8 + (lane >> 3)] = w;
-                    }
-                    if (lane == 0) out_key[k + i] = key[i];
-                }
-            k += queued;
-            queued = 0;
-        };
-        for (; holders; holders &= holders - 1ull) {
-            const uint32_t l = uint32_t(__ffsll((unsigned long long)holders)) - 1u;
-            for (uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(word), int(l))); bits; bits &= bits - 1u) {
-                const uint32_t slot = (w0 + l) * 32u + uint32_t(__ffs(int(bits))) - 1u;
-                if (queued == 0) q0 = slot; else if (queued == 1) q1 = slot; else if (queued == 2) q2 = slot; else q3 = slot;
-                if (++queued == 4) emit_queued();
+        for (uint32_t i = 0; i < 4; i++) if (r0 + i < count) voxel_totals(m, size_t(slot[i]) * 64 + lane, &units[i], &cnt[i], pack_only);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+            if (r0 + i < count) {
+                const float sum = (cnt[i] & kPoisonedCount) ? __int_as_float(0x7fc00000) : float(double(units[i]) * metres_per_unit);   // k_compact_bricks' archive value
+                uint32_t sd_bits, w_bits;
+                cluster_bytes(sum, cnt[i] & ~kPoisonedCount, trunc_recip, &sd_bits, &w_bits);
+                cluster_store(lane, size_t(r0 + i), sd_bits, w_bits, (cnt[i] & ~kPoisonedCount) != 0u, out_tsdf, out_weight, out_mask);
             }
-        }
-        if (queued) emit_queued();
-    }
-}
-// rows of eight cluster words in the order given by `order` (one thread per word)
-__global__ void __launch_bounds__(256)
-k_gather_clusters(const uint32_t* __restrict__ order, uint32_t count, const uint64_t* __restrict__ in_tsdf, const uint64_t* __restrict__ in_weight,
-                  uint64_t* __restrict__ out_tsdf, uint64_t* __restrict__ out_weight) {
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < size_t(count) * 8; i += size_t(gridDim.x) * blockDim.x) {
-        const size_t from = size_t(order[i >> 3]) * 8 + (i & 7);
-        out_tsdf[i] = in_tsdf[from];
-        if (out_weight) out_weight[i] = in_weight[from];
     }
 }
 

@@ -114,9 +114,25 @@ k_radix_histograms(const uint64_t* __restrict__ keys, uint32_t n, uint32_t passe
     for (size_t k = size_t(blockIdx.x) * kSortThreads + threadIdx.x; k < status_words; k += size_t(gridDim.x) * kSortThreads) tile_status[k] = 0u;
     for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += kSortThreads) (&hist[0][0])[k] = 0;
     __syncthreads();
-    for (size_t i = size_t(blockIdx.x) * kSortThreads + threadIdx.x; i < n; i += size_t(gridDim.x) * kSortThreads) {
-        const uint64_t key = keys[i];
-        for (uint32_t p = 0; p < active; p++) atomicAdd(&hist[p][uint32_t(key >> (p * kRadixBits)) & (kRadix - 1)], 1u);
+    // four keys per thread and turn: their loads are in flight together (one at a time, a workgroup's turns were a chain of round trips)
+    const size_t stride = size_t(gridDim.x) * kSortThreads;
+    for (size_t i0 = size_t(blockIdx.x) * kSortThreads + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint64_t key4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) key4[j] = i0 + j * stride < n ? keys[i0 + j * stride] : 0ull;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            if (i0 + j * stride >= n) break;
+            const uint64_t key = key4[j];
+            // (a digit the whole wave agrees on -- the upper digits of block keys: a submap spans a few values of them -- is counted with
+            // one atomic instead of sixty-four on the same LDS word)
+            const uint64_t here = __ballot(true);
+            for (uint32_t p = 0; p < active; p++) {
+                const uint32_t d = uint32_t(key >> (p * kRadixBits)) & (kRadix - 1), d0 = uint32_t(__builtin_amdgcn_readfirstlane(int(d)));
+                if (__ballot(d != d0) == 0ull) { if ((here & ((1ull << (threadIdx.x & 63u)) - 1ull)) == 0ull) atomicAdd(&hist[p][d0], uint32_t(__popcll(here))); }
+                else atomicAdd(&hist[p][d], 1u);
+            }
+        }
     }
     __syncthreads();
     for (uint32_t p = 0; p < active; p++) hist_part[(size_t(blockIdx.x) * kMaxPasses + p) * kRadix + threadIdx.x] = hist[p][threadIdx.x];

@@ -9,6 +9,7 @@ from chad_tsdf_amd import TSDFMap, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=110)
 ap.add_argument("--keep", action="store_true", help="keep the dense archives (no DAG_ONLY)")
+ap.add_argument("--alone", action="store_true", help="wait for every roll-over's fold before the next frame (its kernels' own times, for a trace)")
 args = ap.parse_args()
 dev = [synth.cfg5_frame_torch(k) for k in range(args.frames)]
 torch.cuda.synchronize()
@@ -20,6 +21,8 @@ m.sync(); m.reset(); m.sync()
 t0 = time.perf_counter()
 for k in range(args.frames):
     m.insert(dev[k][0], dev[k][1], ready=True)
+    if args.alone and k and k % 11 == 0:
+        m.sync(); m.finalize()
 t_host = time.perf_counter() - t0
 m.sync()
 t = time.perf_counter() - t0
