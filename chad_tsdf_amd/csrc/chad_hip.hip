@@ -206,7 +206,16 @@ struct chad_map {
     DagFold fold;                                 // the fold in flight (at most one): closed submap number dag_roots.size()
     bool folding = false;
     bool in_fold_setup = false;                   // close_into_dag is setting the fold up (it uses the auxiliary sorter itself)
-    hipStream_t fold_stream = nullptr;            // CHAD_FLAG_DAG_ONLY roll-overs: cluster words and the fold run here, beside the frames and beside the map's
+    hipStream_t fold_stream = nullptr;            // CHAD_FLAG_DAG_ONLY roll-overs: the fold into the DAG runs here, beside the frames and beside the map's
+    hipStream_t close_stream = nullptr;           // ... and the step before it -- the closing table's keys, their order, its cluster words -- here: the next
+                                                  // submap's, beside the fold of the one before (a fold takes as long as the eleven frames of a cfg5 submap and longer)
+    struct PendingFold {                          // a closed submap whose cluster words are made (or on their way, close_stream) and whose fold waits for the one in flight
+        bool set = false;
+        const uint64_t* keys = nullptr; const uint64_t* tsdf = nullptr; const uint64_t* weight = nullptr; const uint8_t* mask = nullptr;
+        uint32_t blocks = 0;
+    } pending;
+    hipEvent_t clusters_ready = nullptr;          // behind the pending submap's cluster words on close_stream
+    uint32_t closings = 0;                        // roll-overs closed into the DAG so far: closing k's cluster words live in cluster_arenas[k & 1]
                                                   // stream (whose next roll-over must not queue behind a fold of several milliseconds)
     hipEvent_t fold_t0 = nullptr, fold_t1 = nullptr;   // device time of the fold in flight
     hipEvent_t spare_cleared = nullptr;           // recorded on fold_stream behind the clear of a table that was handed back as the spare
@@ -255,6 +264,7 @@ struct chad_map {
     Arena merge_a, merge_b, merge_c;              // scratch of the three stages
     Arena archive_arena;                          // CHAD_FLAG_DAG_ONLY: the closing submap's dense copy, from its roll-over to its fold (borrow_submap)
     Arena cluster_arena;                          // the cluster words of the submap being folded (device_cluster_words)
+    Arena cluster_arenas[2];                      // ... under CHAD_FLAG_DAG_ONLY: of the submap being folded and of the one waiting behind it
     uint32_t merge_blocks = 0;                    // this rank's blocks
     uint64_t* merge_keys = nullptr; long long* merge_sum = nullptr; uint32_t* merge_cnt = nullptr;   // ... compacted raw (arena a)
     uint64_t merge_total = 0;                     // blocks over all ranks
@@ -333,6 +343,7 @@ chad_status join_streams(chad_map* m) {
     }
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) HIP_TRY(hipStreamSynchronize(f.prep));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->close_stream) HIP_TRY(hipStreamSynchronize(m->close_stream));
     if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));
     return CHAD_OK;
 }
@@ -390,12 +401,16 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
 // The (key, index) sorter of exports and finalize: buffers of its own, so that no frame slot is ever borrowed (a slot's buffers
 // belong to a frame that may still be in flight, and growing them would free a frame's staged points).  Used on the map's stream only.
 chad_status fold_advance(chad_map* m, bool block);   // (with Submap::finalize, further down)
+inline bool fold_busy(const chad_map* m) { return m->folding || m->pending.set; }   // a roll-over's fold in flight, or waiting for the one in flight
+// the words of RadixSortSignals::dep in the auxiliary sorter: behind the partial histograms the histogram kernel's kHistBlocks workgroups write
+inline uint32_t* aux_sort_dep(const RadixSortBuffers& b) { return b.hist_part + size_t(kHistBlocks) * kMaxPasses * kRadix; }
 chad_status ensure_aux_sort(chad_map* m, size_t n) {
-    if (m->folding && !m->in_fold_setup) {   // a fold in flight sorted with these buffers on its own stream: the map's stream may have them when it is done
-        while (m->folding) TRY(fold_advance(m, true));
+    if (fold_busy(m) && !m->in_fold_setup) {   // a roll-over in flight sorted with these buffers on its own stream: the map's stream may have them when it is done
+        while (fold_busy(m)) TRY(fold_advance(m, true));
     }
     if (n <= m->aux_cap) return CHAD_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->close_stream) HIP_TRY(hipStreamSynchronize(m->close_stream));   // (the previous roll-over's sort)
     size_t cap = std::max<size_t>(n, m->aux_cap * 2);
     cap = (cap + kSortTile - 1) / kSortTile * kSortTile;
     free_sort_buffers(m->aux_sort);
@@ -405,6 +420,8 @@ chad_status ensure_aux_sort(chad_map* m, size_t n) {
     HIP_TRY(hipMalloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
     HIP_TRY(hipMalloc(&b.tile_status, radix_status_words(radix_tiles(cap)) * 4));
+    HIP_TRY(hipMemsetAsync(aux_sort_dep(b), 0, kDepWords * 4, m->stream));   // (RadixSortSignals::dep: zero before a sort; the sort leaves it so)
+    HIP_TRY(hipStreamSynchronize(m->stream));
     b.tiles_capacity = radix_tiles(cap);
     b.resident = m->aux_resident;
     m->aux_cap = cap;
@@ -963,7 +980,7 @@ chad_status prepare_slot(chad_map* m, size_t n, FrameSlot** out) {
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t polls = 0; m->h_consumed[turn * 16] != f.input_seq; polls++) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { HIP_TRY(hipStreamSynchronize(f.prep)); break; }
-            if (m->folding && (polls & 63u) == 63u) TRY(fold_advance(m, false));   // a roll-over's fold waits for the host once on its way: not for as long as the host waits here
+            if (fold_busy(m) && (polls & 63u) == 63u) TRY(fold_advance(m, false));   // a roll-over's fold waits for the host once on its way: not for as long as the host waits here
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -1050,7 +1067,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     g_host_profile.mark(8);
     TRY(note_pose(m, position));
     TRY(finish_closing(m, false));   // a roll-over's archive, once its size is known (never waits)
-    if (m->folding) TRY(fold_advance(m, false));   // ... and its fold into the DAG, a stage at a time (CHAD_FLAG_DAG_ONLY)
+    if (fold_busy(m)) TRY(fold_advance(m, false));   // ... and its fold into the DAG, a stage at a time (CHAD_FLAG_DAG_ONLY)
     m->frames_empty_tail = 0;
 
     TRY(grow_if_needed(m));
@@ -1320,6 +1337,12 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         CREATE_TRY(hipStreamCreateWithPriority(&m->fold_stream, hipStreamNonBlocking, greatest));
     }
+    if (m->fold_stream) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        CREATE_TRY(hipStreamCreateWithPriority(&m->close_stream, hipStreamNonBlocking, std::getenv("CHAD_DEBUG_FOLD_NO_PRIORITY") ? least : greatest));
+    }
+    CREATE_TRY(hipEventCreateWithFlags(&m->clusters_ready, hipEventDisableTiming));
     CREATE_TRY(hipHostMalloc(&m->merge_host, 32 * 8));
     // what the look-back sort may assume about residency: the pass kernel's real occupancy, shared among the frames in flight
     m->sort_resident = radix_resident_workgroups<PointPayload>();
@@ -1327,7 +1350,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->aux_sort.resident = m->aux_resident;
     if (std::getenv("CHAD_DEBUG_SORT_TICKETS")) m->sort_resident = 0u;   // experiments: every sort takes tickets
     for (uint32_t k = 0; k < m->n_slots; k++) m->slot[k].sort.resident = m->sort_resident / (m->serial ? 1u : m->n_slots);
-    CREATE_TRY(hipMalloc(&m->d_cursor, 4));
+    CREATE_TRY(hipMalloc(&m->d_cursor, 8));   // ([1]: k_table_keys' cursor on close_stream, beside whatever the map's stream compacts)
     if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
     if (times_kernels(m))
@@ -1347,6 +1370,7 @@ void chad_map_destroy(chad_map* m) {
     orphan_iterators(m);   // iterators that outlive the map report invalid instead of dangling
     DeviceGuard guard(m->device);
     if (m->closing_comm) (void)finish_closing(m, true);   // an exchange in flight is collective: this rank's remaining stages are issued before the map goes
+    if (m->close_stream) (void)hipStreamSynchronize(m->close_stream);
     if (m->fold_stream) (void)hipStreamSynchronize(m->fold_stream);
     for (auto& f : m->slot) if (f.prep && f.prep != m->stream) (void)hipStreamSynchronize(f.prep);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
@@ -1390,7 +1414,7 @@ void chad_map_destroy(chad_map* m) {
     if (m->producer_ready) (void)hipEventDestroy(m->producer_ready);
     if (m->merge_event) (void)hipEventDestroy(m->merge_event);
     if (m->merge_host) (void)hipHostFree(m->merge_host);
-    m->merge_a.release(); m->merge_b.release(); m->merge_c.release(); m->archive_arena.release(); m->cluster_arena.release();
+    m->merge_a.release(); m->merge_b.release(); m->merge_c.release(); m->archive_arena.release(); m->cluster_arena.release(); m->cluster_arenas[0].release(); m->cluster_arenas[1].release();
     if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
     free_sort_buffers(m->aux_sort);
     m->ddag.release();
@@ -1399,6 +1423,8 @@ void chad_map_destroy(chad_map* m) {
     if (m->fold_t1) (void)hipEventDestroy(m->fold_t1);
     if (m->spare_cleared) (void)hipEventDestroy(m->spare_cleared);
     if (m->fold_stream) (void)hipStreamDestroy(m->fold_stream);
+    if (m->close_stream) (void)hipStreamDestroy(m->close_stream);
+    if (m->clusters_ready) (void)hipEventDestroy(m->clusters_ready);
     if (m->excl_done) (void)hipEventDestroy(m->excl_done);
     if (m->closing_counted) (void)hipEventDestroy(m->closing_counted);
     if (m->closing_count) (void)hipHostFree(m->closing_count);
@@ -1527,7 +1553,7 @@ chad_status chad_map_sync(chad_map* m) {
     DeviceGuard guard(m->device);
     uint32_t overflow = 0;
     TRY(finish_closing(m, true));   // a roll-over's archive (or exchange: every rank syncs at the same point) is part of "all enqueued work"
-    while (m->folding) TRY(fold_advance(m, true));   // ... and so is its fold into the DAG (CHAD_FLAG_DAG_ONLY)
+    while (fold_busy(m)) TRY(fold_advance(m, true));   // ... and so is its fold into the DAG (CHAD_FLAG_DAG_ONLY)
     TRY(read_back_header(m, &overflow));
     if (overflow & kSortFaultStalled) (void)hipMemset(m->d_overflow, 0, 4);   // reported once (every stream is idle here); capacity flags stay until a reset
     if (overflow & kSortFaultStalled) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors (workgroups not dispatched in index order?): at least one frame was sorted incompletely");
@@ -1540,7 +1566,7 @@ chad_status chad_map_reset(chad_map* m) {
     HostProfileScope profiled(7);
     DeviceGuard guard(m->device);
     TRY(finish_closing(m, true));
-    while (m->folding) TRY(fold_advance(m, true));
+    while (fold_busy(m)) TRY(fold_advance(m, true));
     if (!m->closed.empty()) {
         TRY(join_streams(m));
         for (auto& s : m->closed) free_submap(s);
@@ -1887,61 +1913,75 @@ chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum,
 // The fold in flight, one stage further if its numbers have arrived (block: wait for them).  When it completes, the submap's roots join
 // dag_roots and the host's mirror of the level arrays is stale.
 chad_status fold_advance(chad_map* m, bool block) {
-    if (!m->folding) return CHAD_OK;
     hipStream_t s = m->fold_stream ? m->fold_stream : m->stream;
-    bool done = false;
-    uint32_t root_tsdf = 0, root_weight = 0;
-    const int stage_before = m->fold.stage;
-    HIP_TRY(dag_fold_advance(m->ddag, m->fold, s, block, &done, &root_tsdf, &root_weight));
-    if (m->fold.stage == 2 && stage_before == 1) HIP_TRY(hipEventRecord(m->fold_t1, s));   // (behind the last stage's kernels)
-    if (!done) return CHAD_OK;
-    float t = 0;
-    if (hipEventElapsedTime(&t, m->fold_t0, m->fold_t1) == hipSuccess) m->dag_ms_device = t; else (void)hipGetLastError();
-    m->dag_roots.push_back({root_tsdf, root_weight});
-    m->dag_mirror_stale = true;
-    m->folding = false;
+    if (m->folding) {
+        bool done = false;
+        uint32_t root_tsdf = 0, root_weight = 0;
+        const int stage_before = m->fold.stage;
+        HIP_TRY(dag_fold_advance(m->ddag, m->fold, s, block, &done, &root_tsdf, &root_weight));
+        if (m->fold.stage == 2 && stage_before == 1) HIP_TRY(hipEventRecord(m->fold_t1, s));   // (behind the last stage's kernels)
+        if (!done) return CHAD_OK;
+        float t = 0;
+        if (hipEventElapsedTime(&t, m->fold_t0, m->fold_t1) == hipSuccess) m->dag_ms_device = t; else (void)hipGetLastError();
+        m->dag_roots.push_back({root_tsdf, root_weight});
+        m->dag_mirror_stale = true;
+        m->folding = false;
+    }
+    if (m->pending.set) {   // the submap that was closed meanwhile: its fold begins behind its cluster words
+        if (m->close_stream) HIP_TRY(hipStreamWaitEvent(s, m->clusters_ready, 0));
+        HIP_TRY(hipEventRecord(m->fold_t0, s));
+        HIP_TRY(dag_fold_begin(m->ddag, m->fold, m->pending.keys, m->pending.tsdf, m->pending.weight, m->pending.mask, m->pending.blocks, s));
+        m->pending.set = false;
+        m->folding = true;
+    }
     return CHAD_OK;
 }
 
-// CHAD_FLAG_DAG_ONLY, second half of a roll-over: the closing table's block count is on the host.  Its bricks become cluster words
-// straight from the table, in key order (k_table_keys, the sort, k_sorted_clusters: no dense copy is ever made), the table is
-// cleared and handed back as the spare and the fold into the DAG is begun -- all on the fold's own stream, beside the frames and beside the
-// map's stream; the fold's later stages are enqueued by the inserts that follow (fold_advance).  Nothing here waits for the device
-// unless the previous submap's fold is still in flight (it shares the scratch).
+// CHAD_FLAG_DAG_ONLY, second half of a roll-over: the closing table's block count is on the host.  Two steps, on a stream each, beside
+// the frames and beside the map's stream:
+//   A  (close_stream) the closing table's keys, their order, its bricks as cluster words in that order (k_table_keys, the sort,
+//      k_sorted_clusters: no dense copy is ever made); the table is cleared behind that (map's stream) and is the spare again;
+//   B  (fold_stream) the fold of those words into the DAG (dag_device.hpp), its second stage enqueued by the inserts that follow.
+// B takes the submaps one after the other -- a level's addresses depend on everything added before -- but A needs nothing of the
+// DAG: the A of a roll-over runs beside the B of the one before (the words in two arenas, taken in turn), and what paces a
+// trajectory of cfg5's kind is the longer of the two steps instead of their sum.  Nothing here waits for the device unless TWO
+// submaps are already on their way (one being folded, one waiting for that).
 chad_status close_into_dag(chad_map* m, uint32_t blocks) {
-    TRY(fold_archived(m));   // the previous submap's fold, and submaps closed by other routes: the DAG takes them in closing order
-    hipStream_t s = m->fold_stream ? m->fold_stream : m->stream;
+    while (m->pending.set) TRY(fold_advance(m, true));   // (the fold before the waiting one is done: the waiting one begins; the arena of the one before it is free)
+    if (m->closed.size() > m->dag_roots.size() + (m->folding ? 1u : 0u)) TRY(fold_archived(m));   // submaps closed by other routes: the DAG takes them in closing order
+    hipStream_t s = m->close_stream ? m->close_stream : m->stream;
     const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
     const size_t nb = std::max<uint32_t>(blocks, 1);
     const size_t words = nb * 8;
     const size_t need = Arena::padded(nb * 8) + Arena::padded(nb * 4) + (saturate ? 2 : 1) * Arena::padded(words * 8) + Arena::padded(nb);
-    if (need > m->cluster_arena.cap) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipStreamSynchronize(m->stream)); }   // (the arena is about to move)
-    HIP_TRY(m->cluster_arena.reserve(need));
-    uint64_t* keys = m->cluster_arena.take<uint64_t>(nb);
-    uint32_t* slots = m->cluster_arena.take<uint32_t>(nb);
-    uint64_t* tsdf = m->cluster_arena.take<uint64_t>(words);
-    uint64_t* weight = saturate ? m->cluster_arena.take<uint64_t>(words) : nullptr;
-    uint8_t* mask = m->cluster_arena.take<uint8_t>(nb);
+    Arena& arena = m->cluster_arenas[m->closings++ & 1u];   // (its last user was the fold of the roll-over before the one that may be in flight: done)
+    if (need > arena.cap) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipStreamSynchronize(m->stream)); }   // (the arena is about to move)
+    HIP_TRY(arena.reserve(need));
+    uint64_t* keys = arena.take<uint64_t>(nb);
+    uint32_t* slots = arena.take<uint32_t>(nb);
+    uint64_t* tsdf = arena.take<uint64_t>(words);
+    uint64_t* weight = saturate ? arena.take<uint64_t>(words) : nullptr;
+    uint8_t* mask = arena.take<uint8_t>(nb);
     m->in_fold_setup = true;
     const chad_status sorter = blocks ? ensure_aux_sort(m, blocks) : CHAD_OK;
     m->in_fold_setup = false;
     TRY(sorter);
     if (s != m->stream) HIP_TRY(hipStreamWaitEvent(s, m->closing_counted, 0));   // behind the closing table's last update (the count was copied behind them)
-    HIP_TRY(hipEventRecord(m->fold_t0, s));
     if (blocks) {   // the live slots' keys, their order (all eight digits: full 63-bit codes), then the bricks in that order
         RadixSortSignals sig;
         sig.fault = m->d_overflow;
-        HIP_TRY(hipMemsetAsync(m->d_cursor, 0, 4, s));
-        hipLaunchKernelGGL(k_table_keys, dim3(std::max(1u, std::min(2048u, ((m->closing_view.hash_mask >> 5) + 256u) / 256u))), dim3(256), 0, s, m->closing_view, m->d_cursor, blocks, m->aux_sort.keys[0], slots);
+        sig.dep = aux_sort_dep(m->aux_sort);   // block keys: two of the eight passes usually have nothing to do
+        HIP_TRY(hipMemsetAsync(m->d_cursor + 1, 0, 4, s));
+        hipLaunchKernelGGL(k_table_keys, dim3(std::max(1u, std::min(2048u, ((m->closing_view.hash_mask >> 5) + 256u) / 256u))), dim3(256), 0, s, m->closing_view, m->d_cursor + 1, blocks, m->aux_sort.keys[0], slots);
         radix_sort_enqueue(m->aux_sort, blocks, kMaxPasses, nullptr, s, 0, 0, sig);
         HIP_TRY(hipMemcpyAsync(keys, m->aux_sort.keys[0], size_t(blocks) * 8, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_sorted_clusters, grid_for(size_t(blocks) * 16, 256, 4096), dim3(256), 0, s, m->closing_view, (const uint32_t*)m->aux_sort.idx[0], (const uint32_t*)slots, blocks, m->trunc,
                            1.0f / m->trunc /* submap.hpp:23 */, tsdf, weight, mask);
         HIP_TRY(hipGetLastError());
     }
-    // the table's clear: off the fold's chain (the next roll-over waits for the fold, and for the spare only then) -- on the map's stream,
-    // behind the kernel that read the bricks; nothing the frames wait for is enqueued there before the next roll-over
-    if (s != m->stream) { HIP_TRY(hipEventRecord(m->spare_cleared, s)); HIP_TRY(hipStreamWaitEvent(m->stream, m->spare_cleared, 0)); }
+    // the table's clear: on the map's stream, behind the kernel that read the bricks; nothing the frames wait for is enqueued there
+    // before the next roll-over
+    if (s != m->stream) { HIP_TRY(hipEventRecord(m->clusters_ready, s)); HIP_TRY(hipStreamWaitEvent(m->stream, m->clusters_ready, 0)); }
     enqueue_clear(m->closing_view, m->stream);
     HIP_TRY(hipGetLastError());
     m->spare_flags = std::max(m->spare_flags, 1);
@@ -1951,9 +1991,9 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     Submap gone;   // a closed submap without bricks: it is its DAG (read back with chad_map_dag_leaves, the iterator, the mesh from the DAG)
     gone.blocks = blocks; gone.released = true;
     m->closed.push_back(gone);
-    HIP_TRY(dag_fold_begin(m->ddag, m->fold, keys, tsdf, weight, mask, blocks, s));
-    m->folding = true;
-    return CHAD_OK;
+    m->pending.keys = keys; m->pending.tsdf = tsdf; m->pending.weight = weight; m->pending.mask = mask; m->pending.blocks = blocks;
+    m->pending.set = true;
+    return fold_advance(m, false);   // (begins the fold at once if none is in flight)
 }
 
 // Fold the submaps closed since the last call into the DAG, in closing order (the order the reference finalizes them in).
@@ -1963,7 +2003,7 @@ chad_status finalize_closed(chad_map* m) {
 }
 // ... those that were archived as dense copies (the default; the exchange's result; a closing without a spare table), start to finish
 chad_status fold_archived(chad_map* m) {
-    while (m->folding) TRY(fold_advance(m, true));
+    while (fold_busy(m)) TRY(fold_advance(m, true));
     if (m->dag_roots.size() >= m->closed.size()) return CHAD_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));   // (the folds below run on the map's stream: behind whatever a level's growth left on the other one)

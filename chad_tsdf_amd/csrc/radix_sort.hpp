@@ -97,7 +97,17 @@ struct RadixSortSignals {
     uint32_t seq = 0;               // caller's raw points (PointPayload::first), has completed by then (stream order)
     hipEvent_t* pass_events = nullptr;  // kernel timing: launch p takes its dispatch time stamps into pass_events[2p], [2p + 1]
     uint32_t* launches_out = nullptr;   // (host) ... and the number of pass launches is stored here
+    // Passes 5 and 6 (key bits 40..55) are skipped when, over this sort's keys, both digits are FUNCTIONS of the last pass's digit
+    // (bits 56..63): keys that agree in the top digit then agree in those two, and sorting by the top digit orders them as well.
+    // Block keys are such keys: coordinates are stored with an offset of 2^20 (morton.hpp), so around the origin the upper bits of
+    // an axis are 1000..0 or 0111..1 -- all of them change with the sign, none varies on its own -- and far from it they are
+    // constant.  k_radix_histograms checks the dependence (dep: [2][256] first digit seen per top digit, stored + 1, then one word
+    // that is non-zero when two keys disagree; all zero before the sort, zeroed again by the last pass); two passes, so the result
+    // stays in the buffer it would have been in.  Null: every pass runs.
+    uint32_t* dep = nullptr;
 };
+constexpr uint32_t kDepWords = 2 * 256 + 1;
+constexpr uint32_t kDepFirstPass = 5, kDepTopPass = 7;   // 8-bit digits: passes 5 and 6 against pass 7
 
 inline uint32_t radix_tiles(size_t n) { return uint32_t((n + kSortTile - 1) / kSortTile); }
 __host__ __device__ inline uint32_t radix_groups(uint32_t tiles) { return (tiles + kGroupTiles - 1) / kGroupTiles; }
@@ -108,8 +118,11 @@ __host__ __device__ inline size_t radix_status_words(uint32_t tiles, uint32_t ra
 // Also clears the look-back table of the coming passes (saves a memset launch).
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_histograms(const uint64_t* __restrict__ keys, uint32_t n, uint32_t passes, const uint32_t* __restrict__ pass_limit,
-                   uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words) {
+                   uint32_t* __restrict__ hist_part, uint32_t* __restrict__ tile_status, uint32_t status_words, uint32_t* __restrict__ dep) {
     __shared__ uint32_t hist[kMaxPasses][kRadix];
+    __shared__ uint32_t seen[2][kRadix];   // dep: digit of pass 5 / 6 first seen with each top digit, + 1
+    __shared__ uint32_t disagree;
+    if (dep) { for (uint32_t k = threadIdx.x; k < 2 * kRadix; k += kSortThreads) (&seen[0][0])[k] = 0u; if (threadIdx.x == 0) disagree = 0u; }
     const uint32_t active = pass_limit ? min(passes, *pass_limit) : passes;
     for (size_t k = size_t(blockIdx.x) * kSortThreads + threadIdx.x; k < status_words; k += size_t(gridDim.x) * kSortThreads) tile_status[k] = 0u;
     for (uint32_t k = threadIdx.x; k < kMaxPasses * kRadix; k += kSortThreads) (&hist[0][0])[k] = 0;
@@ -124,6 +137,16 @@ k_radix_histograms(const uint64_t* __restrict__ keys, uint32_t n, uint32_t passe
         for (uint32_t j = 0; j < 4; j++) {
             if (i0 + j * stride >= n) break;
             const uint64_t key = key4[j];
+            if (dep) {   // (one lane speaks for a wave that agrees on all three digits: the usual case)
+                const uint32_t top = uint32_t(key >> (kDepTopPass * kRadixBits)) & (kRadix - 1), both = uint32_t(key >> (kDepFirstPass * kRadixBits)) & 0xffffu;
+                const uint32_t word = (top << 16) | both, word0 = uint32_t(__builtin_amdgcn_readfirstlane(int(word)));
+                const bool agreed = __ballot(word != word0) == 0ull;
+                if (!agreed || (__ballot(true) & ((1ull << (threadIdx.x & 63u)) - 1ull)) == 0ull)
+                    for (uint32_t q = 0; q < 2; q++) {
+                        const uint32_t mine = ((both >> (8u * q)) & 0xffu) + 1u, was = atomicCAS(&seen[q][top], 0u, mine);
+                        if (was != 0u && was != mine) disagree = 1u;
+                    }
+            }
             // (a digit the whole wave agrees on -- the upper digits of block keys: a submap spans a few values of them -- is counted with
             // one atomic instead of sixty-four on the same LDS word)
             const uint64_t here = __ballot(true);
@@ -136,6 +159,14 @@ k_radix_histograms(const uint64_t* __restrict__ keys, uint32_t n, uint32_t passe
     }
     __syncthreads();
     for (uint32_t p = 0; p < active; p++) hist_part[(size_t(blockIdx.x) * kMaxPasses + p) * kRadix + threadIdx.x] = hist[p][threadIdx.x];
+    if (dep) {   // this workgroup's view against everybody else's
+        bool bad = disagree != 0u;
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t mine = seen[q][threadIdx.x];
+            if (mine) { const uint32_t was = atomicCAS(&dep[q * kRadix + threadIdx.x], 0u, mine); bad = bad || (was != 0u && was != mine); }
+        }
+        if (bad) atomicOr(&dep[2 * kRadix], 1u);
+    }
 }
 
 // digit_base[p][d] = number of keys whose digit of pass p is d: the sum of the partial tables.  Four workgroups per pass
@@ -364,6 +395,10 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
     const uint32_t limit = pass_limit ? min(uint32_t(kMaxPasses), *pass_limit) : uint32_t(kMaxPasses);
     uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
     (void)kBits;
+    if (sig.dep) {   // (RadixSortSignals::dep; such a sort has a launch per pass)
+        if ((first_pass == kDepFirstPass || first_pass == kDepFirstPass + 1u) && sig.dep[2 * kRadix] == 0u) return;
+        if (first_pass == kDepTopPass && blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < kDepWords; k += kSortThreads) sig.dep[k] = 0u;   // for the next sort
+    }
     // this launch runs behind pass 0 (stream order): the caller's raw points have been read for the last time
     if (sig.consumed && first_pass > 0u && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig.consumed, sig.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (uint32_t pass = first_pass; pass < limit; pass++) {
@@ -443,7 +478,7 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     uint32_t* ticket = b.tile_status + radix_status_words(tiles) - 64;
     if (hist_blocks == 0) {
         hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part, b.tile_status,
-                           uint32_t(radix_status_words(tiles)));
+                           uint32_t(radix_status_words(tiles)), sig.dep);
     }
     // hist_blocks != 0: the caller's keys kernel has already added its digit counts into the striped totals (k_frame_keys)
     const uint32_t base_stripes = hist_blocks ? kBaseStripes : 1u;
