@@ -1327,7 +1327,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipEventCreateWithFlags(&m->merge_event, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->spare_cleared, hipEventDisableTiming));
     CREATE_TRY(hipEventCreate(&m->fold_t0)); CREATE_TRY(hipEventCreate(&m->fold_t1));
-    if (m->serial) m->fold_stream = nullptr;
+    if (m->serial || !(m->flags & CHAD_FLAG_DAG_ONLY)) m->fold_stream = nullptr;   // (only CHAD_FLAG_DAG_ONLY roll-overs use the two streams: a map without the flag does not hold hardware queues for them)
     else if (std::getenv("CHAD_DEBUG_FOLD_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&m->fold_stream, hipStreamNonBlocking));
     else {
         // Streams of one priority share a few hardware queues: at the default priority the fold's chain of fifty launches sat in the
@@ -1745,6 +1745,7 @@ static chad_status export_blocks(chad_map* m, int32_t submap, uint64_t* keys_dev
     // order the bricks by block key with the radix sorter (all 8 digits: keys are full 63-bit codes)
     RadixSortSignals sig;
     sig.fault = m->d_overflow;
+    sig.dep = aux_sort_dep(m->aux_sort);   // (block keys: RadixSortSignals::dep)
     hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
     radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
     hipLaunchKernelGGL(k_gather_bricks, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, keys_device, sum_device, cnt_device);
@@ -1876,6 +1877,7 @@ chad_status device_cluster_words(chad_map* m, const uint64_t* keys, const float*
     // order the bricks by block key with the frame's radix sorter (all 8 digits: keys are full 63-bit codes)
     RadixSortSignals sig;
     sig.fault = m->d_overflow;
+    sig.dep = aux_sort_dep(m->aux_sort);   // (block keys: RadixSortSignals::dep)
     hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
     radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
     hipLaunchKernelGGL(k_leaf_clusters, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, 1.0f / m->trunc /* submap.hpp:23 */,
@@ -2376,6 +2378,7 @@ chad_status mesh_source(chad_map* m, int32_t submap, DevBuf& keys_sorted, DevBuf
     TRY(ensure_aux_sort(m, nb));
     RadixSortSignals sig;
     sig.fault = m->d_overflow;
+    sig.dep = aux_sort_dep(m->aux_sort);   // (block keys: RadixSortSignals::dep)
     hipLaunchKernelGGL(k_copy_u64, grid_for(nb), dim3(256), 0, m->stream, keys, m->aux_sort.keys[0], nb);
     radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, m->stream, 0, 0, sig);
     hipLaunchKernelGGL(k_brick_means, grid_for(size_t(nb) * 64), dim3(256), 0, m->stream, (const uint32_t*)m->aux_sort.idx[0], nb, keys, sum, cnt, keys_sorted.as<uint64_t>(), means.as<float>());
