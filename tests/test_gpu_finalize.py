@@ -229,3 +229,32 @@ def test_device_fold_equals_the_host_fold(chad, monkeypatch, saturate):
         assert np.array_equal(dl[l], hl[l]), f"level {l}"
     assert list(ds["uniques"]) == list(hs["uniques"]) and list(ds["dupes"]) == list(hs["dupes"])
     assert ds["device_bytes"] > 0
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (812.0, -3.0, 0.0), (-1640.0, 407.0, 100.0)])
+def test_block_key_order_near_and_far_from_the_origin(chad, oracle, offset):
+    """The fold wants a submap's blocks in key order, and the sort that puts them there leaves two of its eight passes out when their
+    digits are functions of the top digit over the submap's keys (radix_sort.hpp, RadixSortSignals::dep): around the origin the upper
+    bits of a coordinate all change with its sign (offset 2^20, morton.hpp:21-37), far from it they are constant -- and where a
+    submap lies across a power of two in between (x = 2^14 voxels = 819.2 m here, x = -2^15, y = 2^13) some of them do vary on
+    their own and every pass must run.  Both closing routes -- the dense archive, and CHAD_FLAG_DAG_ONLY's cluster words straight
+    from the table -- against the oracle's finalize of the same leaves: every level array, the counters, the roots."""
+    shift = np.asarray(offset, np.float32)
+    frames = [(pts + shift, pos + shift) for pts, pos in corridor(20, 40_000)]
+    kept = chad.TSDFMap(0.05, 0.10)
+    gone = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    o = oracle.OracleMap(0.05, 0.10)
+    for pts, pos in frames:
+        kept.insert(pts, pos)
+        gone.insert(pts, pos)
+    kept.close_submap()
+    gone.close_submap()
+    closed = kept.closed_submaps
+    assert closed == gone.closed_submaps == 3
+    for k in range(closed):
+        o.close_submap_from_leaves(*kept.export_leaves(k))
+    assert_same_dag(kept, o)
+    assert_same_dag(gone, o)      # (the two maps hold the same integers: test_maps_are_bit_reproducible)
+    for k in range(closed):
+        assert kept.dag_roots(k) == gone.dag_roots(k) == o.dag_roots(k)
+    kept.close(); gone.close()
