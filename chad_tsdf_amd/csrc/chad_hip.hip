@@ -1555,6 +1555,7 @@ chad_status chad_map_sync(chad_map* m) {
     TRY(finish_closing(m, true));   // a roll-over's archive (or exchange: every rank syncs at the same point) is part of "all enqueued work"
     while (fold_busy(m)) TRY(fold_advance(m, true));   // ... and so is its fold into the DAG (CHAD_FLAG_DAG_ONLY)
     TRY(read_back_header(m, &overflow));
+    if (!m->ddag.outgrown.empty()) { TRY(join_streams(m)); m->ddag.free_outgrown(); }   // what the DAG's levels have grown out of: freed where a hipFree's device-wide wait costs nothing
     if (overflow & kSortFaultStalled) (void)hipMemset(m->d_overflow, 0, 4);   // reported once (every stream is idle here); capacity flags stay until a reset
     if (overflow & kSortFaultStalled) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors (workgroups not dispatched in index order?): at least one frame was sorted incompletely");
     if (overflow) return fail(CHAD_ERR_CAPACITY, "block capacity of the active submap exceeded; raise chad_options.max_blocks");

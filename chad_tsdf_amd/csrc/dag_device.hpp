@@ -616,10 +616,13 @@ struct DeviceDag {
     size_t outgrown_bytes = 0;
     bool ready = false;
 
-    void release() {
-        for (auto& l : level) { (void)hipFree(l.table); (void)hipFree(l.raw); l = DagLevelDev{}; }
+    void free_outgrown() {   // (the device is idle: nothing is folding, nothing reads a level)
         for (void* p : outgrown) (void)hipFree(p);
         outgrown.clear(); outgrown_bytes = 0;
+    }
+    void release() {
+        for (auto& l : level) { (void)hipFree(l.table); (void)hipFree(l.raw); l = DagLevelDev{}; }
+        free_outgrown();
         (void)hipFree(d_scalars); (void)hipFree(d_total); (void)hipFree(d_hist); (void)hipFree(arena);
         if (h_small) (void)hipHostFree(h_small);
         d_scalars = nullptr; d_total = nullptr; d_hist = nullptr; arena = nullptr; h_small = nullptr; arena_cap = 0; ready = false;
