@@ -641,7 +641,7 @@ inline hipError_t dag_device_init(DeviceDag& d, hipStream_t s) {
     if ((e = hipHostMalloc(&d.h_small, 4096)) != hipSuccess) return e;
     for (uint32_t l = 0; l <= kDagDepth; l++) {
         DagLevelDev& L = d.level[l];
-        L.table_slots = 1u << 16; L.raw_capacity = 1u << 16;
+        L.table_slots = 1u << 19; L.raw_capacity = 1u << 19;   // (2 + 2..4 MB per level: a room-sized submap's 75 k cluster candidates fit without growing anything)
         if ((e = hipMalloc(&L.table, size_t(L.table_slots) * 4)) != hipSuccess) return e;
         if ((e = hipMalloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4))) != hipSuccess) return e;
         if ((e = hipMemsetAsync(L.table, 0, size_t(L.table_slots) * 4, s)) != hipSuccess) return e;
@@ -782,7 +782,9 @@ inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool
         auto ref = [&](uint32_t l) { return DagLevelRef{d.level[l].table, d.level[l].raw, d.level[l].table_slots - 1, d.level[l].raw_capacity}; };
         // probe | count | commit | resolve of level l over n candidates; beside the probe, the heads among the level's own nodes for the level above
         auto batch = [&](uint32_t l, const void* cand, uint32_t n, uint32_t* pos, uint32_t* result, unsigned long long extra_dupes, const uint64_t* heads_of, uint32_t heads_n) {
-            const dim3 flat = dag_grid(n), chunked(std::max(1u, std::min((n + kDagChunk - 1) / kDagChunk, kDagStepGrid)));
+            // (a small batch probes with an eighth of the threads, eight candidates each: with every candidate of a room-sized submap in
+            // flight at once, the thousands that hold the same few values queue on the same slots -- 61 -> 25 us for a cfg2 frame's clusters)
+            const dim3 flat = dag_grid(n, n < (1u << 20) ? 2048u : 256u), chunked(std::max(1u, std::min((n + kDagChunk - 1) / kDagChunk, kDagStepGrid)));
             DagScalars* sc = d.d_scalars + l;
             if (l == kDagDepth) {
                 hipLaunchKernelGGL(k_dag_probe<false>, flat, dim3(256), 0, s, ref(l), sc, cand, n, pos, heads_of, heads_n, f.head_sums);
