@@ -477,9 +477,10 @@ k_dag_small_levels(DagLevelsArg L, DagScalars* __restrict__ scalars, int top /* 
     __shared__ uint32_t cand[2 * kDagSmall][8];
     __shared__ uint32_t head_pos[kDagSmall + 1];
     __shared__ uint32_t scratch[17];
-    __shared__ uint32_t batch_base;
+    __shared__ uint32_t level_size[kDagDepth];   // the levels' sizes, read once: nobody else adds to these levels while this kernel runs
     const uint32_t t = threadIdx.x;
     uint32_t cur = 0;
+    if (t < kDagDepth) level_size[t] = scalars[t].size;
     if (t < n_below) { prefix[0][t] = prefix_below[t]; addr[0][2 * t] = addr_below[2 * t]; addr[0][2 * t + 1] = addr_below[2 * t + 1]; }
     __syncthreads();
     for (int d = top; d >= 0; d--) {
@@ -509,7 +510,7 @@ k_dag_small_levels(DagLevelsArg L, DagScalars* __restrict__ scalars, int top /* 
         uint32_t* raw = L.raw[d];
         const uint32_t mask = L.mask[d];
         uint32_t pos[2] = {0, 0};
-        const uint32_t base = __hip_atomic_load(&scalars[d].size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (updated by thread 0 only behind the next barriers)
+        const uint32_t base = level_size[d];
         for (uint32_t k = 0; k < 2; k++) {
             const uint32_t i = 2 * t + k;
             if (i >= n) break;
@@ -535,46 +536,49 @@ k_dag_small_levels(DagLevelsArg L, DagScalars* __restrict__ scalars, int top /* 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (atomicMin returns nothing: it must have been performed before anybody reads the slot)
         __syncthreads();
+        // who owns its slot (new: its words are counted), who found a stored value (its address is what the slot holds), who shares a
+        // new value with an earlier candidate of this batch (the owner's address, once the owner has one: from LDS, not from the slot)
         unsigned long long v[2] = {0, 0};
+        uint32_t seen[2] = {0, 0};
         for (uint32_t k = 0; k < 2; k++) {
             const uint32_t i = 2 * t + k;
-            if (i < n && __hip_atomic_load(&table[pos[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == base + i) {
+            if (i >= n) break;
+            seen[k] = __hip_atomic_load(&table[pos[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen[k] == base + i) {
                 uint32_t words = 1;
                 for (int o = 0; o < 8; o++) words += cand[i][o] ? 1u : 0u;
                 v[k] = (1ull << 32) | words;
             }
         }
         uint32_t total_words, total_new;
-        uint32_t at = dag_scan1024(uint32_t(v[0]) + uint32_t(v[1]), &total_words, scratch);
+        uint32_t at = base + dag_scan1024(uint32_t(v[0]) + uint32_t(v[1]), &total_words, scratch);
         (void)dag_scan1024(uint32_t(v[0] >> 32) + uint32_t(v[1] >> 32), &total_new, scratch);
-        if (t == 0) {
+        if (t == 0) {   // (stores and result-less atomics only: nothing here waits for memory)
             DagScalars* s = scalars + d;
-            batch_base = s->size;
-            s->batch_base = s->size; __hip_atomic_store(&s->size, s->size + total_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s->entries += total_new; s->uniques += total_new; s->dupes += n - total_new;
+            s->batch_base = base;
+            __hip_atomic_store(&s->size, base + total_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&s->entries, total_new);
+            atomicAdd(&s->uniques, (unsigned long long)total_new);
+            atomicAdd(&s->dupes, (unsigned long long)(n - total_new));
         }
-        __syncthreads();
-        at += batch_base;
-        uint32_t result[2] = {0, 0};
         for (uint32_t k = 0; k < 2; k++) {
             const uint32_t i = 2 * t + k;
-            if (i >= n || !v[k]) continue;
+            if (i >= n) break;
+            if (!v[k]) { if (seen[k] < base) addr[cur ^ 1][i] = seen[k]; continue; }
             const uint32_t words = uint32_t(v[k]);
             if (at + words <= L.capacity[d]) {
                 uint32_t m = 0, w = at + 1;
                 for (int o = 0; o < 8; o++) if (cand[i][o]) { m |= 1u << o; raw[w++] = cand[i][o]; }
                 raw[at] = m;
             }
-            table[pos[k]] = at;
-            result[k] = at;
+            table[pos[k]] = at;   // (nobody reads this level's table again in this launch)
+            addr[cur ^ 1][i] = at;
             at += words;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (uint32_t k = 0; k < 2; k++) {
             const uint32_t i = 2 * t + k;
-            if (i >= n) break;
-            if (!result[k]) result[k] = __hip_atomic_load(&table[pos[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            addr[cur ^ 1][i] = result[k];
+            if (i < n && !v[k] && seen[k] >= base) addr[cur ^ 1][i] = addr[cur ^ 1][seen[k] - base];
         }
         __syncthreads();
         cur ^= 1;
@@ -782,9 +786,11 @@ inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool
         auto ref = [&](uint32_t l) { return DagLevelRef{d.level[l].table, d.level[l].raw, d.level[l].table_slots - 1, d.level[l].raw_capacity}; };
         // probe | count | commit | resolve of level l over n candidates; beside the probe, the heads among the level's own nodes for the level above
         auto batch = [&](uint32_t l, const void* cand, uint32_t n, uint32_t* pos, uint32_t* result, unsigned long long extra_dupes, const uint64_t* heads_of, uint32_t heads_n) {
-            // (a small batch probes with an eighth of the threads, eight candidates each: with every candidate of a room-sized submap in
-            // flight at once, the thousands that hold the same few values queue on the same slots -- 61 -> 25 us for a cfg2 frame's clusters)
-            const dim3 flat = dag_grid(n, n < (1u << 20) ? 2048u : 256u), chunked(std::max(1u, std::min((n + kDagChunk - 1) / kDagChunk, kDagStepGrid)));
+            // (the cluster level's and level 19's batches of a small submap probe with an eighth of the threads, eight candidates each: with
+            // every candidate of a room-sized submap in flight at once, the thousands that hold the same few values -- empty-but-one
+            // clusters, the all-ones weight nodes -- queue on the same slots: 61 -> 37 and 49 -> 24 us for a cfg2 frame.  Levels above
+            // hold few duplicates and lose by it.)
+            const dim3 flat = dag_grid(n, l + 1 >= kDagDepth && n < (1u << 17) ? 2048u : 256u), chunked(std::max(1u, std::min((n + kDagChunk - 1) / kDagChunk, kDagStepGrid)));
             DagScalars* sc = d.d_scalars + l;
             if (l == kDagDepth) {
                 hipLaunchKernelGGL(k_dag_probe<false>, flat, dim3(256), 0, s, ref(l), sc, cand, n, pos, heads_of, heads_n, f.head_sums);

@@ -2,7 +2,7 @@
 """BASELINE config 5 under CHAD_FLAG_DAG_ONLY (the reference's policy: a closed submap is its DAG and nothing else): frames made on the
 device, inserted back to back; prints the frame time, what finalize cost per submap, memory held.   --frames N (default 110)"""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("CHAD_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (CHAD_AB_ROOT: another build's tree, scripts/ab_cfg5.sh)
 import numpy as np, torch
 from chad_tsdf_amd import TSDFMap, synth
 
