@@ -22,14 +22,16 @@
 //      the global path of k_update_scatter instead, outside the hot loop;
 //   2. workgroup barrier; wave w owns the 16 bricks of slab z = w from here on.  It reads them back -- sixteen lanes per brick,
 //      a row of four cells each, four bricks per pass, all reads in flight together -- to learn which received observations;
-//      lanes 0..15 whose brick was touched and whose speculative look-up (below) did not already show the key claim or find the
-//      slot with one CAS (map_kernels.hpp);
+//      lanes 0..15 whose brick was touched claim or find its slot with one CAS (map_kernels.hpp);
 //   3. every touched brick is flushed with two wave-wide atomic adds (512 B of 64-bit sums, 256 B of counts), the full-rate shape for
 //      memory-side atomics, and its part of the tile is zeroed for the next item; workgroup barrier.
 // Memory operations of a wave complete in issue order, so a load issued behind the flush's atomics waits ~3000
 // cycles for them.  The loop is therefore software-pipelined: right after the first barrier -- before the flush --
-// every wave loads the NEXT item's first chunk of points and the home hash slots of its 16 bricks (speculative,
-// nothing is created), and the next item's record itself was fetched by wave 0 during the walk.
+// every wave loads the NEXT item's first chunk of points, and the next item's record itself was fetched by wave 0 during the walk.
+// (Until round 4 it also loaded the home hash slots of its 16 bricks there, so that a brick whose key was already in place needed
+// no CAS: 64 look-ups per item whatever it touches -- 146 k random 128-byte reads per 1 M-point frame, 18.7 of the kernel's 51.4 MB
+// read, rocprofv3 request counters with and without -- to save CASes that are in flight behind the next item's loads anyway:
+// without them the kernel alone takes 27.8 instead of 29.2 us and the frame rate is 2.3 % higher, scripts/ab_bench.sh.)
 // Work items: the first one is static (workgroup index; its record and the lists' stripe sums come ready-made from
 // k_frame_normals' last workgroup, FrameHeader::first_item / item_first: one round trip in front of the first ray instead of
 // three), the rest are pulled from 256 separate counters (a returning atomic on ONE shared address serialises at ~25 ns per
@@ -165,7 +167,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     // everything a wave holds about an item before it starts on it
     if (blockIdx.x >= nitems) record = make_uint4(0u, 0u, 0u, 0u);   // length 0: no more work
     float4 q_first = make_float4(0, 0, 0, 0), n_first = make_float4(0, 0, 0, 0);            // its first chunk's point and normal for this lane
-    uint64_t my_key = kEmptyKey, early = kEmptyKey;                                         // lanes 0..15: key of their brick, what its home slot held
+    uint64_t my_key = kEmptyKey;                                                            // lanes 0..15: key of their brick
     uint32_t my_slot = 0;
     auto prefetch = [&](const uint4& rec) {
         const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.x))), len = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.y)));
@@ -185,8 +187,6 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
             const uint32_t bx = lane & 3u, by = (lane >> 2) & 3u;
             my_key = (bx == 0u ? x0 : bx == 1u ? xd : bx == 2u ? x2 : x3) | (by == 0u ? y0 : by == 1u ? yd : by == 2u ? y2 : y3) | zs;
             my_slot = hash_block(my_key, m.hash_mask);
-            // plain load that bypasses the L1: a stale "empty" only sends the lane to the CAS; keys never change or vanish during an insert
-            early = __hip_atomic_load(&m.hash_keys[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     prefetch(record);
@@ -309,10 +309,10 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
             }
         }
         if (kStamps) { asm volatile("" :: "s"(touched)); const unsigned long long t1 = stamp_now(); ph[6] += t1 - t0; t0 = t1; }
-        // touched bricks whose key the speculative look-up did not show: one CAS claims or finds the home slot.  It is
+        // touched bricks: one CAS claims or finds the home slot.  It is
         // issued here and resolved behind the next item's loads (below), so its round trip overlaps their address arithmetic
         const bool mine = lane < 16u && ((touched >> lane) & 1u);
-        const bool ask = mine && early != this_key;
+        const bool ask = mine;
         uint64_t seen = this_key;
         if (ask) seen = atomicCAS((unsigned long long*)&m.hash_keys[this_slot], (unsigned long long)kEmptyKey, (unsigned long long)this_key);
         // the loads for the next item (in flight during the rest of step 2 and step 3)

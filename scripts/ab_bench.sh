@@ -1,5 +1,9 @@
 #!/bin/bash
-# A/B helper: N runs of the contract line (100 steps of 4 frames), prints points/s (G), ms per frame, the serial normals time and kernel sum
-n=${1:-5}; shift
-for i in $(seq $n); do "$@" python bench.py --steps 100 --no-extras --cpu-seconds 0 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.readline()); k={x['kernel']:x['ms'] for x in d['roofline']['kernels']}; print(round(d['value']/1e9,3), round(d['ms_per_frame'],4), 'normals', k['k_frame_normals'], 'sum', d['roofline']['kernel_ms_sum_serial'])"; done
+# the headline bench line (pipelined value, the update kernel's time in flight and alone) of this tree against another build's tree, alternating on one box
+other=${1:-scratch/prev}
+for i in 1 2 3; do
+  for root in . $other; do
+    (cd $root && python3 bench.py --steps 100 --no-extras --cpu-seconds 0 2>/dev/null | python3 -c "
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);r=d['roofline'];print('$root', round(d['value']/1e9,3),'G pts/s', d['ms_per_frame'].__round__(4),'ms/frame; update in flight',r['kernel_ms'],'alone',r['kernel_ms_serial'])") || exit 1
+  done
+done
