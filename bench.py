@@ -491,6 +491,9 @@ def main():
         # the same frames with the dense archives kept (the library's default; rounds 1-3 quoted this leg): 33 frames, three roll-overs
         mk5, tk, _ = run_cfg5(min(33, n5), False)
         out["cfg5"]["archives_kept_33_frames_ms_per_frame"] = round(tk / min(33, n5) * 1e3, 4)
+        uk = float(mk5.stats()["ms_oct_upd"])   # the update kernel without a roll-over's two steps beside it (update_kernel_ms above: with them, at the map stream's priority)
+        out["cfg5"]["archives_kept_update_kernel_ms"] = round(uk, 4)
+        out["cfg5"]["archives_kept_update_frac"] = round(b5 / uk / 1e6 / HBM_PEAK_GBS, 5) if uk > 0 else None
         mk5.close()
         del dev
 

@@ -1102,6 +1102,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         const float4* points0 = reinterpret_cast<const float4*>(f.sort.points[0]);
         const float4* points1 = reinterpret_cast<const float4*>(f.sort.points[1]);
         const dim3 gather_grid(std::min<uint32_t>(2048u, (count + kGatherChunk - 1) / kGatherChunk));
+        const auto gather_kernel = digit_bits == uint32_t(kWideBits) ? k_frame_gather<kWideBits> : k_frame_gather<kRadixBits>;
         if (times_kernels(m) || times_stages(m)) {   // timing modes: every kernel (or stage) bracketed, one launch at a time
             LAUNCH_TIMED(m, CHAD_KERNEL_BOUNDS, k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
             LAUNCH_TIMED(m, CHAD_KERNEL_KEYS, k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0],
@@ -1109,10 +1110,11 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             record(m, T_CALC, prep);
             uint32_t pass_launches = 0;
             if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
-            radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits);
+            RadixRest rest;
+            radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, nullptr, &rest);
             if (times_kernels(m)) m->kev_launched[m->ktimed_end % chad_map::kKernelRing] |= ((1u << pass_launches) - 1u) << CHAD_KERNEL_SORT_PASS0;
-            LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, k_frame_gather, gather_grid, dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1],
-                         points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block);
+            LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, gather_kernel, gather_grid, dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, (const uint64_t*)f.sort.keys[0], (const uint64_t*)f.sort.keys[1],
+                         points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block, rest);
             record(m, T_SORT, prep);
             LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
                          reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
@@ -1124,9 +1126,10 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                 L(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
                 L(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.digit_base, f.sort.tile_status,
                   uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks, digit_bits);
-                radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, &L);
-                L(k_frame_gather, gather_grid, dim3(256), 0, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1], points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start,
-                  list_stride, sig.consumed, sig.seq, big_block);
+                RadixRest rest;   // (the sort's catch-all, if its grid calls for one, is the gather kernel's prologue)
+                radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, &L, &rest);
+                L(gather_kernel, gather_grid, dim3(256), 0, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1], points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start,
+                  list_stride, sig.consumed, sig.seq, big_block, rest);
                 L(k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
                   reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
             };

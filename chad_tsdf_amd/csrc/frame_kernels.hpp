@@ -370,13 +370,19 @@ __device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ keys
 // LDS (block heads as a list, item starts as a 2048-bit mask whose next set bit gives an item's length) and
 // reserves output space with ONE atomic per list and chunk; the lists are in no particular order.
 // The sorted (key, idx) pairs are in sort buffer (sort_passes & 1).
-__global__ void __launch_bounds__(256)
+// Its prologue is the sort's catch-all (radix_sort.hpp, radix_rest_points: a frame whose key has outgrown the launches that were
+// enqueued for it -- normally one load and a comparison); kBits: the digit width of this frame's sort.
+template <int kBits>
+__global__ void __launch_bounds__(256, 4)   // (four waves per SIMD, as before the sort's catch-all moved in: <= 128 VGPRs)
 k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __restrict__ part,
-               const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
-               const float4* __restrict__ points0, const float4* __restrict__ points1,
+               const uint64_t* keys0, const uint64_t* keys1, const float4* points0, const float4* points1,
                uint2* __restrict__ segments, uint4* __restrict__ items, uint32_t list_stride,
-               uint32_t* __restrict__ consumed, uint32_t consumed_seq, uint32_t big_block) {
+               uint32_t* __restrict__ consumed, uint32_t consumed_seq, uint32_t big_block, RadixRest rest) {
     constexpr uint32_t kWords = kGatherChunk / 32;
+    if (rest.participants) {
+        const uint32_t limit = min(uint32_t(kMaxPasses), h->sort_passes);
+        if (rest.first_pass < limit) radix_rest_points<kBits>(rest, limit);   // (the same decision in every workgroup)
+    }
     // the sort is over (stream order), so the caller's raw points -- read by its first pass only -- are no longer needed: tell the
     // host (host-mapped word; chad_hip.hip, prepare_slot).  The sort's later launches store the same number earlier when there are any.
     if (consumed && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(consumed, consumed_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -197,7 +197,7 @@ k_radix_bases(const uint32_t* __restrict__ hist_part, uint32_t hist_blocks, uint
 // One pass for the tile of this workgroup.  pay_in may be null: the payload is then made from the element's position
 // (and `first_src`, the raw points, for PointPayload) -- the first pass.  kBits: digit width (8, or 9 with two digits per thread).
 // Returns false -- having done nothing -- when the ticket it drew lies beyond the last tile (a workgroup of the catch-all launch
-// that goes round for more, k_radix_onesweep_rest).
+// that goes round for more, radix_rest_points).
 template <class P, int kBits>
 __device__ __forceinline__ bool
 radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* __restrict__ pay_in,
@@ -424,41 +424,67 @@ k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0,
 }
 
 // The catch-all behind the hinted launches of a sort whose grid is too large to be resident at once (a 1 M-point frame with three
-// frames in flight: 489 tiles against a share of 320 workgroups): passes first_pass .. *pass_limit - 1 -- normally none, and the
-// launch returns at once -- by as many workgroups as ARE resident at once, each drawing tiles by ticket until the pass has none
-// left, with a grid barrier between passes.  (Without it such a frame got a launch per possible pass, eight: six surplus launches
-// of 4.5 us each on the frame's stream and 15 us of host time, every frame of the headline benchmark -- seen in the kernel trace
-// of round 3.)
-template <class P, int kBits = kRadixBits>
-__global__ void __launch_bounds__(kSortThreads)
-k_radix_onesweep_rest(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
-                      uint32_t n, uint32_t first_pass, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
-                      uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src,
-                      RadixSortSignals sig) {
-    const uint32_t limit = min(uint32_t(kMaxPasses), *pass_limit);
-    if (first_pass >= limit) return;
-    uint32_t* arrived = tile_ticket + kMaxPasses;   // zeroed with the look-back table
-    for (uint32_t pass = first_pass; pass < limit; pass++) {
+// frames in flight: 489 tiles against a share of 320 workgroups): passes first_pass .. limit - 1 -- normally none -- by as many
+// workgroups as ARE resident at once (`participants`: the host's share), each drawing tiles by ticket until the pass has none, with a
+// barrier among them behind every pass, the last one included.  Until round 4 a launch of its own that returned at once in
+// nearly every frame -- 5 us in the chain of every large frame, 1.3 % of the frame rate (CHAD_DEBUG_NO_REST experiment); now the
+// prologue of the kernel that follows the sort (k_frame_gather): RadixRest carries what it needs, participants == 0 says "no
+// catch-all: the grid was resident, or every pass got its launch".
+struct RadixRest {
+    uint64_t* keys[2]; uint4* points[2];
+    uint32_t n, first_pass, tiles, base_stripes, participants;
+    const uint32_t* digit_base;
+    uint32_t* tile_status; uint32_t* tile_ticket;
+    const void* first_src;
+    uint32_t* fault;
+};
+// words behind the per-pass tickets (all zeroed with the look-back table before every sort)
+constexpr uint32_t kRestArrived = kMaxPasses, kRestGate = kMaxPasses + 1, kRestDone = kMaxPasses + 2;
+
+// Every workgroup of the calling grid enters with the same `limit` > r.first_pass.  The first r.participants to ARRIVE do the passes (a
+// workgroup that has arrived is running: nobody waits for one that cannot start); the others wait for the word that says so.
+template <int kBits>
+__device__ __forceinline__ void radix_rest_points(const RadixRest& r, uint32_t limit) {
+    __shared__ uint32_t role_;
+    if (threadIdx.x == 0) role_ = atomicAdd(&r.tile_ticket[kRestGate], 1u);
+    __syncthreads();
+    const uint32_t role = role_;
+    uint32_t* done = &r.tile_ticket[kRestDone];
+    if (role >= r.participants) {
+        if (threadIdx.x == 0) {
+            uint32_t polls = 0;
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                if (++polls > kSpinLimit) { if (r.fault) atomicOr(r.fault, kSortFaultStalled); break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            __threadfence();
+        }
+        __syncthreads();
+        return;
+    }
+    uint32_t* arrived = &r.tile_ticket[kRestArrived];
+    for (uint32_t pass = r.first_pass; pass < limit; pass++) {
         const bool odd = pass & 1u;
-        while (radix_onesweep_tile<P, kBits>(odd ? keys1 : keys0, pass == 0 ? nullptr : (odd ? pay1 : pay0), odd ? keys0 : keys1, odd ? pay0 : pay1, n, pass, tiles, digit_base,
-                                             base_stripes, tile_status, tile_ticket, first_src, true, sig.fault))
+        while (radix_onesweep_tile<PointPayload, kBits>(r.keys[odd], pass == 0 ? nullptr : r.points[odd], r.keys[odd ^ 1u], r.points[odd ^ 1u], r.n, pass, r.tiles, r.digit_base,
+                                                        r.base_stripes, r.tile_status, r.tile_ticket, r.first_src, true, r.fault))
             __syncthreads();   // the tile's LDS is read to the end before the next one overwrites it
-        if (pass + 1 >= limit) break;
-        // grid barrier: this pass's output (plain stores) must be visible to every workgroup's loads of the next pass
+        // barrier among the participants: this pass's output (plain stores) must be visible to every workgroup's loads of the next
+        // pass -- and, behind the last pass, to the caller
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence();
             atomicAdd(arrived, 1u);
-            const uint32_t target = gridDim.x * (pass - first_pass + 1u);
+            const uint32_t target = r.participants * (pass - r.first_pass + 1u);
             uint32_t polls = 0;
             while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (++polls > kSpinLimit) { if (sig.fault) atomicOr(sig.fault, kSortFaultStalled); break; }
+                if (++polls > kSpinLimit) { if (r.fault) atomicOr(r.fault, kSortFaultStalled); break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             __threadfence();
         }
         __syncthreads();
     }
+    if (role == 0u && threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // launch_passes (0 = all `passes`): launches to enqueue; the last of them covers whatever passes remain (k_radix_onesweep,
@@ -468,7 +494,8 @@ k_radix_onesweep_rest(uint64_t* __restrict__ keys0, typename P::T* __restrict__ 
 template <class P>
 inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
                                   uint32_t hist_blocks, uint32_t launch_passes, const void* first_src,
-                                  const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits, FrameLauncher* recorder = nullptr) {
+                                  const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits, FrameLauncher* recorder = nullptr, RadixRest* rest_out = nullptr) {
+    if (rest_out) *rest_out = RadixRest{};
     if (n == 0) return;
     FrameLauncher eager;   // (the launches go through `recorder` when the caller records or replays its chain as a graph: frame_graph.hpp)
     eager.stream = stream;
@@ -485,7 +512,7 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     if (!hist_blocks) hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
     const bool hinted = pass_limit && launch_passes && launch_passes < passes && all_resident;
     // a grid too large to be resident at once: the hinted launches, then one catch-all for whatever the frame needs beyond them
-    const bool with_rest = pass_limit && launch_passes && launch_passes < passes && !all_resident && b.resident != 0u;
+    const bool with_rest = pass_limit && launch_passes && launch_passes < passes && !all_resident && b.resident != 0u && rest_out != nullptr;   // (nobody to take the rest: every pass gets its launch)
     const uint32_t launches = hinted || with_rest ? launch_passes : passes;
     for (uint32_t p = 0; p < launches; p++) {
         const bool to_limit = hinted && p + 1 == launches;
@@ -505,14 +532,15 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         };
         if (digit_bits == uint32_t(kWideBits)) launch(k_radix_onesweep<P, kWideBits>); else launch(k_radix_onesweep<P, kRadixBits>);
     }
-    if (with_rest) {
-        const uint32_t grid = tiles < b.resident ? tiles : b.resident;
-        if (digit_bits == uint32_t(kWideBits))
-            L(k_radix_onesweep_rest<P, kWideBits>, dim3(grid), dim3(kSortThreads), 0, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
-              base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
-        else
-            L(k_radix_onesweep_rest<P, kRadixBits>, dim3(grid), dim3(kSortThreads), 0, b.keys[0], pay[0], b.keys[1], pay[1], n, launches, tiles, b.digit_base,
-              base_stripes, b.tile_status, ticket, pass_limit, first_src, sig);
+    if (with_rest) {   // the caller's next kernel finishes the sort if it has to (radix_rest_points): no launch here
+        if constexpr (std::is_same<P, PointPayload>::value) {
+            if (rest_out) {
+                rest_out->keys[0] = b.keys[0]; rest_out->keys[1] = b.keys[1]; rest_out->points[0] = pay[0]; rest_out->points[1] = pay[1];
+                rest_out->n = n; rest_out->first_pass = launches; rest_out->tiles = tiles; rest_out->base_stripes = base_stripes;
+                rest_out->participants = tiles < b.resident ? tiles : b.resident;
+                rest_out->digit_base = b.digit_base; rest_out->tile_status = b.tile_status; rest_out->tile_ticket = ticket; rest_out->first_src = first_src; rest_out->fault = sig.fault;
+            }
+        }
     }
     if (sig.launches_out) *sig.launches_out = launches;
 }
@@ -521,8 +549,8 @@ inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t p
     radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr, sig);
 }
 inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                      uint32_t hist_blocks, uint32_t launch_passes, const RadixSortSignals& sig, uint32_t digit_bits, FrameLauncher* recorder = nullptr) {
-    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, sig, digit_bits, recorder);
+                                      uint32_t hist_blocks, uint32_t launch_passes, const RadixSortSignals& sig, uint32_t digit_bits, FrameLauncher* recorder, RadixRest* rest_out) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, sig, digit_bits, recorder, rest_out);
 }
 // Workgroups of a pass kernel the device holds at once: the kernel's real occupancy (registers, LDS) x CU count, with a quarter
 // held back (the runtime's answer can exceed what the hardware admits by one per CU -- MI355X_MICROARCH.md, Residency).
