@@ -1121,7 +1121,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
         } else {
             // The chain of preparation kernels, every launch through the slot's FrameLauncher: launched one by one, or -- when the
             // frame has the shape of the one recorded for this slot (same size, digit width, pass count, buffers) -- replayed as a
-            // hipGraph with this frame's arguments (frame_graph.hpp: one submit instead of seven to nine).
+            // hipGraph with this frame's arguments (frame_graph.hpp: one submit instead of six to eight).
             auto chain = [&](FrameLauncher& L) {
                 L(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
                 L(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.digit_base, f.sort.tile_status,

@@ -1,7 +1,7 @@
 // frame_graph.hpp -- one submit for a frame's chain of preparation kernels.
 //
-// An insert enqueues bounds -> keys -> two or three sort passes (-> a catch-all) -> gather -> normals on the frame slot's stream:
-// seven to nine launches at about 3 us of host time each.  The idea: record the chain once per frame slot as a hipGraph -- a linear
+// An insert enqueues bounds -> keys -> two or three sort passes -> gather -> normals on the frame slot's stream:
+// six to eight launches (round 4's measurements below still had the sort's catch-all as a launch of its own) at about 3 us of host time each.  The idea: record the chain once per frame slot as a hipGraph -- a linear
 // chain of kernel nodes -- and replay it with every node's arguments replaced (hipGraphExecKernelNodeSetParams: input pointer,
 // pose, sequence number and table change from frame to frame; grids and kernels do not, as long as the frame size, the sort's digit
 // width and its pass count stay what they were).

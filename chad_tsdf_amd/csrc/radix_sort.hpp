@@ -511,7 +511,7 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     const uint32_t base_stripes = hist_blocks ? kBaseStripes : 1u;
     if (!hist_blocks) hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
     const bool hinted = pass_limit && launch_passes && launch_passes < passes && all_resident;
-    // a grid too large to be resident at once: the hinted launches, then one catch-all for whatever the frame needs beyond them
+    // a grid too large to be resident at once: the hinted launches; whatever the frame needs beyond them is left to the caller's next kernel (RadixRest)
     const bool with_rest = pass_limit && launch_passes && launch_passes < passes && !all_resident && b.resident != 0u && rest_out != nullptr;   // (nobody to take the rest: every pass gets its launch)
     const uint32_t launches = hinted || with_rest ? launch_passes : passes;
     for (uint32_t p = 0; p < launches; p++) {
