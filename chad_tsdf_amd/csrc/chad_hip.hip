@@ -218,8 +218,6 @@ struct chad_map {
     uint32_t closings = 0;                        // roll-overs closed into the DAG so far: closing k's cluster words live in cluster_arenas[k & 1]
                                                   // stream (whose next roll-over must not queue behind a fold of several milliseconds)
     hipEvent_t fold_t0 = nullptr, fold_t1 = nullptr;   // device time of the fold in flight
-    hipEvent_t spare_cleared = nullptr;           // recorded on fold_stream behind the clear of a table that was handed back as the spare
-    bool spare_cleared_pending = false;           // ... the map's stream has not waited for it yet
     int spare_flags = 0;                          // the spare's flag word still holds: 1 = its "exact rows" bit (cleared at a roll-over), 2 = everything (it was
                                                   // the active table when the map was reset); spare_ready() resets it before the table is swapped in
     bool dag_on_host = false;                     // CHAD_DEBUG_DAG_HOST: the sequential host fold of dag.hpp instead (what the tests hold the device fold against)
@@ -561,9 +559,8 @@ chad_status merge_advance(chad_map* m, bool block);   // (below: the multi-GPU f
 chad_status fold_advance(chad_map* m, bool block);    // (with Submap::finalize, further down)
 chad_status fold_archived(chad_map* m);
 chad_status close_into_dag(chad_map* m, uint32_t blocks);
-// the map's stream is about to use the spare table: behind its clear, wherever that ran
+// the map's stream is about to use the spare table (its clear ran on this stream, whichever route closed it)
 inline chad_status spare_ready(chad_map* m, bool at_reset = false) {
-    if (m->spare_cleared_pending) { HIP_TRY(hipStreamWaitEvent(m->stream, m->spare_cleared, 0)); m->spare_cleared_pending = false; }
     // the cleared table's flag word, behind its clear (stream order) and before it takes updates: at a reset everything goes (one
     // memset), at a roll-over the sticky overflow bit stays unless the table was the active one when the map was last reset
     if (at_reset || m->spare_flags == 2) HIP_TRY(hipMemsetAsync(m->spare.overflow, 0, 4, m->stream));
@@ -920,7 +917,6 @@ chad_status grow_if_needed(chad_map* m) {
     TRY(finish_closing(m, true));
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->has_spare) {   // the next roll-over allocates one of the new size
-        if (m->spare_cleared_pending) { HIP_TRY(hipEventSynchronize(m->spare_cleared)); m->spare_cleared_pending = false; }
         free_map_storage(m, m->spare); m->has_spare = false;
     }
     MapView bigger;
@@ -1328,7 +1324,6 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->d_consumed), const_cast<uint32_t*>(m->h_consumed), 0));
     CREATE_TRY(hipEventCreateWithFlags(&m->producer_ready, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->merge_event, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&m->spare_cleared, hipEventDisableTiming));
     CREATE_TRY(hipEventCreate(&m->fold_t0)); CREATE_TRY(hipEventCreate(&m->fold_t1));
     if (m->serial || !(m->flags & CHAD_FLAG_DAG_ONLY)) m->fold_stream = nullptr;   // (only CHAD_FLAG_DAG_ONLY roll-overs use the two streams: a map without the flag does not hold hardware queues for them)
     else if (std::getenv("CHAD_DEBUG_FOLD_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&m->fold_stream, hipStreamNonBlocking));
@@ -1424,7 +1419,6 @@ void chad_map_destroy(chad_map* m) {
     if (m->fold.ready) (void)hipEventDestroy(m->fold.ready);
     if (m->fold_t0) (void)hipEventDestroy(m->fold_t0);
     if (m->fold_t1) (void)hipEventDestroy(m->fold_t1);
-    if (m->spare_cleared) (void)hipEventDestroy(m->spare_cleared);
     if (m->fold_stream) (void)hipStreamDestroy(m->fold_stream);
     if (m->close_stream) (void)hipStreamDestroy(m->close_stream);
     if (m->clusters_ready) (void)hipEventDestroy(m->clusters_ready);
@@ -1991,7 +1985,6 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     enqueue_clear(m->closing_view, m->stream);
     HIP_TRY(hipGetLastError());
     m->spare_flags = std::max(m->spare_flags, 1);
-    m->spare_cleared_pending = false;   // (spare_ready: the map's stream is where the table is swapped in)
     m->spare = m->closing_view; m->has_spare = true;
     m->closing_view = MapView{}; m->closing = false;
     Submap gone;   // a closed submap without bricks: it is its DAG (read back with chad_map_dag_leaves, the iterator, the mesh from the DAG)
