@@ -216,10 +216,11 @@ enum { CHAD_DAG_NODE_LEVELS = 20, CHAD_DAG_CLUSTER_LEVEL = 20 };
 typedef struct chad_dag_stats {
     uint64_t submaps;               /* closed submaps folded into the DAG so far */
     uint32_t uniques[21], dupes[21]; /* NodeLevel::_uniques_n/_dupes_n per level (levels.hpp:88); [20] = leaf clusters (levels.hpp:136) */
-    float ms_device, ms_host;       /* of the last chad_map_finalize that had work: device time (key sort, cluster kernel, the fold of the levels) /
+    float ms_device, ms_host;       /* of the last chad_map_finalize that had work: device time (key sort, cluster kernel, the fold of the levels; under CHAD_FLAG_DAG_ONLY the fold alone) /
                                      * host time (bringing the level arrays over when they are read; the whole fold under CHAD_DEBUG_DAG_HOST) */
-    uint64_t device_bytes;          /* HBM held by the DAG: the levels' stores, their look-up tables, the fold's scratch (the reference keeps its
-                                     * NodeLevels in host memory; here Submap::finalize runs on the device, so the DAG lives there) */
+    uint64_t device_bytes;          /* HBM held by the DAG: the levels' stores, their look-up tables, the fold's scratch, and what a level has outgrown
+                                     * since the last chad_map_sync (freed there: a hipFree waits for the whole device) -- the reference keeps its
+                                     * NodeLevels in host memory; here Submap::finalize runs on the device, so the DAG lives there */
 } chad_dag_stats;
 chad_status chad_map_finalize(chad_map* map);
 /* Submap::root_addr_tsdf / root_addr_weight (submap.hpp:108-109) of closed submap `submap`: addresses into level 0 */
