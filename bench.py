@@ -448,15 +448,20 @@ def main():
         free0 = torch.cuda.mem_get_info()[0]
 
         def run_cfg5(frames_n, dag_only):
-            # the map at the size this trajectory needs (2^22 blocks: no table doubling inside the timed region); its spare table and the
-            # DAG's first allocations are made by the warm-up: multi-GB hipMalloc / hipFree calls take 2 to 200 ms depending on the box
-            m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22, dag_only=dag_only)
-            for k in range(min(12, frames_n)):
+            # The map at the size this trajectory needs (2^22 blocks: no table doubling inside the timed region), and the DAG's memory reserved
+            # up front (chad_options.dag_pool_bytes: the levels' stores and tables grow inside one reservation -- the counterpart of the
+            # reference's VirtualArray, virtual_array.hpp:16-19).  Nothing is allocated inside the timed region: a multi-GB hipMalloc / hipFree
+            # takes 2 to 200+ ms depending on the box, and round 3's leg -- 59 GB of level growth by hipMalloc inside the 5 000 timed frames --
+            # measured 0.29 ms per frame on the builder's boxes and 0.64 on the driver's.  cfg5.alloc below is the proof: calls the library
+            # made between the two clock readings.  The warm-up (three roll-overs) makes the spare table and sizes the grow-only scratch.
+            pool = min(72 << 30, int(torch.cuda.mem_get_info()[0] * 0.45)) if dag_only else 0
+            m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22, dag_only=dag_only, dag_pool_bytes=pool)
+            for k in range(min(36, frames_n)):
                 m5.insert(dev[k][0], dev[k][1], ready=True)
             m5.sync()
             if dag_only:
                 m5.finalize()
-            m5.reset(); m5.sync(); m5.stats()
+            m5.reset(); m5.sync(); m5.stats(); m5.host_times(); m5.pipeline_times()
             t1 = time.perf_counter()
             for k in range(frames_n):
                 m5.insert(dev[k][0], dev[k][1], ready=True)
@@ -468,6 +473,7 @@ def main():
             return m5, t5, t_host
 
         m5, t5, t5_host = run_cfg5(n5, True)
+        h5, p5 = m5.host_times(), m5.pipeline_times()
         s5 = m5.stats()
         ds5 = m5.dag_stats()
         held = free0 - torch.cuda.mem_get_info()[0]
@@ -487,6 +493,23 @@ def main():
                        "hash_load": round(s5["blocks"] / s5["hash_capacity"], 5), "table_bytes": int(s5["hash_capacity"]) * (8 + 512 + 256 + 512) + int(s5["hash_capacity"]) // 8,
                        "hbm_held_bytes": int(held), "dag_device_bytes": int(ds5["device_bytes"]), "dag_unique_clusters": int(ds5["uniques"][20]),
                        "overflow": int(s5["overflow"])}
+        # where the time between the two clock readings went.  Host, microseconds per insert call (disjoint; they add up to the call's
+        # time): the host's own work on the frame (bookkeeping + launches) | waiting for a frame slot (three frames in flight: the
+        # device's pace) | the roll-over's bookkeeping | enqueuing the fold's stages | blocked until a fold in flight had finished.
+        # Device, milliseconds per roll-over: step A (closing table -> keys, order, cluster words), step B (the fold), and what the
+        # eleven frames of a submap take when they run alone (archives_kept leg's frames: filled in below).
+        n_ins = max(1, h5["inserts"])
+        roll_us, fold_us, wait_us = p5["rollover_host_s"] / n_ins * 1e6, p5["fold_host_s"] / n_ins * 1e6, p5["fold_wait_s"] / n_ins * 1e6
+        out["cfg5"]["host_us_per_insert"] = {"total": round(h5["us_per_insert"], 2), "frame_work": round(h5["us_host_work"] - roll_us - fold_us - wait_us, 2),
+                                             "wait_for_frame_slot": round(h5["us_wait"], 2), "rollover_bookkeeping": round(roll_us, 2), "fold_enqueue": round(fold_us, 2),
+                                             "fold_wait": round(wait_us, 2), "calls": h5["inserts"],
+                                             "note": "fold_wait also counts the final sync's wait for the last fold (outside the insert calls)"}
+        out["cfg5"]["host_accounted_frac"] = round(h5["us_per_insert"] * n_ins / 1e6 / t5, 4)   # insert calls' time / the leg's wall time (the rest: the final sync + finalize)
+        folds = max(1, p5["folds_completed"])
+        out["cfg5"]["rollover"] = {"rollovers": p5["rollovers"], "folds_completed": p5["folds_completed"], "step_a_ms": round(p5["step_a_ms"] / folds, 4),
+                                   "step_b_ms": round(p5["step_b_ms"] / folds, 4), "frames_per_rollover": 11}
+        out["cfg5"]["alloc"] = {"mallocs": p5["mallocs"], "frees": p5["frees"], "malloc_bytes": p5["malloc_bytes"], "alloc_ms_in_timed_region": round(p5["alloc_s"] * 1e3, 3),
+                                "level_growths": p5["level_growths"], "dag_pool_bytes": p5["dag_pool_bytes"], "dag_pool_peak": p5["dag_pool_peak"], "dag_pool_used": p5["dag_pool_used"]}
         m5.close()
         # the same frames with the dense archives kept (the library's default; rounds 1-3 quoted this leg): 33 frames, three roll-overs
         mk5, tk, _ = run_cfg5(min(33, n5), False)

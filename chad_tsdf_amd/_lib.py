@@ -40,6 +40,7 @@ class Options(C.Structure):
         ("stream", C.c_void_p),
         ("flags", C.c_uint32),
         ("update_mode", C.c_uint32),
+        ("dag_pool_bytes", C.c_uint64),
     ]
 
 
@@ -82,6 +83,19 @@ class DagStats(C.Structure):
     ]
 
 
+class PipelineTimes(C.Structure):   # chad_pipeline_times
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("rollovers", C.c_uint32), ("folds_completed", C.c_uint32), ("level_growths", C.c_uint32),
+        ("rollover_host_s", C.c_double), ("fold_host_s", C.c_double), ("fold_wait_s", C.c_double),
+        ("step_a_ms", C.c_double), ("step_b_ms", C.c_double),
+        ("mallocs", C.c_uint64), ("frees", C.c_uint64), ("malloc_bytes", C.c_uint64),
+        ("alloc_s", C.c_double),
+        ("dag_pool_bytes", C.c_uint64), ("dag_pool_used", C.c_uint64), ("dag_pool_peak", C.c_uint64),
+        ("exchanges", C.c_uint64), ("exchange_bytes", C.c_uint64), ("exchange_union_blocks", C.c_uint64),
+        ("comm_world", C.c_uint32), ("comm_transport", C.c_uint32),
+    ]
+
+
 class HostTimes(C.Structure):
     _fields_ = [("inserts", C.c_uint64), ("insert_s", C.c_double), ("wait_s", C.c_double), ("copy_s", C.c_double)]
 
@@ -119,6 +133,7 @@ SYMBOLS = {
     "chad_map_dag_level_copy": (_i32, [_vp, C.c_uint32, _vp, _sz]),
     "chad_map_dag_stats": (_i32, [_vp, C.POINTER(DagStats)]),
     "chad_map_host_times": (_i32, [_vp, C.POINTER(HostTimes)]),
+    "chad_map_pipeline_times": (_i32, [_vp, C.POINTER(PipelineTimes)]),
     "chad_map_dag_leaves": (_i32, [_vp, _i32, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_export_clusters": (_i32, [_vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_iter_begin": (_i32, [_vp, _i32, C.POINTER(_vp)]),

@@ -1,0 +1,108 @@
+// alloc.hpp -- every device allocation of the library goes through here: metered (how many hipMalloc / hipFree calls, how many bytes,
+// how long the host sat in them -- chad_map_pipeline_times reports the numbers, so that a measurement can show that its timed region
+// allocated nothing), and, for the DAG's level stores, carved out of ONE up-front reservation (DevPool).
+//
+// Why: a hipMalloc / hipFree of hundreds of MB to several GB costs between 2 and 200+ ms depending on the box (page-table set-up and
+// clearing of VRAM that has not been handed out before; a hipFree also waits for the whole device).  The reference's counterpart is
+// VirtualArray (virtual_array.hpp:12-104): 4 GiB of address space reserved per store, committed on first touch -- storage that grows
+// without ever moving or stalling.  Here: chad_options.dag_pool_bytes reserves the DAG's memory when the map is created, and a level that
+// grows takes its new store from the pool and gives the old one back (stream order makes the hand-over safe: every access to a level
+// is enqueued on the fold's stream, the copy / rehash out of the old store included).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstddef>
+#include <cstdint>
+#include <iterator>
+#include <map>
+
+namespace chadhip {
+
+struct AllocMeter {   // per host thread (a map is driven by one thread at a time: include/chad_hip.h)
+    uint64_t mallocs = 0, frees = 0, bytes = 0;
+    double seconds = 0;
+};
+inline AllocMeter& alloc_meter() {
+    static thread_local AllocMeter m;
+    return m;
+}
+
+template <class T>
+inline hipError_t chad_malloc(T** p, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+    AllocMeter& m = alloc_meter();
+    m.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    m.mallocs++;
+    if (e == hipSuccess) m.bytes += bytes;
+    return e;
+}
+inline hipError_t chad_free(void* p) {
+    if (!p) return hipSuccess;
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipFree(p);
+    AllocMeter& m = alloc_meter();
+    m.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    m.frees++;
+    return e;
+}
+
+// One reservation, handed out in pieces: first fit over a list of free ranges ordered by address, neighbours merged on release.  A few
+// hundred allocations over a map's life (twenty-one levels, each doubling a dozen times): the list stays short.
+struct DevPool {
+    char* base = nullptr;
+    size_t cap = 0, used = 0, peak = 0;
+    std::map<size_t, size_t> free_ranges;   // offset -> length
+    static constexpr size_t kAlign = 4096;
+
+    hipError_t reserve(size_t bytes) {
+        release();
+        if (!bytes) return hipSuccess;
+        bytes = (bytes + kAlign - 1) & ~(kAlign - 1);
+        const hipError_t e = chad_malloc(&base, bytes);
+        if (e != hipSuccess) { base = nullptr; return e; }
+        cap = bytes;
+        free_ranges[0] = bytes;
+        return hipSuccess;
+    }
+    void release() {
+        if (base) (void)chad_free(base);
+        base = nullptr; cap = used = peak = 0;
+        free_ranges.clear();
+    }
+    bool owns(const void* p) const { return base && static_cast<const char*>(p) >= base && static_cast<const char*>(p) < base + cap; }
+    void* take(size_t bytes) {   // nullptr: no range of that length left
+        if (!base) return nullptr;
+        bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) & ~(kAlign - 1);
+        for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it) {
+            if (it->second < bytes) continue;
+            const size_t at = it->first, len = it->second;
+            free_ranges.erase(it);
+            if (len > bytes) free_ranges[at + bytes] = len - bytes;
+            used += bytes; peak = std::max(peak, used);
+            return base + at;
+        }
+        return nullptr;
+    }
+    void give(void* p, size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) & ~(kAlign - 1);
+        size_t at = size_t(static_cast<char*>(p) - base), len = bytes;
+        used -= bytes;
+        auto next = free_ranges.lower_bound(at);
+        if (next != free_ranges.begin()) {
+            auto prev = std::prev(next);
+            if (prev->first + prev->second == at) { at = prev->first; len += prev->second; free_ranges.erase(prev); }
+        }
+        if (next != free_ranges.end() && at + len == next->first) { len += next->second; free_ranges.erase(next); }
+        free_ranges[at] = len;
+    }
+    void reset() {   // everything handed out is dead (the DAG was thrown away)
+        free_ranges.clear();
+        if (base) free_ranges[0] = cap;
+        used = 0;
+    }
+};
+
+}  // namespace chadhip

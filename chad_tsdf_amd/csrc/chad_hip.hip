@@ -16,6 +16,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "alloc.hpp"
 #include "comm.hpp"
 #include "dag.hpp"
 #include "dag_device.hpp"
@@ -69,8 +70,8 @@ struct Submap {  // a closed submap: dense copies of its bricks (stands in for t
 
 struct DevBuf {   // device allocation released on every exit path
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    ~DevBuf() { if (p) (void)chad_free(p); }
+    hipError_t alloc(size_t bytes) { return chad_malloc(&p, bytes ? bytes : 8); }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -80,10 +81,10 @@ struct Arena {   // grow-only device scratch, carved up again for every use (no 
     hipError_t reserve(size_t bytes) {   // previous contents are dead
         used = 0;
         if (bytes <= cap) return hipSuccess;
-        if (base) (void)hipFree(base);
+        if (base) (void)chad_free(base);
         base = nullptr; cap = 0;
         const size_t want = bytes + bytes / 2 + 4096;
-        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), want);
+        const hipError_t e = chad_malloc(reinterpret_cast<void**>(&base), want);
         if (e == hipSuccess) cap = want;
         return e;
     }
@@ -94,7 +95,7 @@ struct Arena {   // grow-only device scratch, carved up again for every use (no 
         return p;
     }
     static size_t padded(size_t bytes) { return ((bytes + 255) & ~size_t(255)) + 256; }
-    void release() { if (base) (void)hipFree(base); base = nullptr; cap = used = 0; }
+    void release() { if (base) (void)chad_free(base); base = nullptr; cap = used = 0; }
 };
 
 enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
@@ -212,12 +213,26 @@ struct chad_map {
     struct PendingFold {                          // a closed submap whose cluster words are made (or on their way, close_stream) and whose fold waits for the one in flight
         bool set = false;
         const uint64_t* keys = nullptr; const uint64_t* tsdf = nullptr; const uint64_t* weight = nullptr; const uint8_t* mask = nullptr;
-        uint32_t blocks = 0;
+        uint32_t blocks = 0, parity = 0;
     } pending;
     hipEvent_t clusters_ready = nullptr;          // behind the pending submap's cluster words on close_stream
     uint32_t closings = 0;                        // roll-overs closed into the DAG so far: closing k's cluster words live in cluster_arenas[k & 1]
                                                   // stream (whose next roll-over must not queue behind a fold of several milliseconds)
-    hipEvent_t fold_t0 = nullptr, fold_t1 = nullptr;   // device time of the fold in flight
+    hipEvent_t fold_t0 = nullptr, fold_t1 = nullptr;   // device time of the fold in flight (step B of a roll-over)
+    hipEvent_t close_t0[2] = {nullptr, nullptr}, close_t1[2] = {nullptr, nullptr};   // ... and of step A (keys, order, cluster words) of closing k, by k & 1
+    uint32_t fold_parity = 0;                     // which of the two the submap being folded is
+    bool dag_broken = false;                      // a fold failed half-way (out of memory for a level's growth ...): the DAG is incomplete until the map is reset
+    // Where a roll-over's time goes (chad_map_pipeline_times; cumulative, restarted by the call): host seconds inside the roll-over's bookkeeping
+    // (close_active / finish_closing / close_into_dag), inside fold_advance (enqueuing a fold's stages), of both the part spent BLOCKED until a fold
+    // in flight had finished; device milliseconds of steps A and B summed over the folds completed; counts.
+    struct PipelineTimes {
+        double rollover_host_s = 0, fold_host_s = 0, fold_wait_s = 0, step_a_ms = 0, step_b_ms = 0;
+        uint32_t rollovers = 0, folds_completed = 0;
+        uint64_t exchange_bytes = 0, exchanges = 0, exchange_union_blocks = 0;   // sharded maps: bytes this rank handed to the collectives of its exchanges / exchanges completed / blocks in the last union
+    } pt;
+    bool in_rollover_span = false;
+    AllocMeter alloc_mark;                        // the calling thread's allocation meter at the last chad_map_pipeline_times
+    uint64_t growths_mark = 0;
     int spare_flags = 0;                          // the spare's flag word still holds: 1 = its "exact rows" bit (cleared at a roll-over), 2 = everything (it was
                                                   // the active table when the map was reset); spare_ready() resets it before the table is swapped in
     bool dag_on_host = false;                     // CHAD_DEBUG_DAG_HOST: the sequential host fold of dag.hpp instead (what the tests hold the device fold against)
@@ -287,6 +302,12 @@ struct chad_map {
 
 namespace {
 
+struct HostSpan {   // host time of a scope into a counter of chad_map::pt
+    double& into; std::chrono::steady_clock::time_point t0;
+    explicit HostSpan(double& counter) : into(counter), t0(std::chrono::steady_clock::now()) {}
+    ~HostSpan() { into += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 struct DeviceGuard {  // entry points run on the map's device and restore the caller's
     int prev = -1;
     bool ok = false;
@@ -307,9 +328,9 @@ inline dim3 grid_for(size_t n, int threads = 256, int max_blocks = 2048) {
 }
 
 void free_sort_buffers(RadixSortBuffers& b) {
-    (void)hipFree(b.keys[0]); (void)hipFree(b.keys[1]); (void)hipFree(b.idx[0]); (void)hipFree(b.idx[1]);
-    (void)hipFree(b.points[0]); (void)hipFree(b.points[1]);
-    (void)hipFree(b.hist_part); (void)hipFree(b.digit_base); (void)hipFree(b.tile_status);
+    (void)chad_free(b.keys[0]); (void)chad_free(b.keys[1]); (void)chad_free(b.idx[0]); (void)chad_free(b.idx[1]);
+    (void)chad_free(b.points[0]); (void)chad_free(b.points[1]);
+    (void)chad_free(b.hist_part); (void)chad_free(b.digit_base); (void)chad_free(b.tile_status);
     const uint32_t resident = b.resident;
     b = RadixSortBuffers{};
     b.resident = resident;
@@ -319,9 +340,9 @@ void free_frame_buffers(FrameSlot& f) {
     f.chain.destroy();   // (its nodes name the buffers)
     if (f.h_stage) (void)hipHostFree(f.h_stage);
     f.h_stage = nullptr;
-    (void)hipFree(f.d_xyz);
+    (void)chad_free(f.d_xyz);
     free_sort_buffers(f.sort);
-    (void)hipFree(f.d_normals); (void)hipFree(f.d_seg);
+    (void)chad_free(f.d_normals); (void)chad_free(f.d_seg);
     f.d_xyz = nullptr; f.d_normals = nullptr; f.d_seg = nullptr;
     f.cap_points = 0;
 }
@@ -379,19 +400,19 @@ chad_status ensure_frame_capacity(chad_map* m, FrameSlot& f, size_t n) {
     size_t cap = std::max<size_t>(n, f.cap_points * 2);
     cap = (cap + kSortTile - 1) / kSortTile * kSortTile;
     free_frame_buffers(f);
-    HIP_TRY(hipMalloc(&f.d_xyz, cap * 12));
+    HIP_TRY(chad_malloc(&f.d_xyz, cap * 12));
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipMalloc(&f.sort.keys[i], cap * 8));
-        HIP_TRY(hipMalloc(&f.sort.points[i], cap * 16));  // the points travel with their keys; the last pass's output is the frame in processing order
+        HIP_TRY(chad_malloc(&f.sort.keys[i], cap * 8));
+        HIP_TRY(chad_malloc(&f.sort.points[i], cap * 16));  // the points travel with their keys; the last pass's output is the frame in processing order
     }
-    HIP_TRY(hipMalloc(&f.sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&f.sort.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadixMax * 4));
-    HIP_TRY(hipMalloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
+    HIP_TRY(chad_malloc(&f.sort.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(chad_malloc(&f.sort.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadixMax * 4));
+    HIP_TRY(chad_malloc(&f.sort.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     f.sort.tiles_capacity = radix_tiles(cap);
-    HIP_TRY(hipMalloc(&f.d_normals, cap * 16));
+    HIP_TRY(chad_malloc(&f.d_normals, cap * 16));
     // point blocks uint2 (start, length | flag) and update work items uint4 (start, length, super-block code), each list in
     // kListStripes stripes of cap / kListStripes + kGatherChunk entries (FrameHeader::list_count)
-    HIP_TRY(hipMalloc(&f.d_seg, (cap + size_t(kListStripes) * kGatherChunk) * 24));
+    HIP_TRY(chad_malloc(&f.d_seg, (cap + size_t(kListStripes) * kGatherChunk) * 24));
     f.cap_points = cap;
     return CHAD_OK;
 }
@@ -414,10 +435,10 @@ chad_status ensure_aux_sort(chad_map* m, size_t n) {
     free_sort_buffers(m->aux_sort);
     m->aux_cap = 0;
     RadixSortBuffers& b = m->aux_sort;
-    for (int i = 0; i < 2; i++) { HIP_TRY(hipMalloc(&b.keys[i], cap * 8)); HIP_TRY(hipMalloc(&b.idx[i], cap * 4)); }
-    HIP_TRY(hipMalloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&b.tile_status, radix_status_words(radix_tiles(cap)) * 4));
+    for (int i = 0; i < 2; i++) { HIP_TRY(chad_malloc(&b.keys[i], cap * 8)); HIP_TRY(chad_malloc(&b.idx[i], cap * 4)); }
+    HIP_TRY(chad_malloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(chad_malloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
+    HIP_TRY(chad_malloc(&b.tile_status, radix_status_words(radix_tiles(cap)) * 4));
     HIP_TRY(hipMemsetAsync(aux_sort_dep(b), 0, kDepWords * 4, m->stream));   // (RadixSortSignals::dep: zero before a sort; the sort leaves it so)
     HIP_TRY(hipStreamSynchronize(m->stream));
     b.tiles_capacity = radix_tiles(cap);
@@ -427,8 +448,8 @@ chad_status ensure_aux_sort(chad_map* m, size_t n) {
 }
 
 void free_map_storage(chad_map* m, MapView& v) {
-    (void)hipFree(v.hash_keys); (void)hipFree(v.live_bits);
-    (void)hipFree(v.brick_sum); (void)hipFree(v.brick_cnt); (void)hipFree(v.brick_pack); (void)hipFree(v.brick_count);
+    (void)chad_free(v.hash_keys); (void)chad_free(v.live_bits);
+    (void)chad_free(v.brick_sum); (void)chad_free(v.brick_cnt); (void)chad_free(v.brick_pack); (void)chad_free(v.brick_count);
     if (v.overflow) m->overflow_words_used &= ~(1u << uint32_t(v.overflow - m->d_overflow));
     v = MapView{};
 }
@@ -444,12 +465,12 @@ chad_status alloc_map_storage(chad_map* m, MapView& v, uint64_t blocks, hipStrea
     m->overflow_words_used |= 1u << word;
     v.overflow = m->d_overflow + word;
     HIP_TRY(hipMemsetAsync(v.overflow, 0, 4, stream));
-    HIP_TRY(hipMalloc(&v.hash_keys, hcap * 8));
-    HIP_TRY(hipMalloc(&v.live_bits, hcap / 8));
-    HIP_TRY(hipMalloc(&v.brick_sum, hcap * 512));   // a brick lives at its hash slot; 64-bit sums (map_kernels.hpp)
-    HIP_TRY(hipMalloc(&v.brick_cnt, hcap * 256));
-    HIP_TRY(hipMalloc(&v.brick_pack, hcap * 512));  // staging words of the scatter form (map_kernels.hpp, kPackCountShift)
-    HIP_TRY(hipMalloc(&v.brick_count, kCountStripes * 64));
+    HIP_TRY(chad_malloc(&v.hash_keys, hcap * 8));
+    HIP_TRY(chad_malloc(&v.live_bits, hcap / 8));
+    HIP_TRY(chad_malloc(&v.brick_sum, hcap * 512));   // a brick lives at its hash slot; 64-bit sums (map_kernels.hpp)
+    HIP_TRY(chad_malloc(&v.brick_cnt, hcap * 256));
+    HIP_TRY(chad_malloc(&v.brick_pack, hcap * 512));  // staging words of the scatter form (map_kernels.hpp, kPackCountShift)
+    HIP_TRY(chad_malloc(&v.brick_count, kCountStripes * 64));
     v.hash_mask = uint32_t(hcap - 1);
     v.brick_capacity = uint32_t(blocks);
     hipLaunchKernelGGL(k_fill_u64, grid_for(hcap), dim3(256), 0, stream, v.hash_keys, size_t(hcap), kEmptyKey);
@@ -503,7 +524,7 @@ chad_status finalize_closed(chad_map* m);  // (further down, with the rest of Su
 chad_status ensure_aux_sort(chad_map* m, size_t n);
 
 void free_submap(Submap& s) {
-    if (!s.borrowed) { (void)hipFree(s.keys); (void)hipFree(s.sum); (void)hipFree(s.cnt); }
+    if (!s.borrowed) { (void)chad_free(s.keys); (void)chad_free(s.sum); (void)chad_free(s.cnt); }
     s = Submap{};
 }
 
@@ -522,9 +543,9 @@ chad_status borrow_submap(chad_map* m, Submap& s, uint32_t blocks) {
 chad_status alloc_submap(Submap& s, uint32_t blocks) {
     s.blocks = blocks;
     const size_t nb = std::max<uint32_t>(blocks, 1);
-    HIP_TRY(hipMalloc(&s.keys, nb * 8));
-    HIP_TRY(hipMalloc(&s.sum, nb * 64 * 4));
-    HIP_TRY(hipMalloc(&s.cnt, nb * 64 * 4));
+    HIP_TRY(chad_malloc(&s.keys, nb * 8));
+    HIP_TRY(chad_malloc(&s.sum, nb * 64 * 4));
+    HIP_TRY(chad_malloc(&s.cnt, nb * 64 * 4));
     return CHAD_OK;
 }
 
@@ -1017,8 +1038,12 @@ chad_status note_pose(chad_map* m, const float position[3]) {
     if (m->positions.empty()) m->positions.push_back(pose);
     else {
         if (rolls_over(m, position)) {
+            HostSpan timed(m->pt.rollover_host_s);
+            m->in_rollover_span = true;
             // every rank of a sharded map sees every pose, so all of them get here for the same frame: the merge is collective
-            TRY(is_sharded(m) ? merge_and_close(m, m->comm) : close_active(m));
+            const chad_status closed = is_sharded(m) ? merge_and_close(m, m->comm) : close_active(m);
+            m->in_rollover_span = false;
+            TRY(closed);
             retire_positions(m);
             m->positions.push_back(pose);
         } else m->positions.push_back(pose);
@@ -1062,7 +1087,13 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
     if (n >= (1ull << 30)) return fail(CHAD_ERR_INVALID_ARG, "more than 2^30 points in one frame");
     g_host_profile.mark(8);
     TRY(note_pose(m, position));
-    TRY(finish_closing(m, false));   // a roll-over's archive, once its size is known (never waits)
+    if (m->closing) {
+        HostSpan timed(m->pt.rollover_host_s);
+        m->in_rollover_span = true;
+        const chad_status advanced = finish_closing(m, false);
+        m->in_rollover_span = false;
+        TRY(advanced);
+    }   // a roll-over's archive, once its size is known (never waits)
     if (fold_busy(m)) TRY(fold_advance(m, false));   // ... and its fold into the DAG, a stage at a time (CHAD_FLAG_DAG_ONLY)
     m->frames_empty_tail = 0;
 
@@ -1269,7 +1300,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     if (const char* e = std::getenv("CHAD_STAGE_DIRECT_KB")) m->stage_direct_from = size_t(std::max(0, std::atoi(e))) << 10;
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
     if (const char* a = std::getenv("CHAD_DEBUG_FOLD_POINTS")) { m->fold_due = uint64_t(std::atoll(a)); m->report_folds = true; }
-    if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)hipMalloc(&m->d_stamps, 8192 * 16 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 16 * 8); }
+    if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)chad_malloc(&m->d_stamps, 8192 * 16 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 16 * 8); }
     auto bail = [&](chad_status s) { chad_map_destroy(m); return s; };
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(e_ == hipErrorOutOfMemory ? CHAD_ERR_OUT_OF_MEMORY : CHAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } } while (0)
@@ -1292,7 +1323,12 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
 
     uint64_t blocks = o.max_blocks ? o.max_blocks : (1ull << 21);
     if (blocks > (1ull << 30)) return bail(fail(CHAD_ERR_INVALID_ARG, "max_blocks above 2^30"));
-    CREATE_TRY(hipMalloc(&m->d_overflow, 64));   // 16 words: [0] sort faults, [1..7] the tables' flags, [8] staging-word launches, [9..15] the tables' clear counters
+    {   // the DAG's memory, reserved up front (alloc.hpp): levels then grow without a hipMalloc; CHAD_DAG_POOL_MB overrides
+        uint64_t pool = o.dag_pool_bytes;
+        if (const char* e = std::getenv("CHAD_DAG_POOL_MB")) pool = uint64_t(std::max(0ll, std::atoll(e))) << 20;
+        if (pool) CREATE_TRY(m->ddag.pool.reserve(pool));
+    }
+    CREATE_TRY(chad_malloc(&m->d_overflow, 64));   // 16 words: [0] sort faults, [1..7] the tables' flags, [8] staging-word launches, [9..15] the tables' clear counters
     CREATE_TRY(hipMemsetAsync(m->d_overflow, 0, 64, m->stream));
     if (alloc_map_storage(m, m->view, blocks, m->stream) != CHAD_OK) return bail(CHAD_ERR_OUT_OF_MEMORY);
     m->brick_capacity = m->view.brick_capacity; m->hash_capacity = m->view.hash_mask + 1;
@@ -1302,9 +1338,9 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         else CREATE_TRY(hipStreamCreateWithFlags(&f.prep, hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&f.update_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&f.stage_done, hipEventDisableTiming));
-        CREATE_TRY(hipMalloc(&f.d_hdr, sizeof(FrameHeader)));
+        CREATE_TRY(chad_malloc(&f.d_hdr, sizeof(FrameHeader)));
         CREATE_TRY(hipMemsetAsync(f.d_hdr, 0, sizeof(FrameHeader), m->stream));
-        CREATE_TRY(hipMalloc(&f.d_part, sizeof(FramePartial) * kFrameBlocks));
+        CREATE_TRY(chad_malloc(&f.d_part, sizeof(FramePartial) * kFrameBlocks));
     }
     CREATE_TRY(hipEventCreateWithFlags(&m->excl_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->closing_counted, hipEventDisableTiming));
@@ -1325,6 +1361,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     CREATE_TRY(hipEventCreateWithFlags(&m->producer_ready, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&m->merge_event, hipEventDisableTiming));
     CREATE_TRY(hipEventCreate(&m->fold_t0)); CREATE_TRY(hipEventCreate(&m->fold_t1));
+    if (m->flags & CHAD_FLAG_DAG_ONLY) for (int k = 0; k < 2; k++) { CREATE_TRY(hipEventCreate(&m->close_t0[k])); CREATE_TRY(hipEventCreate(&m->close_t1[k])); }
     if (m->serial || !(m->flags & CHAD_FLAG_DAG_ONLY)) m->fold_stream = nullptr;   // (only CHAD_FLAG_DAG_ONLY roll-overs use the two streams: a map without the flag does not hold hardware queues for them)
     else if (std::getenv("CHAD_DEBUG_FOLD_NO_PRIORITY")) CREATE_TRY(hipStreamCreateWithFlags(&m->fold_stream, hipStreamNonBlocking));
     else {
@@ -1348,7 +1385,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->aux_sort.resident = m->aux_resident;
     if (std::getenv("CHAD_DEBUG_SORT_TICKETS")) m->sort_resident = 0u;   // experiments: every sort takes tickets
     for (uint32_t k = 0; k < m->n_slots; k++) m->slot[k].sort.resident = m->sort_resident / (m->serial ? 1u : m->n_slots);
-    CREATE_TRY(hipMalloc(&m->d_cursor, 8));   // ([1]: k_table_keys' cursor on close_stream, beside whatever the map's stream compacts)
+    CREATE_TRY(chad_malloc(&m->d_cursor, 8));   // ([1]: k_table_keys' cursor on close_stream, beside whatever the map's stream compacts)
     if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
     if (times_kernels(m))
@@ -1399,11 +1436,11 @@ void chad_map_destroy(chad_map* m) {
             std::fprintf(stderr, "stamps: mean cycles per wave: fetch %.0f walk %.0f readback %.0f hash %.0f flush %.0f life %.0f\n", sum[0] / life.size(), sum[3] / life.size(),
                          sum[6] / life.size(), sum[7] / life.size(), sum[4] / life.size(), sum[5] / life.size());
         }
-        (void)hipFree(m->d_stamps);
+        (void)chad_free(m->d_stamps);
     }
     for (auto& f : m->slot) {
         free_frame_buffers(f);
-        (void)hipFree(f.d_hdr); (void)hipFree(f.d_part);
+        (void)chad_free(f.d_hdr); (void)chad_free(f.d_part);
         if (f.update_done) (void)hipEventDestroy(f.update_done);
         if (f.stage_done) (void)hipEventDestroy(f.stage_done);
         if (f.prep && f.prep != m->stream) (void)hipStreamDestroy(f.prep);
@@ -1415,10 +1452,11 @@ void chad_map_destroy(chad_map* m) {
     m->merge_a.release(); m->merge_b.release(); m->merge_c.release(); m->archive_arena.release(); m->cluster_arena.release(); m->cluster_arenas[0].release(); m->cluster_arenas[1].release();
     if (m->h_consumed) (void)hipHostFree(const_cast<uint32_t*>(m->h_consumed));
     free_sort_buffers(m->aux_sort);
-    m->ddag.release();
+    m->ddag.release(true);
     if (m->fold.ready) (void)hipEventDestroy(m->fold.ready);
     if (m->fold_t0) (void)hipEventDestroy(m->fold_t0);
     if (m->fold_t1) (void)hipEventDestroy(m->fold_t1);
+    for (int k = 0; k < 2; k++) { if (m->close_t0[k]) (void)hipEventDestroy(m->close_t0[k]); if (m->close_t1[k]) (void)hipEventDestroy(m->close_t1[k]); }
     if (m->fold_stream) (void)hipStreamDestroy(m->fold_stream);
     if (m->close_stream) (void)hipStreamDestroy(m->close_stream);
     if (m->clusters_ready) (void)hipEventDestroy(m->clusters_ready);
@@ -1430,7 +1468,7 @@ void chad_map_destroy(chad_map* m) {
     for (auto& s : m->closed) free_submap(s);
     free_submap(m->active_copy);
     free_map_storage(m, m->view);
-    (void)hipFree(m->d_overflow); (void)hipFree(m->d_cursor);
+    (void)chad_free(m->d_overflow); (void)chad_free(m->d_cursor);
     if (m->h_live_blocks) (void)hipHostFree(const_cast<uint32_t*>(m->h_live_blocks));
     if (m->h_hdr) (void)hipHostFree(m->h_hdr);
     for (auto& set : m->ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
@@ -1572,7 +1610,8 @@ chad_status chad_map_reset(chad_map* m) {
     }
     m->overflow_latched = 0;
     m->dag = Dag();
-    m->ddag.release();
+    m->ddag.release();   // (the levels' stores go back to the pool; the reservation itself -- chad_options.dag_pool_bytes -- stays)
+    m->dag_broken = false;
     m->dag_mirror_stale = false;
     m->dag_roots.clear();
     m->dag_generation++;
@@ -1674,6 +1713,27 @@ chad_status chad_map_host_times(chad_map* m, chad_host_times* out) {
     if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     out->inserts = m->host_inserts; out->insert_s = m->host_insert_s; out->wait_s = m->host_wait_s; out->copy_s = m->host_copy_s;
     m->host_inserts = 0; m->host_insert_s = m->host_wait_s = m->host_copy_s = 0;
+    return CHAD_OK;
+}
+
+chad_status chad_map_pipeline_times(chad_map* m, chad_pipeline_times* out) {
+    if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    if (out->struct_size < 2 * sizeof(uint32_t)) return fail(CHAD_ERR_INVALID_ARG, "chad_pipeline_times.struct_size not set");
+    chad_pipeline_times t{};
+    t.struct_size = uint32_t(std::min<size_t>(out->struct_size, sizeof(t)));
+    t.rollovers = m->pt.rollovers; t.folds_completed = m->pt.folds_completed;
+    t.level_growths = uint32_t(m->ddag.growths - m->growths_mark);
+    t.rollover_host_s = m->pt.rollover_host_s; t.fold_host_s = m->pt.fold_host_s; t.fold_wait_s = m->pt.fold_wait_s;
+    t.step_a_ms = m->pt.step_a_ms; t.step_b_ms = m->pt.step_b_ms;
+    const AllocMeter& now = alloc_meter();
+    t.mallocs = now.mallocs - m->alloc_mark.mallocs; t.frees = now.frees - m->alloc_mark.frees; t.malloc_bytes = now.bytes - m->alloc_mark.bytes;
+    t.alloc_s = now.seconds - m->alloc_mark.seconds;
+    t.dag_pool_bytes = m->ddag.pool.cap; t.dag_pool_used = m->ddag.pool.used; t.dag_pool_peak = m->ddag.pool.peak;
+    t.exchanges = m->pt.exchanges; t.exchange_bytes = m->pt.exchange_bytes; t.exchange_union_blocks = m->pt.exchange_union_blocks;
+    if (m->comm) { t.comm_world = uint32_t(m->comm->transport_world()); t.comm_transport = m->comm->nccl ? 1u : 2u; }
+    std::memcpy(out, &t, t.struct_size);
+    m->pt = chad_map::PipelineTimes{};
+    m->alloc_mark = now; m->growths_mark = m->ddag.growths;
     return CHAD_OK;
 }
 
@@ -1912,7 +1972,29 @@ chad_status device_clusters(chad_map* m, const uint64_t* keys, const float* sum,
 // Fold the submaps closed since the last call into the DAG, in closing order (the order the reference finalizes them in).
 // The fold in flight, one stage further if its numbers have arrived (block: wait for them).  When it completes, the submap's roots join
 // dag_roots and the host's mirror of the level arrays is stale.
+// A fold that fails half-way (out of memory for a level that has to grow, a launch error) is ABANDONED: its streams are drained, the
+// fold state torn down and the DAG marked incomplete -- every chad_map_dag_* / iterator / finalize call reports that until
+// chad_map_reset.  Without this the map re-entered the failed stage on every later call and could not even be reset.
+static void fold_abort(chad_map* m) {
+    if (m->fold_stream) (void)hipStreamSynchronize(m->fold_stream);
+    if (m->close_stream) (void)hipStreamSynchronize(m->close_stream);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipGetLastError();
+    m->folding = false; m->pending.set = false; m->fold.stage = 0;
+    m->dag_broken = true;
+}
+static chad_status fold_step(chad_map* m, bool block);
 chad_status fold_advance(chad_map* m, bool block) {
+    if (m->dag_broken) { m->folding = false; m->pending.set = false; return CHAD_OK; }   // (nothing left to drive; the readers report it)
+    const auto t0 = std::chrono::steady_clock::now();
+    const chad_status st = fold_step(m, block);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (block ? m->pt.fold_wait_s : m->pt.fold_host_s) += dt;
+    if (m->in_rollover_span) m->pt.rollover_host_s -= dt;   // (the counters are disjoint: a fold driven from inside a roll-over's bookkeeping counts as fold time)
+    if (st != CHAD_OK) { const std::string why = g_error; fold_abort(m); g_error = "Submap::finalize on the device abandoned, the DAG is incomplete until chad_map_reset: " + why; }
+    return st;
+}
+static chad_status fold_step(chad_map* m, bool block) {
     hipStream_t s = m->fold_stream ? m->fold_stream : m->stream;
     if (m->folding) {
         bool done = false;
@@ -1922,7 +2004,10 @@ chad_status fold_advance(chad_map* m, bool block) {
         if (m->fold.stage == 2 && stage_before == 1) HIP_TRY(hipEventRecord(m->fold_t1, s));   // (behind the last stage's kernels)
         if (!done) return CHAD_OK;
         float t = 0;
-        if (hipEventElapsedTime(&t, m->fold_t0, m->fold_t1) == hipSuccess) m->dag_ms_device = t; else (void)hipGetLastError();
+        (void)hipEventSynchronize(m->fold_t1);   // (recorded right behind the copy whose arrival ended the fold: a marker away)
+        if (hipEventElapsedTime(&t, m->fold_t0, m->fold_t1) == hipSuccess) { m->dag_ms_device = t; m->pt.step_b_ms += t; } else (void)hipGetLastError();
+        if (m->close_t0[m->fold_parity] && hipEventElapsedTime(&t, m->close_t0[m->fold_parity], m->close_t1[m->fold_parity]) == hipSuccess) m->pt.step_a_ms += t; else (void)hipGetLastError();
+        m->pt.folds_completed++;
         m->dag_roots.push_back({root_tsdf, root_weight});
         m->dag_mirror_stale = true;
         m->folding = false;
@@ -1931,6 +2016,7 @@ chad_status fold_advance(chad_map* m, bool block) {
         if (m->close_stream) HIP_TRY(hipStreamWaitEvent(s, m->clusters_ready, 0));
         HIP_TRY(hipEventRecord(m->fold_t0, s));
         HIP_TRY(dag_fold_begin(m->ddag, m->fold, m->pending.keys, m->pending.tsdf, m->pending.weight, m->pending.mask, m->pending.blocks, s));
+        m->fold_parity = m->pending.parity;
         m->pending.set = false;
         m->folding = true;
     }
@@ -1949,14 +2035,22 @@ chad_status fold_advance(chad_map* m, bool block) {
 chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     while (m->pending.set) TRY(fold_advance(m, true));   // (the fold before the waiting one is done: the waiting one begins; the arena of the one before it is free)
     if (m->closed.size() > m->dag_roots.size() + (m->folding ? 1u : 0u)) TRY(fold_archived(m));   // submaps closed by other routes: the DAG takes them in closing order
+    if (m->dag_broken) blocks = 0;   // (an earlier fold failed: the frames go on, the closed submaps are lost until chad_map_reset -- every DAG reader says so)
     hipStream_t s = m->close_stream ? m->close_stream : m->stream;
     const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
     const size_t nb = std::max<uint32_t>(blocks, 1);
     const size_t words = nb * 8;
     const size_t need = Arena::padded(nb * 8) + Arena::padded(nb * 4) + (saturate ? 2 : 1) * Arena::padded(words * 8) + Arena::padded(nb);
-    Arena& arena = m->cluster_arenas[m->closings++ & 1u];   // (its last user was the fold of the roll-over before the one that may be in flight: done)
-    if (need > arena.cap) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipStreamSynchronize(m->stream)); }   // (the arena is about to move)
-    HIP_TRY(arena.reserve(need));
+    // (its last user was the fold of the roll-over before the one that may be in flight: done.  The count moves on only when this closing
+    // is committed -- pending.set below: a step that fails in between leaves the parity where it was, so that the retry takes the SAME
+    // arena and never the one the fold in flight is reading: ADVICE r3)
+    const uint32_t parity = m->closings & 1u;
+    Arena& arena = m->cluster_arenas[parity];
+    if (need > arena.cap) {   // the arena is about to move: nothing may still be reading or writing the old one
+        HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipStreamSynchronize(m->stream));
+        if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));
+    }
+    HIP_TRY(arena.reserve(need));   // (grows with half as much again: the submaps of a trajectory differ by tens of per cent, and a hipMalloc stalls the device)
     uint64_t* keys = arena.take<uint64_t>(nb);
     uint32_t* slots = arena.take<uint32_t>(nb);
     uint64_t* tsdf = arena.take<uint64_t>(words);
@@ -1967,6 +2061,7 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     m->in_fold_setup = false;
     TRY(sorter);
     if (s != m->stream) HIP_TRY(hipStreamWaitEvent(s, m->closing_counted, 0));   // behind the closing table's last update (the count was copied behind them)
+    if (m->close_t0[parity]) HIP_TRY(hipEventRecord(m->close_t0[parity], s));
     if (blocks) {   // the live slots' keys, their order (all eight digits: full 63-bit codes), then the bricks in that order
         RadixSortSignals sig;
         sig.fault = m->d_overflow;
@@ -1979,6 +2074,7 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
                            1.0f / m->trunc /* submap.hpp:23 */, tsdf, weight, mask);
         HIP_TRY(hipGetLastError());
     }
+    if (m->close_t1[parity]) HIP_TRY(hipEventRecord(m->close_t1[parity], s));
     // the table's clear: on the map's stream, behind the kernel that read the bricks; nothing the frames wait for is enqueued there
     // before the next roll-over
     if (s != m->stream) { HIP_TRY(hipEventRecord(m->clusters_ready, s)); HIP_TRY(hipStreamWaitEvent(m->stream, m->clusters_ready, 0)); }
@@ -1990,8 +2086,10 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     Submap gone;   // a closed submap without bricks: it is its DAG (read back with chad_map_dag_leaves, the iterator, the mesh from the DAG)
     gone.blocks = blocks; gone.released = true;
     m->closed.push_back(gone);
-    m->pending.keys = keys; m->pending.tsdf = tsdf; m->pending.weight = weight; m->pending.mask = mask; m->pending.blocks = blocks;
-    m->pending.set = true;
+    m->pending.keys = keys; m->pending.tsdf = tsdf; m->pending.weight = weight; m->pending.mask = mask; m->pending.blocks = blocks; m->pending.parity = parity;
+    m->pending.set = !m->dag_broken;
+    m->closings++;
+    m->pt.rollovers++;
     return fold_advance(m, false);   // (begins the fold at once if none is in flight)
 }
 
@@ -2000,9 +2098,11 @@ chad_status finalize_closed(chad_map* m) {
     TRY(finish_closing(m, true));
     return fold_archived(m);
 }
+static chad_status dag_broken_error() { return fail(CHAD_ERR_HIP, "the DAG is incomplete: a fold into it failed earlier (chad_last_error at that call said why); chad_map_reset starts a new one"); }
 // ... those that were archived as dense copies (the default; the exchange's result; a closing without a spare table), start to finish
 chad_status fold_archived(chad_map* m) {
     while (fold_busy(m)) TRY(fold_advance(m, true));
+    if (m->dag_broken) return dag_broken_error();
     if (m->dag_roots.size() >= m->closed.size()) return CHAD_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));   // (the folds below run on the map's stream: behind whatever a level's growth left on the other one)
@@ -2024,7 +2124,9 @@ chad_status fold_archived(chad_map* m) {
             HIP_TRY(hipEventRecord(ev.e0, m->stream));
             DeviceClusters dc;
             TRY(device_cluster_words(m, s.keys, s.sum, s.cnt, s.blocks, saturate, dc));
-            HIP_TRY(dag_device_add_submap(m->ddag, m->fold, dc.keys, dc.tsdf, saturate ? dc.weight : nullptr, dc.mask, s.blocks, m->stream, &root_tsdf, &root_weight));
+            const hipError_t folded = dag_device_add_submap(m->ddag, m->fold, dc.keys, dc.tsdf, saturate ? dc.weight : nullptr, dc.mask, s.blocks, m->stream, &root_tsdf, &root_weight);
+            if (folded != hipSuccess) fold_abort(m);   // (half a submap's nodes may be in the levels: the DAG is incomplete from here on)
+            HIP_TRY(folded);
             HIP_TRY(hipEventRecord(ev.e1, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
             float t = 0;
@@ -2101,8 +2203,12 @@ chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
         out->uniques[kDagDepth] = m->dag.clusters.uniques; out->dupes[kDagDepth] = m->dag.clusters.dupes;
     }
     out->ms_device = m->dag_ms_device; out->ms_host = m->dag_ms_host;
-    out->device_bytes = m->ddag.arena_cap + m->ddag.outgrown_bytes;
-    for (uint32_t l = 0; l <= kDagDepth && m->ddag.ready; l++) out->device_bytes += size_t(m->ddag.level[l].table_slots) * 4 + size_t(m->ddag.level[l].raw_capacity) * (l == kDagDepth ? 8 : 4);
+    out->device_bytes = m->ddag.arena_cap + m->ddag.outgrown_bytes + m->ddag.pool.cap;   // (the pool's whole reservation, used or not; beside it what did not fit)
+    for (uint32_t l = 0; l <= kDagDepth && m->ddag.ready; l++) {
+        const DagLevelDev& L = m->ddag.level[l];
+        if (!m->ddag.pool.owns(L.table)) out->device_bytes += size_t(L.table_slots) * 4;
+        if (!m->ddag.pool.owns(L.raw)) out->device_bytes += size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4);
+    }
     return CHAD_OK;
 }
 
@@ -2491,12 +2597,12 @@ chad_status chad_map_last_frame(chad_map* m, uint32_t* order, uint64_t* mc, floa
     }
     if (mc) {  // the codes are not kept (the frame kernels work from the sort keys): recompute them from the points
         uint64_t* d_mc = nullptr;
-        HIP_TRY(hipMalloc(&d_mc, k * 8));
+        HIP_TRY(chad_malloc(&d_mc, k * 8));
         hipLaunchKernelGGL(k_morton_codes_of_points, grid_for(k, 256, 1 << 22), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(f.sort.points[(m->h_hdr->sort_passes & 1u) ^ 1u]),
                            uint32_t(k), m->recip, d_mc);
         HIP_TRY(hipMemcpyAsync(mc, d_mc, k * 8, hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
-        (void)hipFree(d_mc);
+        (void)chad_free(d_mc);
     }
     if (normals) {
         HIP_TRY(hipMemcpy(tmp.data(), f.d_normals, k * 16, hipMemcpyDeviceToHost));
@@ -2509,9 +2615,9 @@ chad_status chad_walk_rays(const float* xyz, size_t n, const float position[3], 
     if ((n && (!xyz || !voxels || !counts)) || !position || !stride) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     if (!n) return CHAD_OK;
     float* d_xyz = nullptr; int* d_vox = nullptr; uint32_t* d_cnt = nullptr;
-    HIP_TRY(hipMalloc(&d_xyz, n * 12));
-    HIP_TRY(hipMalloc(&d_vox, n * stride * 12));
-    HIP_TRY(hipMalloc(&d_cnt, n * 4));
+    HIP_TRY(chad_malloc(&d_xyz, n * 12));
+    HIP_TRY(chad_malloc(&d_vox, n * stride * 12));
+    HIP_TRY(chad_malloc(&d_cnt, n * 4));
     HIP_TRY(hipMemcpy(d_xyz, xyz, n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_vox, 0, n * stride * 12));
     const float recip = float(1.0 / double(sdf_res));
@@ -2520,7 +2626,7 @@ chad_status chad_walk_rays(const float* xyz, size_t n, const float position[3], 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(voxels, d_vox, n * stride * 12, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(counts, d_cnt, n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_xyz); (void)hipFree(d_vox); (void)hipFree(d_cnt);
+    (void)chad_free(d_xyz); (void)chad_free(d_vox); (void)chad_free(d_cnt);
     return CHAD_OK;
 }
 
@@ -2531,13 +2637,13 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     RadixSortBuffers b{};
     const uint32_t tiles = radix_tiles(n);
     const size_t cap = size_t(tiles) * kSortTile;
-    for (int i = 0; i < 2; i++) { HIP_TRY(hipMalloc(&b.keys[i], cap * 8)); HIP_TRY(hipMalloc(&b.idx[i], cap * 4)); }
-    HIP_TRY(hipMalloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
-    HIP_TRY(hipMalloc(&b.tile_status, radix_status_words(tiles) * 4));
+    for (int i = 0; i < 2; i++) { HIP_TRY(chad_malloc(&b.keys[i], cap * 8)); HIP_TRY(chad_malloc(&b.idx[i], cap * 4)); }
+    HIP_TRY(chad_malloc(&b.hist_part, size_t(kMaxHistBlocks) * kMaxPasses * kRadix * 4));
+    HIP_TRY(chad_malloc(&b.digit_base, size_t(kBaseStripes) * kMaxPasses * kRadix * 4));
+    HIP_TRY(chad_malloc(&b.tile_status, radix_status_words(tiles) * 4));
     b.resident = std::getenv("CHAD_DEBUG_SORT_TICKETS") ? 0u : radix_resident_workgroups<IndexPayload>();   // nothing else runs beside this sort
     RadixSortSignals sig;
-    HIP_TRY(hipMalloc(&sig.fault, 4));
+    HIP_TRY(chad_malloc(&sig.fault, 4));
     HIP_TRY(hipMemset(sig.fault, 0, 4));
     HIP_TRY(hipMemcpy(b.keys[0], keys, n * 8, hipMemcpyHostToDevice));
     const uint32_t passes = std::max(1u, (key_bits + kRadixBits - 1) / kRadixBits);
@@ -2558,11 +2664,11 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     const int out = passes & 1;
     if (keys_out) HIP_TRY(hipMemcpy(keys_out, b.keys[out], n * 8, hipMemcpyDeviceToHost));
     if (order_out) HIP_TRY(hipMemcpy(order_out, b.idx[out], n * 4, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 2; i++) { (void)hipFree(b.keys[i]); (void)hipFree(b.idx[i]); }
-    (void)hipFree(b.hist_part); (void)hipFree(b.digit_base); (void)hipFree(b.tile_status);
+    for (int i = 0; i < 2; i++) { (void)chad_free(b.keys[i]); (void)chad_free(b.idx[i]); }
+    (void)chad_free(b.hist_part); (void)chad_free(b.digit_base); (void)chad_free(b.tile_status);
     uint32_t fault = 0;
     HIP_TRY(hipMemcpy(&fault, sig.fault, 4, hipMemcpyDeviceToHost));
-    (void)hipFree(sig.fault);
+    (void)chad_free(sig.fault);
     if (fault) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors");
     return CHAD_OK;
 }
@@ -2571,13 +2677,13 @@ chad_status chad_morton_codes(const float* xyz, size_t n, float sdf_res, uint64_
     if (n && (!xyz || !mc)) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     if (!n) return CHAD_OK;
     float* d_xyz = nullptr; uint64_t* d_mc = nullptr;
-    HIP_TRY(hipMalloc(&d_xyz, n * 12));
-    HIP_TRY(hipMalloc(&d_mc, n * 8));
+    HIP_TRY(chad_malloc(&d_xyz, n * 12));
+    HIP_TRY(chad_malloc(&d_mc, n * 8));
     HIP_TRY(hipMemcpy(d_xyz, xyz, n * 12, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_morton_codes, dim3(unsigned((n + 255) / 256)), dim3(256), 0, 0, d_xyz, uint32_t(n), float(1.0 / double(sdf_res)), d_mc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(mc, d_mc, n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d_xyz); (void)hipFree(d_mc);
+    (void)chad_free(d_xyz); (void)chad_free(d_mc);
     return CHAD_OK;
 }
 

@@ -25,6 +25,9 @@ struct RcclApi {
     typedef int (*GetUniqueId)(UniqueId*);
     typedef int (*CommInitRank)(void** comm, int nranks, UniqueId id, int rank);
     typedef int (*CommDestroy)(void* comm);
+    typedef int (*CommCount)(const void* comm, int* count);
+    typedef int (*CommAbort)(void* comm);
+    typedef int (*CommGetAsyncError)(void* comm, int* async_error);
     typedef const char* (*GetErrorString)(int);
     typedef int (*AllReduce)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream);
     typedef int (*AllGather)(const void* send, void* recv, size_t sendcount, int datatype, void* comm, hipStream_t stream);
@@ -33,6 +36,9 @@ struct RcclApi {
     GetUniqueId get_unique_id = nullptr;
     CommInitRank comm_init_rank = nullptr;
     CommDestroy comm_destroy = nullptr;
+    CommCount comm_count = nullptr;             // (optional: what the transport itself says about its size)
+    CommAbort comm_abort = nullptr;             // (optional)
+    CommGetAsyncError comm_async_error = nullptr;   // (optional)
     GetErrorString get_error_string = nullptr;
     AllReduce all_reduce = nullptr;
     AllGather all_gather = nullptr;
@@ -48,6 +54,9 @@ struct RcclApi {
         get_unique_id = reinterpret_cast<GetUniqueId>(dlsym(handle, "ncclGetUniqueId"));
         comm_init_rank = reinterpret_cast<CommInitRank>(dlsym(handle, "ncclCommInitRank"));
         comm_destroy = reinterpret_cast<CommDestroy>(dlsym(handle, "ncclCommDestroy"));
+        comm_count = reinterpret_cast<CommCount>(dlsym(handle, "ncclCommCount"));
+        comm_abort = reinterpret_cast<CommAbort>(dlsym(handle, "ncclCommAbort"));
+        comm_async_error = reinterpret_cast<CommGetAsyncError>(dlsym(handle, "ncclCommGetAsyncError"));
         get_error_string = reinterpret_cast<GetErrorString>(dlsym(handle, "ncclGetErrorString"));
         all_reduce = reinterpret_cast<AllReduce>(dlsym(handle, "ncclAllReduce"));
         all_gather = reinterpret_cast<AllGather>(dlsym(handle, "ncclAllGather"));
@@ -71,6 +80,12 @@ struct chad_comm {
     bool no_shortcut = false;                     // CHAD_DEBUG_COMM_NO_SHORTCUT: a one-rank communicator goes through its transport as well
                                                   // (tests: the RCCL calls themselves on a one-GPU box)
     bool exchanges() const { return world > 1 || no_shortcut; }
+    // the size of the job as the TRANSPORT sees it (RCCL: ncclCommCount; a one-rank communicator that never opened RCCL: 1; callbacks: what the caller said)
+    int32_t transport_world() const {
+        int n = world;
+        if (nccl && chadhip::rccl().comm_count && chadhip::rccl().comm_count(nccl, &n) != 0) n = -1;
+        return n;
+    }
 
     // recv[world * bytes] <- every rank's send[bytes], in rank order.  Device buffers; ordered on `stream`.
     bool all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) {

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "alloc.hpp"
 #include "dag.hpp"
 #include "merge_kernels.hpp"
 
@@ -616,20 +617,50 @@ struct DeviceDag {
     uint32_t* d_hist = nullptr;                // [32]: nodes opened per depth, then two words for the roots
     uint32_t* h_small = nullptr;               // pinned: what a fold reads back in the middle (block totals, level histogram) and at its end (roots, scalars)
     char* arena = nullptr; size_t arena_cap = 0;
-    std::vector<void*> outgrown;               // tables and stores a level has grown out of: freed with the DAG (hipFree waits for the whole device -- the frames in flight too)
+    DevPool pool;                              // chad_options.dag_pool_bytes: the levels' tables and stores are carved out of this reservation (alloc.hpp); what
+                                               // does not fit any more comes from hipMalloc as without a pool
+    std::vector<void*> outgrown;               // tables and stores OUTSIDE the pool that a level has grown out of: freed at the next sync (hipFree waits for the
+                                               // whole device -- the frames in flight too)
     size_t outgrown_bytes = 0;
+    uint64_t growths = 0;                      // tables and stores that have been replaced by bigger ones so far
     bool ready = false;
 
+    // a table or store for a level: from the pool while it lasts
+    hipError_t store_alloc(void** out, size_t bytes) {
+        if (void* p = pool.take(bytes)) { *out = p; return hipSuccess; }
+        return chad_malloc(out, bytes);
+    }
+    // ... given up for a bigger one: a range of the pool is free for the NEXT allocation at once (whoever gets it writes it with work enqueued
+    // behind the copy / rehash that still reads it: every access to a level is enqueued on the fold's stream)
+    void store_retire(void* p, size_t bytes) {
+        if (!p) return;
+        if (pool.owns(p)) pool.give(p, bytes);
+        else { outgrown.push_back(p); outgrown_bytes += bytes; }
+    }
+    void store_free(void* p, size_t bytes) {   // (never used by the device, or the device is idle)
+        if (!p) return;
+        if (pool.owns(p)) pool.give(p, bytes); else (void)chad_free(p);
+    }
     void free_outgrown() {   // (the device is idle: nothing is folding, nothing reads a level)
-        for (void* p : outgrown) (void)hipFree(p);
+        for (void* p : outgrown) (void)chad_free(p);
         outgrown.clear(); outgrown_bytes = 0;
     }
-    void release() {
-        for (auto& l : level) { (void)hipFree(l.table); (void)hipFree(l.raw); l = DagLevelDev{}; }
+    // the DAG thrown away (chad_map_reset): the pool's reservation stays -- a map that is reset and filled again allocates nothing
+    void release(bool pool_too = false) {
+        for (uint32_t l = 0; l <= kDagDepth; l++) {
+            DagLevelDev& L = level[l];
+            store_free(L.table, size_t(L.table_slots) * 4); store_free(L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4));
+            L = DagLevelDev{};
+        }
         free_outgrown();
-        (void)hipFree(d_scalars); (void)hipFree(d_total); (void)hipFree(d_hist); (void)hipFree(arena);
-        if (h_small) (void)hipHostFree(h_small);
-        d_scalars = nullptr; d_total = nullptr; d_hist = nullptr; arena = nullptr; h_small = nullptr; arena_cap = 0; ready = false;
+        pool.reset();
+        if (pool_too) pool.release();
+        if (pool_too) {   // (a reset keeps the fold's scratch and the few scalars: a map that is reset and filled again allocates nothing)
+            (void)chad_free(d_scalars); (void)chad_free(d_total); (void)chad_free(d_hist); (void)chad_free(arena);
+            if (h_small) (void)hipHostFree(h_small);
+            d_scalars = nullptr; d_total = nullptr; d_hist = nullptr; h_small = nullptr; arena = nullptr; arena_cap = 0;
+        }
+        ready = false;
         for (auto& s : h_scalars) s = DagScalars{};
     }
 };
@@ -639,15 +670,15 @@ inline dim3 dag_grid(size_t n, uint32_t per = 256, uint32_t cap = 2048) { return
 inline hipError_t dag_device_init(DeviceDag& d, hipStream_t s) {
     if (d.ready) return hipSuccess;
     hipError_t e;
-    if ((e = hipMalloc(&d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1))) != hipSuccess) return e;
-    if ((e = hipMalloc(&d.d_total, 8 * 64)) != hipSuccess) return e;
-    if ((e = hipMalloc(&d.d_hist, 4 * 32)) != hipSuccess) return e;
-    if ((e = hipHostMalloc(&d.h_small, 4096)) != hipSuccess) return e;
+    if (!d.d_scalars && (e = chad_malloc(&d.d_scalars, sizeof(DagScalars) * (kDagDepth + 1))) != hipSuccess) return e;
+    if (!d.d_total && (e = chad_malloc(&d.d_total, 8 * 64)) != hipSuccess) return e;
+    if (!d.d_hist && (e = chad_malloc(&d.d_hist, 4 * 32)) != hipSuccess) return e;
+    if (!d.h_small && (e = hipHostMalloc(&d.h_small, 4096)) != hipSuccess) return e;
     for (uint32_t l = 0; l <= kDagDepth; l++) {
         DagLevelDev& L = d.level[l];
         L.table_slots = 1u << 19; L.raw_capacity = 1u << 19;   // (2 + 2..4 MB per level: a room-sized submap's 75 k cluster candidates fit without growing anything)
-        if ((e = hipMalloc(&L.table, size_t(L.table_slots) * 4)) != hipSuccess) return e;
-        if ((e = hipMalloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4))) != hipSuccess) return e;
+        if ((e = d.store_alloc(reinterpret_cast<void**>(&L.table), size_t(L.table_slots) * 4)) != hipSuccess) return e;
+        if ((e = d.store_alloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4))) != hipSuccess) return e;
         if ((e = hipMemsetAsync(L.table, 0, size_t(L.table_slots) * 4, s)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(L.raw, 0, l == kDagDepth ? 8 : 4, s)) != hipSuccess) return e;   // address 0: the reserved word (levels.hpp:52, :118)
         d.h_scalars[l] = DagScalars{};
@@ -671,12 +702,13 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
         slots = std::min<size_t>(slots, size_t(1) << 31);
         if (need_slots > (size_t(1) << 31)) return hipErrorOutOfMemory;   // (a table of 2^31 slots: a billion values in one level)
         uint32_t* bigger = nullptr;
-        if ((e = hipMalloc(&bigger, slots * 4)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(bigger, 0, slots * 4, s)) != hipSuccess) { (void)hipFree(bigger); return e; }
+        if ((e = d.store_alloc(reinterpret_cast<void**>(&bigger), slots * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(bigger, 0, slots * 4, s)) != hipSuccess) { d.store_free(bigger, slots * 4); return e; }
         if (cluster) hipLaunchKernelGGL(k_dag_rehash<false>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
         else hipLaunchKernelGGL(k_dag_rehash<true>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
         // (no wait, no hipFree: what follows on this stream comes behind the rehash, and nothing else reads a level while a fold is in flight)
-        d.outgrown.push_back(L.table); d.outgrown_bytes += size_t(L.table_slots) * 4;
+        d.store_retire(L.table, size_t(L.table_slots) * 4);
+        d.growths++;
         L.table = bigger; L.table_slots = uint32_t(slots);
     }
     const size_t need_words = size_t(d.h_scalars[l].size) + n * words_each + 16;
@@ -687,9 +719,10 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
         words = std::min<size_t>(words, (size_t(1) << 32) - 1 - n);
         const size_t unit = cluster ? 8 : 4;
         void* bigger = nullptr;
-        if ((e = hipMalloc(&bigger, words * unit)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(bigger, L.raw, size_t(d.h_scalars[l].size) * unit, hipMemcpyDeviceToDevice, s)) != hipSuccess) { (void)hipFree(bigger); return e; }
-        d.outgrown.push_back(L.raw); d.outgrown_bytes += size_t(L.raw_capacity) * unit;
+        if ((e = d.store_alloc(&bigger, words * unit)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(bigger, L.raw, size_t(d.h_scalars[l].size) * unit, hipMemcpyDeviceToDevice, s)) != hipSuccess) { d.store_free(bigger, words * unit); return e; }
+        d.store_retire(L.raw, size_t(L.raw_capacity) * unit);
+        d.growths++;
         L.raw = bigger; L.raw_capacity = uint32_t(words);
     }
     return hipSuccess;
@@ -726,9 +759,9 @@ inline hipError_t dag_fold_begin(DeviceDag& d, DagFold& f, const uint64_t* keys,
                         padded(std::max<size_t>(cc_ub, 2 * nbp)) + 2 * (padded(nbp * 8) + padded(nbp * 64) + 2 * padded(nbp * 8) + padded((nbp + 1) * 4));
     if (need > d.arena_cap) {
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-        (void)hipFree(d.arena); d.arena = nullptr; d.arena_cap = 0;
-        if ((e = hipMalloc(&d.arena, need + need / 4)) != hipSuccess) return e;
-        d.arena_cap = need + need / 4;
+        (void)chad_free(d.arena); d.arena = nullptr; d.arena_cap = 0;
+        if ((e = chad_malloc(&d.arena, need + need / 2)) != hipSuccess) return e;   // (grow-only, with room: submaps of a trajectory differ by tens of per cent)
+        d.arena_cap = need + need / 2;
     }
     size_t used = 0;
     auto take = [&](size_t bytes) { void* p = d.arena + used; used += padded(bytes); return p; };

@@ -22,7 +22,8 @@ def _np_f32(a, shape_last=3):
 class TSDFMap:
     def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, device: int = -1, max_blocks: int = 0,
                  max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, time_update: bool = False, fixed_capacity: bool = False, update_mode: int = 0,
-                 dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False, mesh_from_dag: bool = False, space_carving: bool = False):
+                 dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False, mesh_from_dag: bool = False, space_carving: bool = False,
+                 dag_pool_bytes: int = 0):
         self._lib = _lib.load()
         self._sdf_res = float(sdf_res)
         self._sdf_trunc = float(sdf_trunc)
@@ -34,6 +35,7 @@ class TSDFMap:
         opt.stream = stream or None
         opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.FLAG_MESH_FROM_DAG if mesh_from_dag else 0) | (_lib.FLAG_SPACE_CARVING if space_carving else 0)
         opt.update_mode = update_mode
+        opt.dag_pool_bytes = dag_pool_bytes
         handle = C.c_void_p()
         _lib.check(self._lib.chad_map_create(sdf_res, sdf_trunc, C.byref(opt), C.byref(handle)), "TSDFMap")
         self._h = handle
@@ -192,6 +194,13 @@ class TSDFMap:
         n = max(1, int(t.inserts))
         return {"inserts": int(t.inserts), "us_per_insert": t.insert_s / n * 1e6, "us_wait": t.wait_s / n * 1e6, "us_copy": t.copy_s / n * 1e6,
                 "us_host_work": (t.insert_s - t.wait_s - t.copy_s) / n * 1e6}
+
+    def pipeline_times(self) -> dict:
+        """Where the roll-overs' time went and what was allocated since the last call (chad_pipeline_times; the counters restart)."""
+        t = _lib.PipelineTimes()
+        t.struct_size = C.sizeof(_lib.PipelineTimes)
+        _lib.check(self._lib.chad_map_pipeline_times(self._h, C.byref(t)), "TSDFMap.pipeline_times")
+        return {name: getattr(t, name) for name, _ in _lib.PipelineTimes._fields_ if name != "struct_size"}
 
     def kernel_times(self) -> dict:
         """Mean duration (ms) and launch count of every kernel of the insert pipeline since the last call (time_kernels=True)."""

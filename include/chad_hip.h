@@ -45,6 +45,12 @@ typedef struct chad_options {
                             streams owned by the map (three in flight) */
     uint32_t flags;      /* CHAD_FLAG_* */
     uint32_t update_mode; /* CHAD_UPDATE_* */
+    uint64_t dag_pool_bytes; /* HBM reserved when the map is created for the DAG of closed submaps (NodeLevels, levels.hpp:141-199): the
+                            levels' stores and look-up tables are carved out of it and grow inside it, so that a long trajectory under
+                            CHAD_FLAG_DAG_ONLY never calls hipMalloc / hipFree while it runs (each a device-wide stall of 2-200 ms per GB,
+                            box dependent).  The counterpart of VirtualArray's up-front reservation (virtual_array.hpp:16-19).  0 = none:
+                            levels grow by hipMalloc.  When the pool is used up, growth falls back to hipMalloc (chad_pipeline_times
+                            shows it).  chad_map_reset keeps the reservation.  Environment override: CHAD_DAG_POOL_MB */
 } chad_options;
 
 enum {
@@ -153,6 +159,29 @@ chad_status chad_map_kernel_times(chad_map* map, chad_kernel_times* out);
 typedef struct chad_host_times { uint64_t inserts; double insert_s, wait_s, copy_s; } chad_host_times;
 chad_status chad_map_host_times(chad_map* map, chad_host_times* out);
 const char* chad_kernel_name(int32_t id);
+/* Where a roll-over's time goes, and whether anything was allocated (measurement; the reference's counterpart is
+ * the wall-clock timer around insert, tsdf.cpp:41,72-74, which includes Submap::finalize at a roll-over, tsdf.cpp:53).  Counters since
+ * the previous call (they restart); set struct_size = sizeof(chad_pipeline_times) before the call -- the library fills no more than that.
+ *   host side   rollover_host_s: inside the roll-over's bookkeeping (table swap, sizing, enqueuing step A; includes any wait for the
+ *               roll-over before it); fold_host_s: enqueuing the stages of Submap::finalize on the device (about fifty launches per
+ *               submap); fold_wait_s: BLOCKED until a fold in flight had finished (two submaps on their way, or a sync / export)
+ *   device side step_a_ms: closing table -> block keys, their order, cluster words (summed over the folds completed); step_b_ms: the fold
+ *               of those words into the DAG's levels.  A runs beside the B of the roll-over before it, both beside the frames
+ *   allocation  hipMalloc / hipFree calls the library made on the CALLING THREAD, their bytes and host seconds; level_growths: DAG
+ *               stores or tables replaced by bigger ones; dag_pool_*: chad_options.dag_pool_bytes, in use now, most in use so far
+ *   exchange    sharded maps: exchanges completed, bytes this rank handed to their collectives (send side), blocks in the last union */
+typedef struct chad_pipeline_times {
+    uint32_t struct_size;
+    uint32_t rollovers, folds_completed, level_growths;
+    double rollover_host_s, fold_host_s, fold_wait_s;
+    double step_a_ms, step_b_ms;
+    uint64_t mallocs, frees, malloc_bytes;
+    double alloc_s;
+    uint64_t dag_pool_bytes, dag_pool_used, dag_pool_peak;
+    uint64_t exchanges, exchange_bytes, exchange_union_blocks;
+    uint32_t comm_world, comm_transport; /* ranks of the attached communicator as the TRANSPORT reports them (ncclCommCount for RCCL; 0 = none attached) / 1 RCCL, 2 callbacks */
+} chad_pipeline_times;
+chad_status chad_map_pipeline_times(chad_map* map, chad_pipeline_times* out);
 
 /* Multi-GPU merge support: per-block partial sums of a submap, on the DEVICE, sorted by block key
  * (key = MortonCode & ~63, the reference's lookup key, octree.hpp:33-36).  sum[b*64+v] is the sum of

@@ -142,12 +142,14 @@ def test_dag_only_roll_over_with_small_frame_capacity(chad, oracle):
     m.close()
 
 
-def test_cfg3_full_stream(chad):
+def test_cfg3_full_stream(chad, oracle):
     """BASELINE config 3 at its stated size: 500 frames x 200 k points, sensor advancing 0.05 m per frame.  Device-resident,
     enqueued back to back (three frames in flight, roll-overs asynchronous).  Checked: roll-overs when frames 101 / 202 / 303 /
     404 arrive (tsdf.cpp:52, SURVEY.md 8(d)); every submap bit-identical to the same stream inserted one frame at a time;
     per submap, sum of weights == sum of the frames' update counts; hash load <= 0.5; the active submap after frames 0..99 is
-    the reference's (V = 737 935, sum of weights 135 382 309)."""
+    the reference's (V = 737 935, sum of weights 135 382 309); and submap 0 -- frames 0..100, 101 accumulated
+    frames, weights up to ~1 700 -- against the ORACLE's octree of the same frames at the full size: leaf set and weights exact,
+    signed distances within 1e-4 (octree.hpp:153-164; no widening for the running mean's drift)."""
     import torch
 
     n_frames = 500
@@ -176,6 +178,16 @@ def test_cfg3_full_stream(chad):
         assert int(leaves[2].sum(dtype=np.uint64)) == sum(updates[bounds[s]:bounds[s + 1]]), f"submap {s}"
         assert np.isfinite(leaves[1]).all() and np.abs(leaves[1]).max() <= 0.10 * (1 + 1e-5)
     serial.close()
+    # submap 0 at its full size against the oracle (the reference's running-mean leaves after 101 frames)
+    o = oracle.OracleMap(0.05, 0.10)
+    for k in range(closed_at[0]):
+        o.insert(*frames[k])
+    assert o.closed_submaps == 0
+    want0 = o.export_leaves(-1)
+    assert int(want0[2].max()) > 1000, "the accumulation this test is about did not happen"
+    worst = assert_leaves_match(per_submap[0], want0, 0.10)
+    print(f"cfg3 submap 0 against the oracle: {len(want0[0])} leaves, max weight {int(want0[2].max())}, worst sd error {worst:.2e} of the bound's scale")
+    del o
     # the way a stream is inserted: no synchronisation at all
     m = chad.TSDFMap(0.05, 0.10)
     for (_, pos), d in zip(frames, dev):
