@@ -10,9 +10,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -20,6 +24,7 @@
 #include "comm.hpp"
 #include "dag.hpp"
 #include "dag_device.hpp"
+#include "exchange_kernels.hpp"
 #include "frame_graph.hpp"
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
@@ -278,6 +283,23 @@ struct chad_map {
     Arena archive_arena;                          // CHAD_FLAG_DAG_ONLY: the closing submap's dense copy, from its roll-over to its fold (borrow_submap)
     Arena cluster_arena;                          // the cluster words of the submap being folded (device_cluster_words)
     Arena cluster_arenas[2];                      // ... under CHAD_FLAG_DAG_ONLY: of the submap being folded and of the one waiting behind it
+    // The SPARSE exchange (exchange_kernels.hpp; sharded maps under CHAD_FLAG_DAG_ONLY): what exists travels, ownership is by Morton key range,
+    // every rank turns its range into cluster words and rank 0 folds the submap -- once.  Five stages (sparse_stages), polled like the dense ones.
+    static constexpr uint32_t kMergeHostWords = 4096;   // merge_host: [0, 1024) heads of all ranks | [1024, 1040) splitters | [1056, 1568) the G x G matrix | [1600, 1616) union sizes | [1632] this rank's
+    bool closing_sparse = false;
+    bool dag_remote = false;                      // this rank's closed submaps were folded on rank 0: it holds no DAG of its own
+    struct SparseExchange {
+        uint32_t nb = 0, wide = 0, n_union = 0, recv_blocks = 0;
+        uint64_t* keys_sorted = nullptr; uint32_t* slot_sorted = nullptr; uint64_t* mask = nullptr; uint32_t* prefix = nullptr; uint32_t* first_block = nullptr;
+        uint32_t* chunk_sums = nullptr; uint32_t* d_words = nullptr;
+        uint64_t* d_small = nullptr;              // head | all heads | splitters | row | matrix | union size | all union sizes (device side of merge_host's words)
+        char* send = nullptr; char* recv = nullptr;
+        uint64_t* sorted = nullptr; uint32_t* heads = nullptr; uint32_t* d_union_n = nullptr;
+        uint64_t blocks_from[16] = {}, words_from[16] = {};   // what every rank sends to THIS rank
+        uint32_t wide_of[16] = {};
+        size_t recv_off[16] = {};
+        char* out = nullptr; size_t out_bytes = 0;   // this range's result: keys | tsdf words | (weight words) | masks, contiguous
+    } sx;
     uint32_t merge_blocks = 0;                    // this rank's blocks
     uint64_t* merge_keys = nullptr; long long* merge_sum = nullptr; uint32_t* merge_cnt = nullptr;   // ... compacted raw (arena a)
     uint64_t merge_total = 0;                     // blocks over all ranks
@@ -680,6 +702,10 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
     HIP_TRY(hipMemcpyAsync(m->closing_count + kCountStripes * 16, m->view.overflow, 4, hipMemcpyDeviceToHost, m->stream));   // ... and whether it overflowed (final: its updates are done)
     HIP_TRY(hipEventRecord(m->closing_counted, m->stream));
     m->closing_view = m->view; m->closing = true; m->closing_comm = c; m->merge_stage = 0;
+    // a sharded map that keeps closed submaps as their DAG only exchanges what exists and folds once, on rank 0 (sparse_stages); one that
+    // keeps the archives reduces dense bricks so that every rank ends up with the merged submap (merge_stages)
+    static const bool dense_always = std::getenv("CHAD_DEBUG_DENSE_EXCHANGE") != nullptr;
+    m->closing_sparse = (m->flags & CHAD_FLAG_DAG_ONLY) && !m->dag_on_host && !dense_always;
     m->view = m->spare; m->spare = MapView{}; m->has_spare = false;
     *m->h_live_blocks = 0;
     staging_restart(m);
@@ -693,6 +719,8 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
 // watchdog, NCCL_TIMEOUT, ends that wait); a failed exchange is fatal for the sharded map as a whole.
 static void merge_abort(chad_map* m) {
     if (!m->closing) return;
+    if (chad_comm* c = m->closing_comm) c->abort();   // (RCCL: a collective stuck on the stream is killed with its communicator; the communicator is dead from here on)
+    m->closing_sparse = false;
     enqueue_clear(m->closing_view, m->stream);
     (void)hipGetLastError();
     m->spare_flags = std::max(m->spare_flags, 1);
@@ -703,9 +731,33 @@ static void merge_abort(chad_map* m) {
     m->closing_view = MapView{}; m->closing = false; m->closing_comm = nullptr; m->merge_stage = 0;
 }
 
+// Look at / wait for an event of the exchange.  A wait is bounded (CHAD_COMM_TIMEOUT_S, default 120 s, 0 = for ever): a peer that never
+// issues its collective -- it crashed, it took another branch -- must end in an error on this rank, not in a hang (the stage is then
+// abandoned: merge_abort, which also tears the RCCL communicator down so that the stuck collective leaves the stream).
+static double comm_timeout_s() {
+    static const double limit = std::getenv("CHAD_COMM_TIMEOUT_S") ? std::atof(std::getenv("CHAD_COMM_TIMEOUT_S")) : 120.0;
+    return limit;
+}
+static chad_status comm_wait(chad_map* m, hipEvent_t ev, bool block) {
+    (void)m;
+    if (!block) return CHAD_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t polls = 0;; polls++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return CHAD_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorNotReady) HIP_TRY(e);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (comm_timeout_s() > 0 && waited > comm_timeout_s())
+            return fail(CHAD_ERR_HIP, "a stage of the exchange did not complete within " + std::to_string(int(comm_timeout_s())) + " s (a peer that never issued its collective?)");
+        if (polls > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
 static chad_status merge_stages(chad_map* m, bool block);
+static chad_status sparse_stages(chad_map* m, bool block);
 chad_status merge_advance(chad_map* m, bool block) {
-    const chad_status s = merge_stages(m, block);
+    const chad_status s = m->closing_sparse ? sparse_stages(m, block) : merge_stages(m, block);
     if (s != CHAD_OK) { const std::string why = g_error; merge_abort(m); g_error = "multi-GPU exchange abandoned on this rank: " + why; }
     return s;
 }
@@ -716,8 +768,8 @@ static chad_status merge_stages(chad_map* m, bool block) {
     const uint32_t world = uint32_t(c->world);
     for (;;) {
         hipEvent_t pending = m->merge_stage == 0 ? m->closing_counted : m->merge_event;
-        if (block) HIP_TRY(hipEventSynchronize(pending));
-        else if (hipEventQuery(pending) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
+        TRY(comm_wait(m, pending, block));
+        if (hipEventQuery(pending) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
         if (m->merge_stage == 0) {
             uint32_t nb = 0;
             for (uint32_t k = 0; k < kCountStripes; k++) nb += m->closing_count[k * 16];
@@ -761,6 +813,7 @@ static chad_status merge_stages(chad_map* m, bool block) {
                 hipLaunchKernelGGL(k_fill_u64, grid_for(longest), dim3(256), 0, s, send, size_t(longest), kEmptyKey);
                 if (m->merge_blocks) HIP_TRY(hipMemcpyAsync(send, m->merge_keys, size_t(m->merge_blocks) * 8, hipMemcpyDeviceToDevice, s));
                 COMM_TRY(c->all_gather(send, recv, longest * 8, s));
+                m->pt.exchange_bytes += longest * 8;
                 TRY(ensure_aux_sort(m, total));
                 hipLaunchKernelGGL(k_concat_keys, grid_for(longest), dim3(256), 0, s, recv, uint32_t(longest), rc, world, m->aux_sort.keys[0]);
                 RadixSortSignals sig;
@@ -793,6 +846,7 @@ static chad_status merge_stages(chad_map* m, bool block) {
                 HIP_TRY(hipGetLastError());
                 COMM_TRY(c->all_reduce(dense_sum, cells, CHAD_REDUCE_I64, s));
                 COMM_TRY(c->all_reduce(dense_cnt, cells, CHAD_REDUCE_U32, s));
+                m->pt.exchange_bytes += cells * 12; m->pt.exchange_union_blocks = n_union;
                 // the archive's format, converted exactly as the single-GPU archive converts (k_compact_bricks)
                 hipLaunchKernelGGL(k_dense_to_archive, grid_for(cells), dim3(256), 0, s, dense_sum, dense_cnt, cells, m->trunc, arch.sum, arch.cnt);
             }
@@ -802,7 +856,283 @@ static chad_status merge_stages(chad_map* m, bool block) {
             m->closed.push_back(arch);
             m->spare = m->closing_view; m->has_spare = true;   // usable behind the clear: whoever swaps it in does so on this stream
             m->closing_view = MapView{}; m->closing = false; m->closing_comm = nullptr; m->merge_stage = 0;
+            m->pt.exchanges++;
             return release_finalized(m);
+        }
+    }
+}
+#undef COMM_TRY
+
+
+// ---- the sparse exchange (exchange_kernels.hpp): frame-sharded maps that keep closed submaps as their DAG only -----------------------
+// Stages, each enqueued on the map's stream when the previous one's numbers have reached the host (polled by every insert, waited
+// for by whatever needs the closed submap):
+//   0 -> 1  (local block count known)  the closing table's keys in Morton order; all-gather of every rank's count + 64 sample keys
+//   1 -> 2  (all heads known)          splitters (the same on every rank); this rank's blocks per range; their voxel masks and the
+//                                      payload's layout; all-gather of the G x G matrix "blocks and words from rank a for rank b"
+//   2 -> 3  (matrix known)             the slices packed; point-to-point exchange; sorted union of the keys this rank received
+//   3 -> 4  (union size known)         the slices added into dense accumulators over the union; cluster words of the range;
+//                                      all-gather of the ranges' sizes
+//   4 -> done (sizes known)            the ranges' cluster words to rank 0, which concatenates them -- Morton order -- and folds the
+//                                      submap into its DAG (beside the next frames, like a single GPU's roll-over); the closing
+//                                      table is cleared and becomes the spare.  The other ranks hold no DAG (dag_remote).
+#define COMM_TRY(expr) do { if (!(expr)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: " + c->error); } while (0)
+static chad_status sparse_stages(chad_map* m, bool block) {
+    chad_comm* c = m->closing_comm;
+    hipStream_t s = m->stream;
+    const uint32_t world = uint32_t(c->world), me = uint32_t(c->rank);
+    chad_map::SparseExchange& x = m->sx;
+    uint64_t* H = m->merge_host;
+    constexpr uint32_t kHead = kXSamples + 1, kHSplit = 1024, kHMatrix = 1056, kHAllU = 1600, kHUnion = 1640;
+    const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
+    for (;;) {
+        hipEvent_t pending = m->merge_stage == 0 ? m->closing_counted : m->merge_event;
+        TRY(comm_wait(m, pending, block));
+        if (hipEventQuery(pending) != hipSuccess) { (void)hipGetLastError(); return CHAD_OK; }
+        // device side of the small words (stage 0 makes them): head | all heads | splitters | row | matrix | my union size | all union sizes
+        uint64_t* d_head = x.d_small; uint64_t* d_all_heads = d_head + kHead; uint64_t* d_split = d_all_heads + kHead * 16; uint64_t* d_row = d_split + 16;
+        uint64_t* d_matrix = d_row + 32; uint64_t* d_u = d_matrix + 512; uint64_t* d_all_u = d_u + 2;
+        if (m->merge_stage == 0) {
+            uint32_t nb = 0;
+            for (uint32_t k = 0; k < kCountStripes; k++) nb += m->closing_count[k * 16];
+            const uint32_t flags = m->closing_count[kCountStripes * 16];
+            m->overflow_latched |= flags & kTableOverflowed;
+            x = chad_map::SparseExchange{};
+            x.nb = nb; x.wide = (flags & kTableExactRows) ? 1u : 0u;
+            const uint32_t chunks = (nb + kUniqueChunk - 1) / kUniqueChunk;
+            const size_t nbp = size_t(nb) + 1;
+            HIP_TRY(m->merge_a.reserve(Arena::padded(nbp * 8) + 3 * Arena::padded(nbp * 4) + Arena::padded(nbp * 8) + Arena::padded(17 * 4) + Arena::padded((size_t(chunks) + 1) * 4) + Arena::padded(4) + Arena::padded(2048 * 8)));
+            x.keys_sorted = m->merge_a.take<uint64_t>(nbp);
+            uint32_t* slots = m->merge_a.take<uint32_t>(nbp);
+            x.slot_sorted = m->merge_a.take<uint32_t>(nbp);
+            x.prefix = m->merge_a.take<uint32_t>(nbp);
+            x.mask = m->merge_a.take<uint64_t>(nbp);
+            x.first_block = m->merge_a.take<uint32_t>(17);
+            x.chunk_sums = m->merge_a.take<uint32_t>(size_t(chunks) + 1);
+            x.d_words = m->merge_a.take<uint32_t>(1);
+            x.d_small = m->merge_a.take<uint64_t>(2048);
+            d_head = x.d_small; d_all_heads = d_head + kHead;
+            if (nb) {   // this rank's live slots in key order (close_into_dag's step A, first half)
+                m->in_fold_setup = true;   // (nothing sorts on another stream in this mode: no need to wait for a fold in flight)
+                const chad_status sorter = ensure_aux_sort(m, nb);
+                m->in_fold_setup = false;
+                TRY(sorter);
+                RadixSortSignals sig;
+                sig.fault = m->d_overflow;
+                sig.dep = aux_sort_dep(m->aux_sort);
+                HIP_TRY(hipMemsetAsync(m->d_cursor + 1, 0, 4, s));
+                hipLaunchKernelGGL(k_table_keys, dim3(std::max(1u, std::min(2048u, ((m->closing_view.hash_mask >> 5) + 256u) / 256u))), dim3(256), 0, s, m->closing_view, m->d_cursor + 1, nb, m->aux_sort.keys[0], slots);
+                radix_sort_enqueue(m->aux_sort, nb, kMaxPasses, nullptr, s, 0, 0, sig);
+                HIP_TRY(hipMemcpyAsync(x.keys_sorted, m->aux_sort.keys[0], size_t(nb) * 8, hipMemcpyDeviceToDevice, s));
+                hipLaunchKernelGGL(k_xchg_order, grid_for(nb), dim3(256), 0, s, (const uint32_t*)m->aux_sort.idx[0], (const uint32_t*)slots, nb, x.slot_sorted);   // (the sorter is free again behind this)
+            }
+            hipLaunchKernelGGL(k_xchg_head, dim3(1), dim3(128), 0, s, (const uint64_t*)x.keys_sorted, nb, x.wide, d_head);
+            HIP_TRY(hipGetLastError());
+            COMM_TRY(c->all_gather(d_head, d_all_heads, kHead * 8, s));
+            m->pt.exchange_bytes += kHead * 8;
+            HIP_TRY(hipMemcpyAsync(H, d_all_heads, size_t(kHead) * 8 * world, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(m->merge_event, s));
+            m->merge_stage = 1;
+        } else if (m->merge_stage == 1) {
+            // the splitters: weighted quantiles of all ranks' samples (a sample of rank r stands for nb_r / 65 of its blocks) -- plain
+            // deterministic host arithmetic on words every rank holds alike
+            std::vector<std::pair<uint64_t, double>> samples;
+            double total = 0;
+            for (uint32_t r = 0; r < world; r++) {
+                const uint64_t head = H[size_t(r) * kHead];
+                const uint32_t n_r = uint32_t(head);
+                if (n_r >= (1u << 30)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible block count from a rank");
+                x.wide_of[r] = uint32_t(head >> 32) & 1u;
+                if (!n_r) continue;
+                for (uint32_t i = 0; i < kXSamples; i++) samples.emplace_back(H[size_t(r) * kHead + 1 + i], double(n_r) / double(kXSamples + 1));
+                total += double(n_r) * double(kXSamples) / double(kXSamples + 1);
+            }
+            std::stable_sort(samples.begin(), samples.end(), [](const std::pair<uint64_t, double>& a, const std::pair<uint64_t, double>& b) { return a.first < b.first; });
+            {
+                double cum = 0; size_t at = 0;
+                for (uint32_t j = 1; j < world; j++) {
+                    const double target = total * double(j) / double(world);
+                    while (at < samples.size() && cum + samples[at].second < target) cum += samples[at++].second;
+                    H[kHSplit + j - 1] = at < samples.size() ? samples[at].first : ~0ull;
+                }
+            }
+            if (world > 1) HIP_TRY(hipMemcpyAsync(d_split, &H[kHSplit], size_t(world - 1) * 8, hipMemcpyHostToDevice, s));
+            const uint32_t nb = x.nb, chunks = (nb + kUniqueChunk - 1) / kUniqueChunk;
+            hipLaunchKernelGGL(k_xchg_ranges, dim3(1), dim3(64), 0, s, (const uint64_t*)x.keys_sorted, nb, (const uint64_t*)d_split, world, x.first_block);
+            if (nb) {
+                hipLaunchKernelGGL(k_xchg_masks, grid_for(size_t(nb) * 16, 256, 4096), dim3(256), 0, s, m->closing_view, (const uint32_t*)x.slot_sorted, nb, x.mask);
+                hipLaunchKernelGGL(k_xchg_chunk_sums, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, (const uint64_t*)x.mask, nb, x.chunk_sums);
+                hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, s, x.chunk_sums, chunks, x.d_words);
+            }
+            hipLaunchKernelGGL(k_xchg_prefix, dim3(std::max(1u, std::min(chunks, 2048u))), dim3(256), 0, s, (const uint64_t*)x.mask, nb, (const uint32_t*)x.chunk_sums, (const uint32_t*)x.d_words, x.prefix);
+            hipLaunchKernelGGL(k_xchg_row, dim3(1), dim3(64), 0, s, (const uint32_t*)x.first_block, (const uint32_t*)x.prefix, world, d_row);
+            HIP_TRY(hipGetLastError());
+            COMM_TRY(c->all_gather(d_row, d_matrix, size_t(world) * 16, s));
+            m->pt.exchange_bytes += size_t(world) * 16;
+            HIP_TRY(hipMemcpyAsync(&H[kHMatrix], d_matrix, size_t(world) * world * 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(m->merge_event, s));
+            m->merge_stage = 2;
+        } else if (m->merge_stage == 2) {
+            auto blocks_of = [&](uint32_t from, uint32_t to) { return H[kHMatrix + (size_t(from) * world + to) * 2]; };
+            auto words_of = [&](uint32_t from, uint32_t to) { return H[kHMatrix + (size_t(from) * world + to) * 2 + 1]; };
+            auto slice = [&](uint32_t from, uint32_t to) { return xchg_slice_bytes(blocks_of(from, to), words_of(from, to), x.wide_of[from] ? 2u : 1u); };
+            ExchangePlan plan;
+            XchgSlices slices{};
+            size_t send_total = 0, recv_total = 0, mine_check = 0;
+            uint64_t recv_blocks = 0;
+            for (uint32_t r = 0; r < world; r++) {
+                if (blocks_of(r, me) >= (1ull << 30) || words_of(r, me) > blocks_of(r, me) * 64) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible slice size from a rank");
+                plan.send_off[r] = send_total; plan.send_bytes[r] = slice(me, r); slices.off[r] = send_total; send_total += plan.send_bytes[r];
+                plan.recv_off[r] = recv_total; plan.recv_bytes[r] = slice(r, me); x.recv_off[r] = recv_total; recv_total += plan.recv_bytes[r];
+                x.blocks_from[r] = blocks_of(r, me); x.words_from[r] = words_of(r, me); recv_blocks += x.blocks_from[r];
+                mine_check += blocks_of(me, r);
+                size_t before = 0, whole = 0;
+                for (uint32_t d = 0; d < world; d++) { if (d < me) before += slice(r, d); whole += slice(r, d); }
+                plan.peer_off[r] = before; plan.longest_send = std::max(plan.longest_send, whole);
+            }
+            if (mine_check != x.nb) return fail(CHAD_ERR_HIP, "multi-GPU exchange: this rank's ranges do not add up to its blocks");
+            if (recv_blocks >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks in one rank's range");
+            x.recv_blocks = uint32_t(recv_blocks);
+            const uint32_t chunks = uint32_t((recv_blocks + kUniqueChunk - 1) / kUniqueChunk);
+            HIP_TRY(m->merge_b.reserve(Arena::padded(send_total) + Arena::padded(recv_total) + Arena::padded((recv_blocks + 1) * 8) + Arena::padded((size_t(chunks) + 1) * 4) + Arena::padded(4)));
+            x.send = m->merge_b.take<char>(send_total + 8);
+            x.recv = m->merge_b.take<char>(recv_total + 8);
+            x.sorted = m->merge_b.take<uint64_t>(recv_blocks + 1);
+            x.heads = m->merge_b.take<uint32_t>(size_t(chunks) + 1);
+            x.d_union_n = m->merge_b.take<uint32_t>(1);
+            if (x.nb) hipLaunchKernelGGL(k_xchg_pack, grid_for(size_t(x.nb) * 64, 256, 4096), dim3(256), 0, s, m->closing_view, (const uint32_t*)x.slot_sorted, (const uint64_t*)x.keys_sorted, (const uint64_t*)x.mask,
+                                         (const uint32_t*)x.prefix, (const uint32_t*)x.first_block, x.nb, world, x.wide, x.send, slices);
+            HIP_TRY(hipGetLastError());
+            COMM_TRY(c->exchange_slices(x.send, x.recv, plan, s));
+            m->pt.exchange_bytes += plan.bytes_out(int(me), int(world));
+            if (recv_blocks) {   // sorted union of the keys this rank received (its own slice among them)
+                m->in_fold_setup = true;
+                const chad_status sorter = ensure_aux_sort(m, recv_blocks);
+                m->in_fold_setup = false;
+                TRY(sorter);
+                size_t at = 0;
+                for (uint32_t r = 0; r < world; r++) {
+                    if (x.blocks_from[r]) HIP_TRY(hipMemcpyAsync(m->aux_sort.keys[0] + at, x.recv + x.recv_off[r], size_t(x.blocks_from[r]) * 8, hipMemcpyDeviceToDevice, s));
+                    at += x.blocks_from[r];
+                }
+                RadixSortSignals sig;
+                sig.fault = m->d_overflow;
+                radix_sort_enqueue(m->aux_sort, uint32_t(recv_blocks), kMaxPasses, nullptr, s, 0, 0, sig);
+                HIP_TRY(hipMemcpyAsync(x.sorted, m->aux_sort.keys[0], size_t(recv_blocks) * 8, hipMemcpyDeviceToDevice, s));
+                hipLaunchKernelGGL(k_unique_count, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, (const uint64_t*)x.sorted, uint32_t(recv_blocks), x.heads);
+                hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, s, x.heads, chunks, x.d_union_n);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(&H[kHUnion], x.d_union_n, 4, hipMemcpyDeviceToHost, s));
+            }
+            HIP_TRY(hipEventRecord(m->merge_event, s));
+            m->merge_stage = 3;
+        } else if (m->merge_stage == 3) {
+            const uint32_t n_union = x.recv_blocks ? uint32_t(H[kHUnion] & 0xffffffffull) : 0u;
+            if (n_union > x.recv_blocks) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible union size");
+            x.n_union = n_union;
+            const size_t cells = size_t(n_union) * 64, nu = size_t(n_union) + 1;
+            const uint32_t uchunks = (n_union + kUniqueChunk - 1) / kUniqueChunk;
+            x.out_bytes = xchg_range_bytes(n_union, size_t(n_union) * 8, saturate);   // (room for the worst case; what travels is sized by the words that exist)
+            HIP_TRY(m->merge_c.reserve(Arena::padded(x.out_bytes + 8) + Arena::padded(cells * 8 + 8) + Arena::padded(cells * 4 + 8) + (saturate ? 2 : 1) * Arena::padded(nu * 64) + Arena::padded(nu) +
+                                       Arena::padded(nu * 8) + Arena::padded(nu * 4) + Arena::padded((size_t(uchunks) + 1) * 4) + Arena::padded(4)));
+            x.out = m->merge_c.take<char>(x.out_bytes + 8);
+            long long* acc_sum = m->merge_c.take<long long>(cells + 1);
+            uint32_t* acc_cnt = m->merge_c.take<uint32_t>(cells + 1);
+            uint64_t* rows_tsdf = m->merge_c.take<uint64_t>(nu * 8);
+            uint64_t* rows_weight = saturate ? m->merge_c.take<uint64_t>(nu * 8) : nullptr;
+            uint8_t* rows_mask = m->merge_c.take<uint8_t>(nu);
+            uint64_t* mask64 = m->merge_c.take<uint64_t>(nu);
+            uint32_t* first = m->merge_c.take<uint32_t>(nu);
+            uint32_t* usums = m->merge_c.take<uint32_t>(size_t(uchunks) + 1);
+            uint32_t* d_total = m->merge_c.take<uint32_t>(1);
+            uint64_t* out_keys = reinterpret_cast<uint64_t*>(x.out);
+            if (n_union) {
+                const uint32_t chunks = (x.recv_blocks + kUniqueChunk - 1) / kUniqueChunk;
+                hipLaunchKernelGGL(k_unique_write, dim3(std::min(chunks, 2048u)), dim3(256), 0, s, (const uint64_t*)x.sorted, x.recv_blocks, (const uint32_t*)x.heads, out_keys);
+                HIP_TRY(hipMemsetAsync(acc_sum, 0, cells * 8, s));
+                HIP_TRY(hipMemsetAsync(acc_cnt, 0, cells * 4, s));
+                for (uint32_t r = 0; r < world; r++)   // one source after the other: plain adds, exact in any order
+                    if (x.blocks_from[r]) hipLaunchKernelGGL(k_xchg_accumulate, grid_for(size_t(x.blocks_from[r]) * 64, 256, 4096), dim3(256), 0, s, (const char*)(x.recv + x.recv_off[r]), uint32_t(x.blocks_from[r]),
+                                                             x.wide_of[r], (const uint64_t*)out_keys, n_union, acc_sum, acc_cnt);
+                hipLaunchKernelGGL(k_xchg_clusters, grid_for(cells, 256, 4096), dim3(256), 0, s, (const long long*)acc_sum, (const uint32_t*)acc_cnt, n_union, m->trunc, 1.0f / m->trunc /* submap.hpp:23 */,
+                                   rows_tsdf, rows_weight, rows_mask);
+                // only the octets that hold leaves travel: their places by a scan of the masks' bit counts
+                hipLaunchKernelGGL(k_xchg_widen, grid_for(n_union), dim3(256), 0, s, (const uint8_t*)rows_mask, n_union, mask64);
+                hipLaunchKernelGGL(k_xchg_chunk_sums, dim3(std::min(uchunks, 2048u)), dim3(256), 0, s, (const uint64_t*)mask64, n_union, usums);
+                hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, s, usums, uchunks, d_total);
+            }
+            hipLaunchKernelGGL(k_xchg_prefix, dim3(std::max(1u, std::min(uchunks, 2048u))), dim3(256), 0, s, (const uint64_t*)mask64, n_union, (const uint32_t*)usums, (const uint32_t*)d_total, first);
+            hipLaunchKernelGGL(k_xchg_compact_rows, grid_for(std::max<size_t>(cells / 8, 1), 256, 4096), dim3(256), 0, s, (const uint64_t*)rows_tsdf, (const uint64_t*)rows_weight, (const uint8_t*)rows_mask,
+                               (const uint32_t*)first, n_union, x.out, d_u);
+            HIP_TRY(hipGetLastError());
+            COMM_TRY(c->all_gather(d_u, d_all_u, 16, s));
+            m->pt.exchange_bytes += 16;
+            HIP_TRY(hipMemcpyAsync(&H[kHAllU], d_all_u, size_t(world) * 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(m->merge_event, s));
+            m->merge_stage = 4;
+        } else {
+            // the ranges to rank 0, which holds the DAG
+            ExchangePlan plan;
+            uint64_t total_blocks = 0;
+            size_t recv_total = 0;
+            for (uint32_t r = 0; r < world; r++) {
+                const uint64_t u = H[kHAllU + 2 * r], w = H[kHAllU + 2 * r + 1];
+                if (u >= (1ull << 30) || w > u * 8) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible range size from a rank");
+                total_blocks += u;
+                if (me == 0) { plan.recv_off[r] = recv_total; plan.recv_bytes[r] = xchg_range_bytes(u, w, saturate); recv_total += plan.recv_bytes[r]; }
+                plan.longest_send = std::max(plan.longest_send, xchg_range_bytes(u, w, saturate));
+            }
+            if (total_blocks >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks in one submap");
+            if (H[kHAllU + 2 * me] != x.n_union) return fail(CHAD_ERR_HIP, "multi-GPU exchange: this rank's range size came back changed");
+            const size_t my_bytes = xchg_range_bytes(x.n_union, H[kHAllU + 2 * me + 1], saturate);
+            plan.send_bytes[0] = my_bytes;   // (everything goes to rank 0; a peer's slice for rank 0 starts at the beginning of its buffer: peer_off = 0)
+            if (me == 0) {
+                while (m->pending.set) TRY(fold_advance(m, true));   // (at most one submap waits while another is folded: close_into_dag's rule)
+                const size_t nb = std::max<uint64_t>(total_blocks, 1), words = nb * 8;
+                const size_t need = Arena::padded(nb * 8) + (saturate ? 2 : 1) * Arena::padded(words * 8) + Arena::padded(nb);
+                const uint32_t parity = m->closings & 1u;
+                Arena& arena = m->cluster_arenas[parity];
+                if (need > arena.cap) { HIP_TRY(hipStreamSynchronize(s)); if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream)); }
+                HIP_TRY(arena.reserve(need));
+                uint64_t* keys = arena.take<uint64_t>(nb);
+                uint64_t* tsdf = arena.take<uint64_t>(words);
+                uint64_t* weight = saturate ? arena.take<uint64_t>(words) : nullptr;
+                uint8_t* mask = arena.take<uint8_t>(nb);
+                HIP_TRY(m->merge_b.reserve(Arena::padded(recv_total + 8)));   // (the slices of stage 2 are dead: stage 3's kernels have run)
+                char* staging = m->merge_b.take<char>(recv_total + 8);
+                if (m->close_t0[parity]) HIP_TRY(hipEventRecord(m->close_t0[parity], s));
+                COMM_TRY(c->exchange_slices(x.out, staging, plan, s));
+                size_t at = 0;
+                for (uint32_t r = 0; r < world; r++) {   // ranges in rank order = ascending Morton order
+                    const uint64_t u = H[kHAllU + 2 * r], w = H[kHAllU + 2 * r + 1];
+                    if (!u) continue;
+                    const char* from = staging + plan.recv_off[r];
+                    HIP_TRY(hipMemcpyAsync(keys + at, from, u * 8, hipMemcpyDeviceToDevice, s));
+                    hipLaunchKernelGGL(k_xchg_expand_rows, grid_for(u * 8, 256, 4096), dim3(256), 0, s, from, uint32_t(u), uint32_t(w), saturate ? 1u : 0u, tsdf + at * 8, saturate ? weight + at * 8 : nullptr, mask + at);
+                    at += u;
+                }
+                HIP_TRY(hipGetLastError());
+                if (m->close_t1[parity]) HIP_TRY(hipEventRecord(m->close_t1[parity], s));
+                HIP_TRY(hipEventRecord(m->clusters_ready, s));
+                m->pending.keys = keys; m->pending.tsdf = tsdf; m->pending.weight = weight; m->pending.mask = mask; m->pending.blocks = uint32_t(total_blocks); m->pending.parity = parity;
+                m->pending.set = !m->dag_broken;
+                m->closings++;
+            } else {
+                COMM_TRY(c->exchange_slices(x.out, nullptr, plan, s));
+                m->pt.exchange_bytes += my_bytes;
+                m->dag_roots.push_back({0u, 0u});   // (a place holder: the submap's roots are rank 0's to know)
+                m->dag_remote = true;
+            }
+            enqueue_clear(m->closing_view, s);
+            HIP_TRY(hipGetLastError());
+            m->spare_flags = std::max(m->spare_flags, 1);
+            m->spare = m->closing_view; m->has_spare = true;
+            m->closing_view = MapView{}; m->closing = false; m->closing_comm = nullptr; m->closing_sparse = false; m->merge_stage = 0;
+            Submap gone;   // a closed submap without bricks: it is its DAG (on rank 0)
+            gone.blocks = uint32_t(total_blocks); gone.released = true;
+            m->closed.push_back(gone);
+            m->pt.exchanges++; m->pt.exchange_union_blocks = total_blocks; m->pt.rollovers++;
+            return me == 0 ? fold_advance(m, false) : CHAD_OK;
         }
     }
 }
@@ -1378,7 +1708,7 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
         CREATE_TRY(hipStreamCreateWithPriority(&m->close_stream, hipStreamNonBlocking, std::getenv("CHAD_DEBUG_FOLD_NO_PRIORITY") ? least : greatest));
     }
     CREATE_TRY(hipEventCreateWithFlags(&m->clusters_ready, hipEventDisableTiming));
-    CREATE_TRY(hipHostMalloc(&m->merge_host, 32 * 8));
+    CREATE_TRY(hipHostMalloc(&m->merge_host, chad_map::kMergeHostWords * 8));
     // what the look-back sort may assume about residency: the pass kernel's real occupancy, shared among the frames in flight
     m->sort_resident = radix_resident_workgroups<PointPayload>();
     m->aux_resident = radix_resident_workgroups<IndexPayload>() / (m->serial ? 1u : m->n_slots + 1u);
@@ -1611,7 +1941,7 @@ chad_status chad_map_reset(chad_map* m) {
     m->overflow_latched = 0;
     m->dag = Dag();
     m->ddag.release();   // (the levels' stores go back to the pool; the reservation itself -- chad_options.dag_pool_bytes -- stays)
-    m->dag_broken = false;
+    m->dag_broken = false; m->dag_remote = false;
     m->dag_mirror_stale = false;
     m->dag_roots.clear();
     m->dag_generation++;
@@ -1867,8 +2197,28 @@ chad_status chad_comm_create_rccl(const uint8_t id[CHAD_COMM_ID_BYTES], int32_t 
         if (!err.empty()) { delete c; return fail(CHAD_ERR_HIP, err); }
         RcclApi::UniqueId uid;
         std::memcpy(&uid, id, CHAD_COMM_ID_BYTES);
-        const int r = rccl().comm_init_rank(&c->nccl, world, uid, rank);   // collective: returns once every rank has joined
-        if (r) { delete c; return fail(CHAD_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().get_error_string(r)); }
+        // ncclCommInitRank is collective: it returns once every rank has joined -- or never, when one does not.  It runs on a helper thread
+        // that this call waits for with a limit (CHAD_COMM_TIMEOUT_S, default 120 s): a job whose ranks do not all arrive ends in an error
+        // message here instead of a hang (the helper thread is then left behind; the process is expected to give up).
+        struct Init { std::mutex mu; std::condition_variable cv; bool done = false; int result = 0; void* comm = nullptr; };
+        auto st = std::make_shared<Init>();
+        const int device = c->device;
+        std::thread([st, uid, world, rank, device]() {
+            (void)hipSetDevice(device);
+            void* comm = nullptr;
+            const int r = rccl().comm_init_rank(&comm, world, uid, rank);
+            std::lock_guard<std::mutex> lock(st->mu);
+            st->result = r; st->comm = comm; st->done = true;
+            st->cv.notify_all();
+        }).detach();
+        {
+            std::unique_lock<std::mutex> lock(st->mu);
+            const bool arrived = comm_timeout_s() > 0 ? st->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return st->done; }) : (st->cv.wait(lock, [&] { return st->done; }), true);
+            if (!arrived) { delete c; return fail(CHAD_ERR_HIP, "ncclCommInitRank did not return within " + std::to_string(int(comm_timeout_s())) + " s: not every rank of the job has joined (rank " + std::to_string(rank) + " of " + std::to_string(world) + ")"); }
+            if (st->result) { delete c; return fail(CHAD_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().get_error_string(st->result)); }
+            c->nccl = st->comm;
+        }
+        if (c->transport_world() != world) { const int seen = c->transport_world(); chad_comm_destroy(c); return fail(CHAD_ERR_HIP, "RCCL reports " + std::to_string(seen) + " ranks, the caller said " + std::to_string(world)); }
     }
     *out = c;
     return CHAD_OK;
@@ -2098,6 +2448,7 @@ chad_status finalize_closed(chad_map* m) {
     TRY(finish_closing(m, true));
     return fold_archived(m);
 }
+static chad_status dag_remote_error() { return fail(CHAD_ERR_INVALID_ARG, "this rank holds no DAG: the closed submaps of a frame-sharded map under CHAD_FLAG_DAG_ONLY are folded on rank 0 (read them back there)"); }
 static chad_status dag_broken_error() { return fail(CHAD_ERR_HIP, "the DAG is incomplete: a fold into it failed earlier (chad_last_error at that call said why); chad_map_reset starts a new one"); }
 // ... those that were archived as dense copies (the default; the exchange's result; a closing without a spare table), start to finish
 chad_status fold_archived(chad_map* m) {
@@ -2163,6 +2514,7 @@ chad_status chad_map_dag_roots(chad_map* m, int32_t submap, uint32_t* root_tsdf,
     if (!m || !root_tsdf || !root_weight) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
     TRY(finalize_closed(m));
+    if (m->dag_remote) return dag_remote_error();
     if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
     *root_tsdf = m->dag_roots[size_t(submap)][0]; *root_weight = m->dag_roots[size_t(submap)][1];
     return CHAD_OK;
@@ -2173,6 +2525,7 @@ chad_status chad_map_dag_level_words(chad_map* m, uint32_t level, size_t* words)
     if (level > CHAD_DAG_CLUSTER_LEVEL) return fail(CHAD_ERR_INVALID_ARG, "level out of range");
     DeviceGuard guard(m->device);
     TRY(finalize_closed(m));
+    if (m->dag_remote) return dag_remote_error();
     if (!m->dag_on_host && m->ddag.ready) { *words = m->ddag.h_scalars[level].size; return CHAD_OK; }   // (no need to bring the words over to count them)
     *words = level < kDagDepth ? m->dag.nodes[level].raw.size() : m->dag.clusters.raw.size();
     return CHAD_OK;
@@ -2216,6 +2569,7 @@ chad_status chad_map_dag_leaves(chad_map* m, int32_t submap, uint64_t* mc, float
     if (!m || !count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
     TRY(finalize_closed(m));
+    if (m->dag_remote) return dag_remote_error();
     if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
     TRY(dag_host(m));
     size_t k = 0;
@@ -2272,6 +2626,7 @@ chad_status chad_map_iter_begin(chad_map* m, int32_t submap, chad_iter** out) {
     *out = nullptr;
     DeviceGuard guard(m->device);
     TRY(finalize_closed(m));
+    if (m->dag_remote) return dag_remote_error();
     // tsdf.cpp:106-110: "chad::TSDFMap::begin() given faulty root address"
     if (submap < 0 || size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range (only closed submaps are in the DAG)");
     TRY(dag_host(m));
@@ -2453,6 +2808,7 @@ chad_status mesh_source(chad_map* m, int32_t submap, DevBuf& keys_sorted, DevBuf
     if (from_dag) {
         // what the reference meshes (lvr2.cpp:30-90): the leaves read back through the DAG, signed distances de-quantised from 8 bits
         TRY(finalize_closed(m));
+        if (m->dag_remote) return dag_remote_error();
         if (size_t(submap) >= m->dag_roots.size()) return fail(CHAD_ERR_INVALID_ARG, "submap index out of range");
         TRY(dag_host(m));
         std::vector<uint64_t> keys;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -31,7 +32,10 @@ struct RcclApi {
     typedef const char* (*GetErrorString)(int);
     typedef int (*AllReduce)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream);
     typedef int (*AllGather)(const void* send, void* recv, size_t sendcount, int datatype, void* comm, hipStream_t stream);
-    enum { kUint32 = 3, kInt64 = 4, kUint64 = 5, kSum = 0 };   // ncclDataType_t / ncclRedOp_t values (rccl.h:448-472)
+    typedef int (*Send)(const void* send, size_t count, int datatype, int peer, void* comm, hipStream_t stream);
+    typedef int (*Recv)(void* recv, size_t count, int datatype, int peer, void* comm, hipStream_t stream);
+    typedef int (*GroupCall)(void);
+    enum { kInt8 = 0, kUint32 = 3, kInt64 = 4, kUint64 = 5, kSum = 0 };   // ncclDataType_t / ncclRedOp_t values (rccl.h:448-472)
     void* handle = nullptr;
     GetUniqueId get_unique_id = nullptr;
     CommInitRank comm_init_rank = nullptr;
@@ -42,6 +46,8 @@ struct RcclApi {
     GetErrorString get_error_string = nullptr;
     AllReduce all_reduce = nullptr;
     AllGather all_gather = nullptr;
+    Send send = nullptr; Recv recv = nullptr;   // (optional: the sparse exchange's point-to-point step; without them it reports an error)
+    GroupCall group_start = nullptr, group_end = nullptr;
 
     // empty string on success
     std::string load() {
@@ -60,6 +66,10 @@ struct RcclApi {
         get_error_string = reinterpret_cast<GetErrorString>(dlsym(handle, "ncclGetErrorString"));
         all_reduce = reinterpret_cast<AllReduce>(dlsym(handle, "ncclAllReduce"));
         all_gather = reinterpret_cast<AllGather>(dlsym(handle, "ncclAllGather"));
+        send = reinterpret_cast<Send>(dlsym(handle, "ncclSend"));
+        recv = reinterpret_cast<Recv>(dlsym(handle, "ncclRecv"));
+        group_start = reinterpret_cast<GroupCall>(dlsym(handle, "ncclGroupStart"));
+        group_end = reinterpret_cast<GroupCall>(dlsym(handle, "ncclGroupEnd"));
         if (!get_unique_id || !comm_init_rank || !comm_destroy || !get_error_string || !all_reduce || !all_gather) { handle = nullptr; return "librccl.so.1 lacks an expected symbol"; }
         return "";
     }
@@ -67,6 +77,16 @@ struct RcclApi {
 inline RcclApi& rccl() { static RcclApi api; return api; }
 
 }  // namespace chadhip
+
+// Who sends what to whom in one point-to-point step (chad_comm::exchange_slices): byte ranges of this rank's send and receive buffers
+// per peer -- and, for the callback transport, where this rank's slice lies in every PEER's send buffer and how long the longest send
+// buffer of the job is (that transport gathers whole send buffers: a rehearsal path, not the product's).
+struct ExchangePlan {
+    static constexpr int kMax = 16;
+    size_t send_off[kMax] = {}, send_bytes[kMax] = {}, recv_off[kMax] = {}, recv_bytes[kMax] = {}, peer_off[kMax] = {};
+    size_t longest_send = 0;
+    size_t bytes_out(int rank, int world) const { size_t b = 0; for (int r = 0; r < world; r++) if (r != rank) b += send_bytes[r]; return b; }
+};
 
 struct chad_comm {
     int32_t rank = 0, world = 1;
@@ -80,6 +100,11 @@ struct chad_comm {
     bool no_shortcut = false;                     // CHAD_DEBUG_COMM_NO_SHORTCUT: a one-rank communicator goes through its transport as well
                                                   // (tests: the RCCL calls themselves on a one-GPU box)
     bool exchanges() const { return world > 1 || no_shortcut; }
+    bool dead = false;                            // abort() has been called: every later collective fails at once
+    void abort() {
+        if (nccl && !dead && chadhip::rccl().comm_abort) { (void)chadhip::rccl().comm_abort(nccl); nccl = nullptr; }
+        dead = true; error = "the communicator was aborted after a failed exchange";
+    }
     // the size of the job as the TRANSPORT sees it (RCCL: ncclCommCount; a one-rank communicator that never opened RCCL: 1; callbacks: what the caller said)
     int32_t transport_world() const {
         int n = world;
@@ -89,6 +114,7 @@ struct chad_comm {
 
     // recv[world * bytes] <- every rank's send[bytes], in rank order.  Device buffers; ordered on `stream`.
     bool all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) {
+        if (dead) return false;
         if (!exchanges()) return hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, stream) == hipSuccess;
         if (nccl) {
             if (bytes % 8) { error = "all_gather: size not a multiple of 8"; return false; }
@@ -102,8 +128,46 @@ struct chad_comm {
         if (hipMemcpyAsync(recv, host.data() + bytes, bytes * size_t(world), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { error = "all_gather: staging copy failed"; return false; }
         return true;
     }
+    // Every rank hands every other rank one slice of `send` and receives one into `recv` (sizes and places: the plan, the same picture on
+    // every rank).  RCCL: one group of ncclSend / ncclRecv pairs -- point-to-point over xGMI, every link carrying only what its two
+    // ends exchange.  Callbacks: whole send buffers gathered through the caller's all_gather, the slices picked out on the host.
+    bool exchange_slices(const void* send, void* recv, const ExchangePlan& p, hipStream_t stream) {
+        if (dead) return false;
+        const char* src = static_cast<const char*>(send);
+        char* dst = static_cast<char*>(recv);
+        if (p.send_bytes[rank] && hipMemcpyAsync(dst + p.recv_off[rank], src + p.send_off[rank], p.send_bytes[rank], hipMemcpyDeviceToDevice, stream) != hipSuccess) { error = "exchange_slices: local copy failed"; return false; }
+        if (world == 1) return true;
+        if (nccl) {
+            chadhip::RcclApi& api = chadhip::rccl();
+            if (!api.send || !api.recv || !api.group_start || !api.group_end) { error = "librccl.so.1 lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd"; return false; }
+            int r = api.group_start();
+            for (int peer = 0; peer < world && !r; peer++) {
+                if (peer == rank) continue;
+                if (p.send_bytes[peer]) r = api.send(src + p.send_off[peer], p.send_bytes[peer], chadhip::RcclApi::kInt8, peer, nccl, stream);
+                if (!r && p.recv_bytes[peer]) r = api.recv(dst + p.recv_off[peer], p.recv_bytes[peer], chadhip::RcclApi::kInt8, peer, nccl, stream);
+            }
+            const int e = api.group_end();
+            if (r || e) { error = std::string("ncclSend / ncclRecv: ") + api.get_error_string(r ? r : e); return false; }
+            return true;
+        }
+        const size_t pad = (std::max<size_t>(p.longest_send, 8) + 7) & ~size_t(7);
+        size_t mine = 0;
+        for (int r = 0; r < world; r++) mine = std::max(mine, p.send_off[r] + p.send_bytes[r]);
+        if (mine > pad) { error = "exchange_slices: a send buffer longer than the plan's longest"; return false; }
+        host.resize(pad * size_t(world + 1));
+        if (mine && (hipMemcpyAsync(host.data(), send, mine, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)) { error = "exchange_slices: staging copy failed"; return false; }
+        if (gather(user, host.data(), host.data() + pad, pad) != 0) { error = "exchange_slices: all_gather callback failed"; return false; }
+        for (int r = 0; r < world; r++) {
+            if (r == rank || !p.recv_bytes[r]) continue;
+            if (p.peer_off[r] + p.recv_bytes[r] > pad) { error = "exchange_slices: a slice outside its sender's buffer"; return false; }
+            if (hipMemcpyAsync(dst + p.recv_off[r], host.data() + pad * size_t(r + 1) + p.peer_off[r], p.recv_bytes[r], hipMemcpyHostToDevice, stream) != hipSuccess) { error = "exchange_slices: staging copy failed"; return false; }
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) { error = "exchange_slices: staging copy failed"; return false; }
+        return true;
+    }
     // buf[count] <- sum over the ranks, in place.  dtype: CHAD_REDUCE_U32 / CHAD_REDUCE_I64.
     bool all_reduce(void* buf, size_t count, int32_t dtype, hipStream_t stream) {
+        if (dead) return false;
         if (!exchanges() || count == 0) return true;
         const size_t bytes = count * (dtype == CHAD_REDUCE_I64 ? 8 : 4);
         if (nccl) {

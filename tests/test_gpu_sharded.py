@@ -266,3 +266,80 @@ def test_a_rank_that_stops_right_after_a_roll_over_still_completes_the_exchange(
     assert np.array_equal(got["mc"], want[0]) and np.array_equal(got["w"], want[2])
     assert np.array_equal(got["sd"].view(np.uint32), want[1].view(np.uint32))
     single.close()
+
+
+def _cfg5_dag_rank(rank, world, port, outdir, n_frames):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chad_tsdf_amd import synth
+    from chad_tsdf_amd.sharded import ShardedTSDFMap
+
+    dev = {k: synth.cfg5_frame_torch(k)[0] for k in range(rank, n_frames, world)}   # a rank only ever sees the points of its own frames
+    torch.cuda.synchronize()
+    sm = ShardedTSDFMap(0.02, 0.06, max_points=200_000, max_blocks=1 << 22, dag_only=True)
+    sm.local.pipeline_times()
+    for k in range(n_frames):
+        sm.insert(dev.get(k), np.array([0.5 * k, 0.0, 0.0], dtype=np.float32))   # no synchronisation: the exchanges ride beside the frames
+    sm.merge_and_close()
+    sm.local.sync()
+    sm.local.finalize()
+    assert sm.local.stats()["overflow"] == 0
+    pt = sm.local.pipeline_times()
+    np.save(os.path.join(outdir, f"cfg5_rank{rank}_exchange.npy"),
+            np.array([pt["exchanges"], pt["exchange_bytes"], pt["exchange_union_blocks"], pt["folds_completed"], pt["comm_world"], pt["comm_transport"]], dtype=np.uint64))
+    if rank == 0:
+        n_sub = sm.closed_submaps
+        levels = {f"level{l}": sm.local.dag_level(l) for l in range(21)}
+        np.savez(os.path.join(outdir, "cfg5_rank0_dag.npz"), roots=np.array([sm.local.dag_roots(s) for s in range(n_sub)], np.uint32), **levels)
+    else:   # the other ranks hold no DAG: the fold ran once, on rank 0
+        from chad_tsdf_amd._lib import ChadError
+
+        with pytest.raises(ChadError, match="rank 0"):
+            sm.local.dag_roots(0)
+    sm.local.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg5_sharded_dag_only_equals_one_gpu_word_for_word(tmp_path, world):
+    """BASELINE config 5's multi-GPU shape on the ranks this box can hold (they share its GPU: callback transport over gloo): 110 frames
+    of the outdoor trajectory -- ten roll-overs by the 5 m rule, plus the open submap closed at the end -- dealt round-robin over 2 and
+    4 ranks under CHAD_FLAG_DAG_ONLY.  The exchange at a roll-over is the SPARSE one (exchange_kernels.hpp: keys, voxel masks and one
+    staging word per touched voxel to the owner of the Morton key range; cluster words of each range to rank 0) and Submap::finalize
+    runs ONCE per submap, on rank 0.  Rank 0's DAG must equal the DAG one GPU builds from the whole stream: all 21 level arrays and
+    every submap's roots, word for word (submap.hpp:10-106, levels.hpp:141-199).  Bytes a rank hands to the exchange per roll-over are
+    printed and bounded: the dense all-reduce of round 3 moved 1.27 GB per rank and roll-over here."""
+    import torch.multiprocessing as mp
+
+    import chad_tsdf_amd
+    from chad_tsdf_amd import synth
+
+    n_frames = 110
+    mp.spawn(_cfg5_dag_rank, args=(world, 29553 + world, str(tmp_path), n_frames), nprocs=world, join=True)
+    single = chad_tsdf_amd.TSDFMap(0.02, 0.06, max_points=200_000, max_blocks=1 << 22, dag_only=True)
+    for k in range(n_frames):
+        pts, pos = synth.cfg5_frame_torch(k)
+        single.insert(pts, pos)
+    single.close_submap()
+    single.finalize()
+    n_sub = single.closed_submaps
+    assert n_sub == 10
+    got = np.load(tmp_path / "cfg5_rank0_dag.npz")
+    assert np.array_equal(got["roots"], np.array([single.dag_roots(s) for s in range(n_sub)], np.uint32)), "roots differ from the single-GPU DAG"
+    for l in range(21):
+        assert np.array_equal(got[f"level{l}"], single.dag_level(l)), f"level {l} differs from the single-GPU DAG"
+    single.close()
+    per_rollover = []
+    for rank in range(world):
+        exchanges, sent, union_blocks, folds, comm_world, transport = np.load(tmp_path / f"cfg5_rank{rank}_exchange.npy").tolist()
+        assert exchanges == n_sub and comm_world == world and transport == 2
+        assert folds == (n_sub if rank == 0 else 0), "Submap::finalize must run once per submap, on rank 0 only"
+        per_rollover.append(sent / exchanges / 1e6)
+    print(f"world {world}: MB handed to the exchange per roll-over and rank: {[round(b, 1) for b in per_rollover]} (last union: {union_blocks} blocks)")
+    assert max(per_rollover) <= 80.0 and sum(per_rollover) / world <= 60.0
