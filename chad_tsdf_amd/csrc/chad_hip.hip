@@ -883,7 +883,7 @@ static chad_status sparse_stages(chad_map* m, bool block) {
     const uint32_t world = uint32_t(c->world), me = uint32_t(c->rank);
     chad_map::SparseExchange& x = m->sx;
     uint64_t* H = m->merge_host;
-    constexpr uint32_t kHead = kXSamples + 1, kHSplit = 1024, kHMatrix = 1056, kHAllU = 1600, kHUnion = 1640;
+    constexpr uint32_t kHead = kXHeadWords, kHSplit = 1024, kHMatrix = 1056, kHAllU = 1600, kHUnion = 1640;
     const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
     for (;;) {
         hipEvent_t pending = m->merge_stage == 0 ? m->closing_counted : m->merge_event;
@@ -934,28 +934,9 @@ static chad_status sparse_stages(chad_map* m, bool block) {
             HIP_TRY(hipEventRecord(m->merge_event, s));
             m->merge_stage = 1;
         } else if (m->merge_stage == 1) {
-            // the splitters: weighted quantiles of all ranks' samples (a sample of rank r stands for nb_r / 65 of its blocks) -- plain
-            // deterministic host arithmetic on words every rank holds alike
-            std::vector<std::pair<uint64_t, double>> samples;
-            double total = 0;
-            for (uint32_t r = 0; r < world; r++) {
-                const uint64_t head = H[size_t(r) * kHead];
-                const uint32_t n_r = uint32_t(head);
-                if (n_r >= (1u << 30)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible block count from a rank");
-                x.wide_of[r] = uint32_t(head >> 32) & 1u;
-                if (!n_r) continue;
-                for (uint32_t i = 0; i < kXSamples; i++) samples.emplace_back(H[size_t(r) * kHead + 1 + i], double(n_r) / double(kXSamples + 1));
-                total += double(n_r) * double(kXSamples) / double(kXSamples + 1);
-            }
-            std::stable_sort(samples.begin(), samples.end(), [](const std::pair<uint64_t, double>& a, const std::pair<uint64_t, double>& b) { return a.first < b.first; });
-            {
-                double cum = 0; size_t at = 0;
-                for (uint32_t j = 1; j < world; j++) {
-                    const double target = total * double(j) / double(world);
-                    while (at < samples.size() && cum + samples[at].second < target) cum += samples[at++].second;
-                    H[kHSplit + j - 1] = at < samples.size() ? samples[at].first : ~0ull;
-                }
-            }
+            // the splitters: plain deterministic host arithmetic on words every rank holds alike (exchange_plan.hpp)
+            if (!xchg_splitters(H, world, &H[kHSplit])) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible block count from a rank");
+            for (uint32_t r = 0; r < world; r++) x.wide_of[r] = uint32_t(H[size_t(r) * kHead] >> 32) & 1u;
             if (world > 1) HIP_TRY(hipMemcpyAsync(d_split, &H[kHSplit], size_t(world - 1) * 8, hipMemcpyHostToDevice, s));
             const uint32_t nb = x.nb, chunks = (nb + kUniqueChunk - 1) / kUniqueChunk;
             hipLaunchKernelGGL(k_xchg_ranges, dim3(1), dim3(64), 0, s, (const uint64_t*)x.keys_sorted, nb, (const uint64_t*)d_split, world, x.first_block);
@@ -975,20 +956,15 @@ static chad_status sparse_stages(chad_map* m, bool block) {
         } else if (m->merge_stage == 2) {
             auto blocks_of = [&](uint32_t from, uint32_t to) { return H[kHMatrix + (size_t(from) * world + to) * 2]; };
             auto words_of = [&](uint32_t from, uint32_t to) { return H[kHMatrix + (size_t(from) * world + to) * 2 + 1]; };
-            auto slice = [&](uint32_t from, uint32_t to) { return xchg_slice_bytes(blocks_of(from, to), words_of(from, to), x.wide_of[from] ? 2u : 1u); };
             ExchangePlan plan;
+            if (!xchg_slice_plan(&H[kHMatrix], x.wide_of, world, me, plan)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible slice size from a rank");
             XchgSlices slices{};
-            size_t send_total = 0, recv_total = 0, mine_check = 0;
-            uint64_t recv_blocks = 0;
+            const size_t send_total = plan.send_total(), recv_total = plan.recv_total();
+            uint64_t recv_blocks = 0, mine_check = 0;
             for (uint32_t r = 0; r < world; r++) {
-                if (blocks_of(r, me) >= (1ull << 30) || words_of(r, me) > blocks_of(r, me) * 64) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible slice size from a rank");
-                plan.send_off[r] = send_total; plan.send_bytes[r] = slice(me, r); slices.off[r] = send_total; send_total += plan.send_bytes[r];
-                plan.recv_off[r] = recv_total; plan.recv_bytes[r] = slice(r, me); x.recv_off[r] = recv_total; recv_total += plan.recv_bytes[r];
+                slices.off[r] = plan.send_off[r]; x.recv_off[r] = plan.recv_off[r];
                 x.blocks_from[r] = blocks_of(r, me); x.words_from[r] = words_of(r, me); recv_blocks += x.blocks_from[r];
                 mine_check += blocks_of(me, r);
-                size_t before = 0, whole = 0;
-                for (uint32_t d = 0; d < world; d++) { if (d < me) before += slice(r, d); whole += slice(r, d); }
-                plan.peer_off[r] = before; plan.longest_send = std::max(plan.longest_send, whole);
             }
             if (mine_check != x.nb) return fail(CHAD_ERR_HIP, "multi-GPU exchange: this rank's ranges do not add up to its blocks");
             if (recv_blocks >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks in one rank's range");
@@ -1074,18 +1050,10 @@ static chad_status sparse_stages(chad_map* m, bool block) {
             // the ranges to rank 0, which holds the DAG
             ExchangePlan plan;
             uint64_t total_blocks = 0;
-            size_t recv_total = 0;
-            for (uint32_t r = 0; r < world; r++) {
-                const uint64_t u = H[kHAllU + 2 * r], w = H[kHAllU + 2 * r + 1];
-                if (u >= (1ull << 30) || w > u * 8) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible range size from a rank");
-                total_blocks += u;
-                if (me == 0) { plan.recv_off[r] = recv_total; plan.recv_bytes[r] = xchg_range_bytes(u, w, saturate); recv_total += plan.recv_bytes[r]; }
-                plan.longest_send = std::max(plan.longest_send, xchg_range_bytes(u, w, saturate));
-            }
+            if (!xchg_gather_plan(&H[kHAllU], world, me, saturate, plan, &total_blocks)) return fail(CHAD_ERR_HIP, "multi-GPU exchange: implausible range size from a rank");
             if (total_blocks >= (1ull << 30)) return fail(CHAD_ERR_CAPACITY, "multi-GPU exchange: more than 2^30 blocks in one submap");
             if (H[kHAllU + 2 * me] != x.n_union) return fail(CHAD_ERR_HIP, "multi-GPU exchange: this rank's range size came back changed");
-            const size_t my_bytes = xchg_range_bytes(x.n_union, H[kHAllU + 2 * me + 1], saturate);
-            plan.send_bytes[0] = my_bytes;   // (everything goes to rank 0; a peer's slice for rank 0 starts at the beginning of its buffer: peer_off = 0)
+            const size_t my_bytes = plan.send_bytes[0], recv_total = plan.recv_total();
             if (me == 0) {
                 while (m->pending.set) TRY(fold_advance(m, true));   // (at most one submap waits while another is folded: close_into_dag's rule)
                 const size_t nb = std::max<uint64_t>(total_blocks, 1), words = nb * 8;
@@ -3026,6 +2994,20 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     HIP_TRY(hipMemcpy(&fault, sig.fault, 4, hipMemcpyDeviceToHost));
     (void)chad_free(sig.fault);
     if (fault) return fail(CHAD_ERR_HIP, "a radix sort tile gave up waiting for its predecessors");
+    return CHAD_OK;
+}
+
+chad_status chad_exchange_splitters(const uint64_t* heads, uint32_t world, uint64_t* splitters) {
+    if (!heads || !splitters || world < 1 || world > uint32_t(kMaxRanks)) return fail(CHAD_ERR_INVALID_ARG, "null argument or world out of range");
+    return xchg_splitters(heads, world, splitters) ? CHAD_OK : fail(CHAD_ERR_INVALID_ARG, "implausible block count in a head");
+}
+
+chad_status chad_exchange_layout(const uint64_t* matrix, const uint32_t* wide, uint32_t world, uint32_t rank, uint64_t* out) {
+    if (!matrix || !wide || !out || world < 1 || world > uint32_t(kMaxRanks) || rank >= world) return fail(CHAD_ERR_INVALID_ARG, "null argument or rank / world out of range");
+    ExchangePlan plan;
+    if (!xchg_slice_plan(matrix, wide, world, rank, plan)) return fail(CHAD_ERR_INVALID_ARG, "implausible slice size in the matrix");
+    for (uint32_t r = 0; r < world; r++) { out[5 * r] = plan.send_off[r]; out[5 * r + 1] = plan.send_bytes[r]; out[5 * r + 2] = plan.recv_off[r]; out[5 * r + 3] = plan.recv_bytes[r]; out[5 * r + 4] = plan.peer_off[r]; }
+    out[5 * world] = plan.longest_send;
     return CHAD_OK;
 }
 

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/chad_hip.h"
+#include "exchange_plan.hpp"
 
 namespace chadhip {
 
@@ -78,16 +79,6 @@ inline RcclApi& rccl() { static RcclApi api; return api; }
 
 }  // namespace chadhip
 
-// Who sends what to whom in one point-to-point step (chad_comm::exchange_slices): byte ranges of this rank's send and receive buffers
-// per peer -- and, for the callback transport, where this rank's slice lies in every PEER's send buffer and how long the longest send
-// buffer of the job is (that transport gathers whole send buffers: a rehearsal path, not the product's).
-struct ExchangePlan {
-    static constexpr int kMax = 16;
-    size_t send_off[kMax] = {}, send_bytes[kMax] = {}, recv_off[kMax] = {}, recv_bytes[kMax] = {}, peer_off[kMax] = {};
-    size_t longest_send = 0;
-    size_t bytes_out(int rank, int world) const { size_t b = 0; for (int r = 0; r < world; r++) if (r != rank) b += send_bytes[r]; return b; }
-};
-
 struct chad_comm {
     int32_t rank = 0, world = 1;
     int device = 0;
@@ -131,7 +122,7 @@ struct chad_comm {
     // Every rank hands every other rank one slice of `send` and receives one into `recv` (sizes and places: the plan, the same picture on
     // every rank).  RCCL: one group of ncclSend / ncclRecv pairs -- point-to-point over xGMI, every link carrying only what its two
     // ends exchange.  Callbacks: whole send buffers gathered through the caller's all_gather, the slices picked out on the host.
-    bool exchange_slices(const void* send, void* recv, const ExchangePlan& p, hipStream_t stream) {
+    bool exchange_slices(const void* send, void* recv, const chadhip::ExchangePlan& p, hipStream_t stream) {
         if (dead) return false;
         const char* src = static_cast<const char*>(send);
         char* dst = static_cast<char*>(recv);

@@ -15,14 +15,12 @@
 // Slice (source -> destination), nb blocks, w payload words:   keys u64[nb] | masks u64[nb] | first u32[nb] (padded to 8 bytes) |
 // payload u64[w]: the words of block i are payload[first[i] * width ...], one group per set bit of masks[i], in voxel order.
 #pragma once
+#include "exchange_plan.hpp"
 #include "merge_kernels.hpp"
 
 namespace chadhip {
 
-constexpr uint32_t kXSamples = 64;   // sample keys per rank the splitters are drawn from
-
 __host__ __device__ inline size_t xchg_pad8(size_t bytes) { return (bytes + 7) & ~size_t(7); }
-inline size_t xchg_slice_bytes(size_t blocks, size_t words, uint32_t width) { return 16 * blocks + xchg_pad8(4 * blocks) + 8 * words * width; }
 
 // the live slots in key order: slot_sorted[r] = slot of the r-th smallest key (order: the sorter's payload, positions in k_table_keys' list)
 __global__ void __launch_bounds__(256)
@@ -182,8 +180,6 @@ k_xchg_clusters(const long long* __restrict__ acc_sum, const uint32_t* __restric
 // ---- a range's cluster words on their way to rank 0: only the octets that hold leaves travel (a cfg5 block holds leaves in about three
 // of its eight octets).  Range slice, U blocks, W words:   keys u64[U] | first u32[U] (padded to 8 bytes) | masks u8[U] (padded) |
 // tsdf words u64[W] | weight words u64[W] (CHAD_FLAG_DAG_SATURATE_WEIGHTS only); block b's words are [first[b], first[b] + popcount(masks[b])).
-inline size_t xchg_range_bytes(size_t blocks, size_t words, bool weights) { return 8 * blocks + xchg_pad8(4 * blocks) + xchg_pad8(blocks) + 8 * words * (weights ? 2 : 1); }
-
 __global__ void __launch_bounds__(256)
 k_xchg_widen(const uint8_t* __restrict__ mask8, uint32_t n, uint64_t* __restrict__ mask64) {
     for (size_t b = size_t(blockIdx.x) * blockDim.x + threadIdx.x; b < n; b += size_t(gridDim.x) * blockDim.x) mask64[b] = mask8[b];

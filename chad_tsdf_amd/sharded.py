@@ -4,28 +4,24 @@ Why this shards: within a frame, every stage of TSDFMap
 points and pose (tsdf.cpp:64-70); the only cross-frame state is the per-voxel mean and count, and the reference's
 update is a mean of unit-weight observations (octree.hpp:161-163), so per-GPU partial (sum, count) bricks combine
 exactly by addition.  Frame k of the stream goes to rank k % world_size; the roll-over decision (tsdf.cpp:46-61)
-depends only on the pose sequence, so every rank takes it identically without communication.  The exchange
-happens when a submap closes:
+depends only on the pose sequence, so every rank takes it identically without communication.
 
-  1. all_gather of each rank's sorted block keys (counts first, then keys padded to the longest list);
-  2. every rank forms the same sorted union and scatters its bricks into dense [B_union, 64] buffers;
-  3. all_reduce(SUM) of the f32 sums and of the i32 counts (backend "nccl" = RCCL over xGMI on ROCm);
-  4. every rank archives the merged bricks as the closed submap (sd = sum / count at read-back).
-
-With the HIP map all of this lives behind the C ABI (include/chad_hip.h, "Multi-GPU"): chad_map_attach_comm makes insert()
-frame-sharded and the exchange runs in the library -- RCCL all-gather / all-reduce of 64-bit integer sums and counts, so N ranks
-archive bit for bit what one GPU archives.  This module only builds the communicator (`Comm`: the RCCL id travels over
-torch.distributed; with the gloo backend the library's collectives are served by torch.distributed callbacks on host buffers,
-which is how several ranks are rehearsed on one GPU) and keeps the SPMD wrapper.  `merge_blocks` and the Python protocol below
-remain for duck-typed stand-in maps (the CPU tests of the sharding logic, tests/test_distributed_gloo.py).
+All of it lives behind the C ABI (include/chad_hip.h, "Multi-GPU"): chad_map_attach_comm makes insert() frame-sharded and the
+exchange at a submap close runs in the library, on 64-bit integer sums, so N ranks build bit for bit what one GPU builds:
+  * a map that keeps its closed submaps' dense archives: all-gather of block keys, sorted union, all-reduce of dense [U x 64]
+    sums and counts -- every rank ends up with the merged submap (merge_kernels.hpp);
+  * a map under CHAD_FLAG_DAG_ONLY (long trajectories, BASELINE config 5): the SPARSE exchange -- keys, voxel masks and one word
+    per touched voxel to the owner of a Morton key range, each range's cluster words to rank 0, Submap::finalize once, there
+    (exchange_kernels.hpp).
+This module only builds the communicator (`Comm`: the RCCL id travels over torch.distributed; with the gloo backend the library's
+collectives are served by torch.distributed callbacks on host buffers, which is how several ranks are rehearsed on one GPU) and
+keeps the SPMD wrapper.
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 import torch.distributed as dist
-
-SUBMAP_DISTANCE = np.float32(5.0)  # tsdf.cpp:52
 
 
 class Comm:
@@ -92,47 +88,10 @@ class Comm:
     __del__ = close
 
 
-def merge_blocks(keys: torch.Tensor, sums: torch.Tensor, cnts: torch.Tensor, group=None):
-    """Combine per-rank partial bricks.  keys int64 [B] (distinct, in any order), sums f32 [B,64], cnts i32 [B,64].
-
-    Returns (union keys [U], summed sums [U,64], summed counts [U,64]), identical on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        return keys, sums, cnts
-    home = keys.device
-    if keys.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal of the GPU path over gloo: collectives on host copies
-        merged = merge_blocks(keys.cpu(), sums.cpu(), cnts.cpu(), group)
-        return tuple(t.to(home) for t in merged)
-    dev = keys.device
-    n_local = torch.tensor([keys.numel()], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    longest = max(max(counts), 1)
-    padded = torch.full((longest,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
-    padded[: keys.numel()] = keys
-    gathered = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded, group=group)
-    union = torch.unique(torch.cat([g[:c] for g, c in zip(gathered, counts)]))  # sorted
-    dense_sum = torch.zeros((union.numel(), 64), dtype=torch.float32, device=dev)
-    dense_cnt = torch.zeros((union.numel(), 64), dtype=torch.int32, device=dev)
-    if keys.numel():
-        at = torch.searchsorted(union, keys)
-        dense_sum[at] = sums
-        dense_cnt[at] = cnts
-    if union.numel():
-        dist.all_reduce(dense_sum, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(dense_cnt, op=dist.ReduceOp.SUM, group=group)
-    return union, dense_sum, dense_cnt
-
-
 class ShardedTSDFMap:
-    """SPMD wrapper: every rank calls insert() for every frame, in the same order, with the same position.
-
-    `local` is this rank's single-device map: chad_tsdf_amd.TSDFMap on a GPU (the default), or any object with
-    insert / export_blocks / close_submap_with_blocks / export_leaves (the gloo tests pass a CPU stand-in).
-    Points are only needed on the rank that owns the frame (frame index % world size); other ranks may pass None.
-    """
+    """SPMD wrapper: every rank calls insert() for every frame, in the same order, with the same position.  Points are only needed on
+    the rank that owns the frame (frame index % world size); the other ranks may pass None.  `local`: this rank's TSDFMap (made here
+    from map_kwargs by default).  Ownership, pose bookkeeping and the exchange at a roll-over all happen in the library."""
 
     def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, local=None, group=None, comm=None, **map_kwargs):
         if local is None:
@@ -143,76 +102,29 @@ class ShardedTSDFMap:
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._first_pose = None  # first pose of the active submap (positions.front(), tsdf.cpp:51)
-        self._frame = 0          # frames seen in the stream
-        self._empty = np.zeros((0, 3), dtype=np.float32)
-        self._fast = hasattr(local, "would_roll_over") and hasattr(local, "note_pose")  # the HIP map; stand-ins take the numpy path
-        # the HIP map shards inside the library: attach a communicator and every insert / roll-over / close does the right thing there
-        self._native = hasattr(local, "attach_comm")
-        self.comm = None
-        if self._native:
-            self.comm = comm if comm is not None else (Comm(group) if self.world > 1 else None)   # (a Comm may serve several maps, one after the other)
-            local.attach_comm(self.comm)
+        self.comm = comm if comm is not None else (Comm(group) if self.world > 1 else None)   # (a Comm may serve several maps, one after the other)
+        local.attach_comm(self.comm)
+        self._open = False   # the active submap holds a pose
 
     def owner(self, frame: int) -> int:
         return frame % self.world
 
-    def _rolls_over(self, pos: np.ndarray) -> bool:
-        # tsdf.cpp:52 in f32, same operation order as glm::distance (and as the C library's host code)
-        d = pos - self._first_pose
-        return bool(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > SUBMAP_DISTANCE)
-
     def insert(self, points, position):
         pos = np.ascontiguousarray(position, dtype=np.float32).reshape(3)
-        if self._native:   # ownership (frame k -> rank k % world), pose bookkeeping and the exchange at a roll-over all happen in the library
-            if points is None:
-                self.local.note_pose(pos)
-            else:
-                self.local.insert(points, pos)
-            self._first_pose = pos
-            self._frame += 1
-            return
-        # The roll-over rule, evaluated identically on every rank before the frame.  A rank that does not own the frame
-        # spends about 3 us here (one query + one pose-only insert, both plain C calls): at 8 ranks that is what bounds the
-        # strong scaling of a stream of small frames, so the path avoids numpy arithmetic where the local map offers the calls.
-        if self._fast:
-            if self.local.would_roll_over(pos):   # false while the active submap holds no pose
-                self.merge_and_close()      # collective; leaves every local map with an empty active submap
-            self._first_pose = pos          # (only "a submap is open" matters on this path; the library keeps the poses)
-            if self._frame % self.world == self.rank:
-                self.local.insert(points, pos)
-            else:
-                self.local.note_pose(pos)
-            self._frame += 1
-            return
-        if self._first_pose is None:
-            self._first_pose = pos.copy()
-        elif self._rolls_over(pos):
-            self.merge_and_close()          # collective; leaves every local map with an empty active submap
-            self._first_pose = pos.copy()   # the frame that triggers the roll-over opens the new submap (tsdf.cpp:55-57)
-        mine = self.owner(self._frame) == self.rank
-        # ranks that do not own the frame still record its pose (an empty insert runs only the bookkeeping of
-        # tsdf.cpp:46-61), so all local maps agree on the submap's first pose
-        self.local.insert(points if mine else self._empty, pos)
-        self._frame += 1
+        if points is None:
+            self.local.note_pose(pos)
+        else:
+            self.local.insert(points, pos)
+        self._open = True
 
     def merge_and_close(self):
-        """The exchange step: merge the active submap across ranks and archive it on every rank."""
-        if self._native:
-            self.local.merge_and_close()
-            self._first_pose = None
-            return
-        try:
-            keys, sums, cnts = self.local.export_blocks(-1, ordered=False)   # the merge orders the union of all ranks' keys
-        except TypeError:  # a stand-in map without the option
-            keys, sums, cnts = self.local.export_blocks(-1)
-        keys, sums, cnts = merge_blocks(keys, sums, cnts, self.group)
-        self.local.close_submap_with_blocks(keys, sums, cnts)
-        self._first_pose = None
+        """The exchange step (collective): merge the active submap across the ranks and close it."""
+        self.local.merge_and_close()
+        self._open = False
 
     def save(self, filename: str):
         """TSDFMap::save (tsdf.cpp:76-86): merge + close the active submap, rank 0 writes the first submap."""
-        if self._first_pose is not None:
+        if self._open:
             self.merge_and_close()
         if self.rank == 0:
             self.local.save(filename)
@@ -222,7 +134,7 @@ class ShardedTSDFMap:
         return self.local.closed_submaps
 
     def export_leaves(self, submap: int):
-        """Leaves of a CLOSED (merged) submap; identical on every rank."""
+        """Leaves of a CLOSED (merged) submap; identical on every rank (maps that keep their archives)."""
         if submap < 0:
             raise ValueError("the active submap is spread over the ranks; call merge_and_close() first")
         return self.local.export_leaves(submap)

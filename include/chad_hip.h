@@ -342,6 +342,15 @@ chad_status chad_morton_codes(const float* xyz, size_t n, float sdf_res, uint64_
  * order_out[i] its position in the input (equal keys keep input order).  Either output may be NULL. */
 chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, uint64_t* keys_out, uint32_t* order_out);
 
+/* Stage entries for the CPU tests of the sparse multi-GPU exchange (no device needed): the host arithmetic every rank runs on the words
+ * it has all-gathered (chad_tsdf_amd/csrc/exchange_plan.hpp).  chad_exchange_splitters: heads[world][65] -- per rank its block count
+ * (low 32 bits of word 0; bit 32: two payload words per voxel) and 64 sample keys of its sorted list -- -> the world - 1 splitter keys
+ * that cut the Morton key space into the ranks' ranges.  chad_exchange_layout: matrix[a][b] = {blocks, words} rank a holds for rank b's
+ * range, wide[a] its payload width flag -> for rank `rank`, out[5 r .. 5 r + 4] = {send offset, send bytes, receive offset, receive
+ * bytes, offset of this rank's slice in rank r's send buffer}, out[5 world] = the longest send buffer of the job. */
+chad_status chad_exchange_splitters(const uint64_t* heads, uint32_t world, uint64_t* splitters);
+chad_status chad_exchange_layout(const uint64_t* matrix, const uint32_t* wide, uint32_t world, uint32_t rank, uint64_t* out);
+
 /* Thread-local message of the last failure on this thread ("" if none). */
 const char* chad_last_error(void);
 /* Library/build identification, e.g. "chad_hip 0.1 gfx950". */

@@ -1,8 +1,13 @@
-"""The N > 1 path on CPU: two ranks (gloo), frames dealt round-robin, partial bricks merged at submap close.
+"""The N > 1 path on CPU, two ranks over gloo.
 
-The per-rank single-device map is a CPU stand-in built on the oracle (this is test infrastructure: the product's
-ShardedTSDFMap only sees the duck-typed `local` object); what is under test is the sharding logic and the
-exchange step of chad_tsdf_amd/sharded.py -- the same code that runs over RCCL on GPUs."""
+1. The PRODUCT's host arithmetic of the sparse exchange (chad_tsdf_amd/csrc/exchange_plan.hpp through the C ABI's stage entries
+   chad_exchange_splitters / chad_exchange_layout -- they need no device): two ranks with different sorted block lists all-gather
+   their heads, derive the splitters, their per-range rows and the byte layout of the point-to-point step, run that step the way the
+   callback transport does (whole send buffers gathered, slices picked out by the layout's offsets) on slices packed in the
+   documented format, and the owners' accumulated voxels must be the sum over both ranks -- key ranges disjoint, ordered, complete.
+2. The frame-sharding PROTOCOL restated in Python (tests/sharding_standin.py) over an oracle-backed stand-in map: frames dealt
+   round-robin, the roll-over rule taken identically on both ranks, one merge per submap.  (The library's own sharding and both of
+   its exchanges run on the GPU: tests/test_gpu_sharded.py, tests/test_gpu_exchange_faults.py.)"""
 import os
 import sys
 
@@ -68,9 +73,9 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from chad_tsdf_amd.sharded import ShardedTSDFMap
+    from tests.sharding_standin import StandinShardedMap
 
-    sm = ShardedTSDFMap(0.05, 0.10, local=OracleLocalMap(0.05, 0.10))
+    sm = StandinShardedMap(OracleLocalMap(0.05, 0.10))
     for k, (pts, pos) in enumerate(_frames()):
         sm.insert(pts if k % world == rank else None, pos)  # non-owners do not even get the points
     sm.merge_and_close()
@@ -102,10 +107,118 @@ def test_two_ranks_match_one_map(tmp_path, oracle):
 
 
 def test_merge_blocks_single_rank_is_identity():
-    from chad_tsdf_amd.sharded import merge_blocks
+    from tests.sharding_standin import merge_blocks
 
     k = torch.tensor([64, 128], dtype=torch.int64)
     s = torch.ones((2, 64))
     c = torch.ones((2, 64), dtype=torch.int32)
     k2, s2, c2 = merge_blocks(k, s, c)
     assert k2 is k and s2 is s and c2 is c
+
+
+# ---- the product's exchange planning on two gloo ranks ---------------------------------------------------------------------------
+S = 64   # kXSamples
+
+
+def _share(rank):
+    """A rank's share of a submap: sorted distinct block keys, a voxel mask per block, one staging word per set voxel (count << 40 | sum)."""
+    rng = np.random.default_rng(100 + rank)
+    n = 5000 + 3000 * rank
+    # block keys: Morton-like 63-bit values with the low six bits clear; the two ranks overlap in about a third of their blocks
+    pool = np.sort(np.random.default_rng(7).choice(1 << 40, size=12000, replace=False).astype(np.uint64)) << np.uint64(6)
+    keys = np.sort(rng.choice(pool, size=n, replace=False))
+    masks = rng.integers(1, 1 << 63, size=n, dtype=np.uint64) & rng.integers(1, 1 << 63, size=n, dtype=np.uint64) | np.uint64(1)
+    counts = np.array([bin(int(m)).count("1") for m in masks], dtype=np.int64)
+    words = (rng.integers(1, 200, size=int(counts.sum())).astype(np.uint64) << np.uint64(40)) | rng.integers(0, 1 << 20, size=int(counts.sum())).astype(np.uint64)
+    return keys, masks, counts, words
+
+
+def _plan_worker(rank, world, port, out_dir):
+    import ctypes as C
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chad_tsdf_amd import _lib
+
+    lib = _lib.load()   # (loads without a GPU; only the two host-side stage entries are called)
+    keys, masks, counts, words = _share(rank)
+    n = len(keys)
+    # stage 0: head = [count | width flag << 32, 64 samples at even distances] (k_xchg_head), all-gathered
+    head = np.empty(S + 1, np.uint64)
+    head[0] = n
+    head[1:] = keys[(np.arange(1, S + 1, dtype=np.int64) * n) // (S + 1)]
+    heads = [torch.zeros(S + 1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(heads, torch.from_numpy(head.view(np.int64)))
+    heads = np.stack([h.numpy().view(np.uint64) for h in heads])
+    split = np.zeros(world - 1, np.uint64)
+    _lib.check(lib.chad_exchange_splitters(heads.ctypes.data, world, split.ctypes.data), "splitters")
+    # stage 1: my blocks per range (k_xchg_ranges: lower bounds of the splitters), their words; the G x G matrix all-gathered
+    first = np.concatenate([[0], np.searchsorted(keys, split, side="left"), [n]]).astype(np.int64)
+    prefix = np.concatenate([[0], np.cumsum(counts)])
+    row = np.array([[first[d + 1] - first[d], prefix[first[d + 1]] - prefix[first[d]]] for d in range(world)], np.uint64)
+    rows = [torch.zeros(2 * world, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(rows, torch.from_numpy(row.reshape(-1).view(np.int64)))
+    matrix = np.stack([r.numpy().view(np.uint64) for r in rows]).reshape(world, world, 2)
+    wide = np.zeros(world, np.uint32)
+    layout = np.zeros(5 * world + 1, np.uint64)
+    _lib.check(lib.chad_exchange_layout(np.ascontiguousarray(matrix).ctypes.data, wide.ctypes.data, world, rank, layout.ctypes.data), "layout")
+    send_off, send_bytes, recv_off, recv_bytes, peer_off = (layout[:5 * world].reshape(world, 5).astype(np.int64).T)
+    longest = int(layout[5 * world])
+    # stage 2: the slices, packed as exchange_kernels.hpp documents them: keys | masks | first u32 (padded to 8) | payload
+    send = np.zeros(longest, np.uint8)
+    for d in range(world):
+        a, b = first[d], first[d + 1]
+        nb = b - a
+        sl = np.concatenate([keys[a:b].view(np.uint8), masks[a:b].view(np.uint8), np.pad((prefix[a:b] - prefix[a]).astype(np.uint32).view(np.uint8), (0, (-4 * nb) % 8)),
+                             words[prefix[a]:prefix[b]].view(np.uint8)])
+        assert len(sl) == send_bytes[d], "the layout's slice size is the documented format's"
+        send[send_off[d]:send_off[d] + len(sl)] = sl
+    gathered = [torch.zeros(longest, dtype=torch.uint8) for _ in range(world)]   # the callback transport: whole send buffers gathered
+    dist.all_gather(gathered, torch.from_numpy(send))
+    # stage 3: what arrives for MY range, accumulated per (key, voxel)
+    acc = {}
+    lo = 0 if rank == 0 else int(split[rank - 1])
+    hi = (1 << 64) if rank == world - 1 else int(split[rank])
+    for r in range(world):
+        buf = gathered[r].numpy()[peer_off[r]:peer_off[r] + recv_bytes[r]] if r != rank else send[send_off[rank]:send_off[rank] + send_bytes[rank]]
+        nb = int(matrix[r, rank, 0])
+        k = buf[:8 * nb].view(np.uint64)
+        mk = buf[8 * nb:16 * nb].view(np.uint64)
+        fi = buf[16 * nb:16 * nb + 4 * nb].view(np.uint32)
+        pay = buf[16 * nb + 4 * nb + (-4 * nb) % 8:].view(np.uint64)
+        assert len(pay) == int(matrix[r, rank, 1])
+        assert nb == 0 or (int(k.min()) >= lo and int(k.max()) < hi), "a key outside the owner's range"
+        for i in range(nb):
+            j = int(fi[i])
+            for v in range(64):
+                if (int(mk[i]) >> v) & 1:
+                    acc[(int(k[i]), v)] = acc.get((int(k[i]), v), 0) + int(pay[j])
+                    j += 1
+    np.save(os.path.join(out_dir, f"plan_rank{rank}.npy"), np.array(sorted((k, v, w) for (k, v), w in acc.items()), dtype=np.uint64))
+    np.save(os.path.join(out_dir, f"split_rank{rank}.npy"), split)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sparse_exchange_planning_on_two_ranks(tmp_path):
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_plan_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    want = {}
+    for rank in range(world):
+        keys, masks, counts, words = _share(rank)
+        j = 0
+        for k, mk in zip(keys.tolist(), masks.tolist()):
+            for v in range(64):
+                if (mk >> v) & 1:
+                    want[(k, v)] = want.get((k, v), 0) + int(words[j])
+                    j += 1
+    got = np.concatenate([np.load(tmp_path / f"plan_rank{r}.npy") for r in range(world)])   # range 0 then range 1: ascending keys
+    assert np.array_equal(np.load(tmp_path / "split_rank0.npy"), np.load(tmp_path / "split_rank1.npy")), "the ranks derived different splitters"
+    assert len(got) == len(want)
+    assert np.all(got[1:, 0] >= got[:-1, 0]), "the ranges, concatenated in rank order, are not in Morton order"
+    for k, v, w in got.tolist():
+        assert want[(k, v)] == w
+    sizes = [len(np.load(tmp_path / f"plan_rank{r}.npy")) for r in range(world)]
+    assert min(sizes) > 0.3 * sum(sizes), f"the splitters left the ranges unbalanced: {sizes}"

@@ -75,7 +75,7 @@ def test_partial_maps_add_up(chad):
     """Linearity (what the multi-GPU merge relies on): blocks(A) + blocks(B) == blocks(A then B)."""
     import torch
 
-    from chad_tsdf_amd.sharded import merge_blocks
+    from tests.sharding_standin import merge_blocks
 
     (pa, pos_a), (pb, pos_b) = synth.cfg2_frame(500_000, seed=21), synth.cfg2_frame(500_000, seed=22, sensor=(0.8, 0.3, -0.2))
     both = chad.TSDFMap(0.05, 0.10)
@@ -245,8 +245,8 @@ def test_three_frames_in_flight_all_outgrow_the_enqueued_sort_passes(chad):
 
 
 def test_sharded_map_with_one_rank_equals_the_plain_map(chad):
-    """ShardedTSDFMap (sharded.py) without a process group is a one-rank world: its roll-over goes through the merge path
-    (unordered block export -> close_submap_with_blocks) and must leave the same submaps as the plain map's own roll-over."""
+    """ShardedTSDFMap (sharded.py) without a process group is a one-rank world: no communicator is attached and its roll-over is the
+    plain map's own; it must leave the same submaps."""
     from chad_tsdf_amd.sharded import ShardedTSDFMap
 
     plain = chad.TSDFMap(0.05, 0.10)
@@ -265,9 +265,11 @@ def test_sharded_map_with_one_rank_equals_the_plain_map(chad):
 
 
 def test_roll_over_query_is_the_rule_of_the_insert(chad):
-    """chad_map_would_roll_over answers tsdf.cpp:50-52 without side effects; the sharded map's C-call path and its numpy
-    path (the one stand-in maps take) close submaps at the same frames."""
+    """chad_map_would_roll_over answers tsdf.cpp:50-52 without side effects; the library's own sharding and the protocol restated in
+    Python (tests/sharding_standin.py: the roll-over rule in numpy, the merge through export_blocks / close_submap_with_blocks) close
+    submaps at the same frames."""
     from chad_tsdf_amd.sharded import ShardedTSDFMap
+    from tests.sharding_standin import StandinShardedMap
 
     m = chad.TSDFMap(0.05, 0.10)
     f32 = lambda *v: np.asarray(v, dtype=np.float32)
@@ -279,9 +281,8 @@ def test_roll_over_query_is_the_rule_of_the_insert(chad):
     m.insert(np.zeros((0, 3), np.float32), f32(6.5, 2, 3))
     assert m.closed_submaps == 1 and not m.would_roll_over(f32(11.4, 2, 3)) and m.would_roll_over(f32(11.6, 2, 3))
     closed = []
-    for fast in (True, False):
-        s = ShardedTSDFMap(0.05, 0.10)
-        s._fast = s._native = fast   # True: the library's own sharding (chad_map_attach_comm); False: the Python protocol stand-in maps take
+    for native in (True, False):
+        s = ShardedTSDFMap(0.05, 0.10) if native else StandinShardedMap(chad.TSDFMap(0.05, 0.10))
         for k in range(0, 260, 7):
             pts, pos = synth.cfg3_frame(k, 3000)
             s.insert(pts, pos)
