@@ -2997,6 +2997,17 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
     return CHAD_OK;
 }
 
+chad_status chad_selftest_reciprocal(uint64_t out[4]) {
+    if (!out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DevBuf d;
+    HIP_TRY(d.alloc(32));
+    HIP_TRY(hipMemset(d.p, 0, 32));
+    hipLaunchKernelGGL(k_selftest_reciprocal, dim3(8192), dim3(256), 0, 0, d.as<unsigned long long>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d.p, 32, hipMemcpyDeviceToHost));
+    return CHAD_OK;
+}
+
 chad_status chad_exchange_splitters(const uint64_t* heads, uint32_t world, uint64_t* splitters) {
     if (!heads || !splitters || world < 1 || world > uint32_t(kMaxRanks)) return fail(CHAD_ERR_INVALID_ARG, "null argument or world out of range");
     return xchg_splitters(heads, world, splitters) ? CHAD_OK : fail(CHAD_ERR_INVALID_ARG, "implausible block count in a head");

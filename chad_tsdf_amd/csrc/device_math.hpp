@@ -51,8 +51,38 @@ __device__ __forceinline__ I3 morton_decode(uint64_t mc) {
 // ---- small float helpers in the reference's evaluation order (glm 1.0.1 generic vec3 code) -------------------
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ F3 sub3(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+// ---- correctly rounded 1 / x without the IEEE division's ten-instruction expansion ------------------------------------------------
+// hipcc expands `1.0f / x` into v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup (and two mode switches): what the quotient
+// needs over the whole f32 range.  For a NORMAL x whose reciprocal is normal too -- biased exponent 1 .. 252, |x| in [2^-126, 2^126) --
+// v_rcp_f32 followed by ONE Newton step in FMAs, r + r (1 - x r), already IS the correctly rounded quotient: checked by enumeration
+// of all 2^32 bit patterns on gfx950 (scripts/rcp_exhaustive.hip; the library's own function is held against `/` the same way by
+// chad_selftest_reciprocal, tests/test_gpu_parity.py::test_fast_reciprocal_equals_the_ieee_quotient_for_every_float -- zero
+// mismatches inside the range, every input of exponent 253 / 254 outside it wrong: the range test below is exact).  Everything else
+// -- zero, denormals, huge values, infinities, NaN -- takes the IEEE sequence, in a branch a wave skips when none of its lanes needs it.
+// A ray pays for four reciprocals (octree.hpp:92-93: normalize, 1 / dir): 44 instructions of its set-up become 12 + the range tests.
+__device__ __forceinline__ float rcp_newton(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ bool rcp_newton_exact_for(float x) {   // biased exponent in [1, 252]; false for NaN
+    const float a = fabsf(x);
+    return a >= 1.17549435e-38f /* 2^-126 */ && a < 8.50705917e37f /* 2^126 */;
+}
+__device__ __forceinline__ float recip1(float x) {
+    float r;
+    if (__builtin_expect(rcp_newton_exact_for(x), 1)) r = rcp_newton(x);
+    else { asm volatile("; IEEE division for an operand outside [2^-126, 2^126)" ::: "memory"); r = 1.0f / x; }   // (the asm keeps the branch a branch)
+    return r;
+}
+__device__ __forceinline__ F3 recip3(F3 v) {   // 1 / v, component by component: one range test for the three
+    const float lo = __builtin_fminf(__builtin_fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)), hi = __builtin_fmaxf(__builtin_fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+    F3 r;
+    if (__builtin_expect(lo >= 1.17549435e-38f && hi < 8.50705917e37f, 1)) r = F3{rcp_newton(v.x), rcp_newton(v.y), rcp_newton(v.z)};   // (a NaN component -- excluded upstream, point_usable -- comes out NaN on either path)
+    else { asm volatile("; IEEE divisions for a direction with a zero, tiny or non-finite component" ::: "memory"); r = F3{1.0f / v.x, 1.0f / v.y, 1.0f / v.z}; }
+    return r;
+}
 __device__ __forceinline__ F3 unit3(F3 v) {  // glm::normalize: v * (1 / sqrt(dot(v, v)))
-    const float s = 1.0f / sqrtf(dot3(v, v));
+    const float s = recip1(sqrtf(dot3(v, v)));
     return {v.x * s, v.y * s, v.z * s};
 }
 __device__ __forceinline__ bool finite3(F3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
@@ -82,7 +112,7 @@ struct RayWalk {
 
     __device__ __forceinline__ void begin(F3 p, F3 pos, float res, float recip, float trunc) {
         const F3 dir = unit3(sub3(p, pos));                                     // :92
-        const F3 inv{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};                 // :93
+        const F3 inv = recip3(dir);                                             // :93
         const F3 a{p.x - dir.x * trunc, p.y - dir.y * trunc, p.z - dir.z * trunc};  // :94
         const F3 b{p.x + dir.x * trunc, p.y + dir.y * trunc, p.z + dir.z * trunc};  // :95
         cur = voxel_of(a, recip);                                               // :96
@@ -98,7 +128,7 @@ struct RayWalk {
     // the same traversal rule on an arbitrary segment from -> to with direction dir (the space-carving extension walks the
     // free part of a ray with it: map_kernels.hpp, k_carve)
     __device__ __forceinline__ void begin_segment(F3 from, F3 to, F3 dir, float res, float recip) {
-        const F3 inv{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+        const F3 inv = recip3(dir);
         cur = voxel_of(from, recip);
         last = voxel_of(to, recip);
         step = {sgn(last.x - cur.x), sgn(last.y - cur.y), sgn(last.z - cur.z)};

@@ -266,6 +266,28 @@ __global__ void k_walk_rays(const float* __restrict__ xyz, uint32_t n, F3 pos, f
     counts[i] = k;
 }
 
+// Self-test of device_math.hpp's reciprocal against the IEEE quotient, over ALL 2^32 f32 bit patterns: out[0] inputs inside the range
+// rcp_newton is used for, out[1] of those where it differs from 1.0f / x (must be 0), out[2] inputs -- any -- where recip1 differs
+// (must be 0; NaN equals NaN), out[3] inputs outside the range where rcp_newton WOULD differ (why the range test is there)
+__global__ void __launch_bounds__(256)
+k_selftest_reciprocal(unsigned long long* __restrict__ out) {
+    unsigned long long in_range = 0, bad_fast = 0, bad_any = 0, bad_outside = 0;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < (1ull << 32); i += uint64_t(gridDim.x) * blockDim.x) {
+        const float x = __uint_as_float(uint32_t(i));
+        const float want = 1.0f / x, fast = rcp_newton(x), got = recip1(x);
+        const bool same_fast = __float_as_uint(fast) == __float_as_uint(want) || (fast != fast && want != want);
+        if (rcp_newton_exact_for(x)) { in_range++; bad_fast += same_fast ? 0u : 1u; } else bad_outside += same_fast ? 0u : 1u;
+        bad_any += (__float_as_uint(got) == __float_as_uint(want) || (got != got && want != want)) ? 0u : 1u;
+    }
+    const unsigned long long v[4] = {in_range, bad_fast, bad_any, bad_outside};
+    for (int k = 0; k < 4; k++) {
+        unsigned long long t = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(&out[k], t);
+    }
+}
+
 // Morton codes of a frame's points in processing order (float4 x, y, z, index): the stage read-back of chad_map_last_frame
 __global__ void k_morton_codes_of_points(const float4* __restrict__ pts, uint32_t n, float recip, uint64_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

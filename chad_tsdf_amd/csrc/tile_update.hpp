@@ -133,7 +133,9 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) mark_exact_rows(m);   // the tile flush adds to the exact rows (map_kernels.hpp, kTableExactRows)
     if (kStamps) wall_lists = wall_clock64();
-    const uint32_t n_long = first_long[kListStripes], nitems = n_long + first_short[kListStripes];
+    // (wave-uniform: kept in scalar registers -- as vector registers they were the two the register allocator spilled to scratch)
+    const uint32_t n_long = uint32_t(__builtin_amdgcn_readfirstlane(int(first_long[kListStripes])));
+    const uint32_t nitems = n_long + uint32_t(__builtin_amdgcn_readfirstlane(int(first_short[kListStripes])));
     auto item_record = [&](uint32_t v) {
         const bool is_long = v < n_long;
         const uint32_t* first = is_long ? first_long : first_short;

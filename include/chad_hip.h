@@ -342,6 +342,13 @@ chad_status chad_morton_codes(const float* xyz, size_t n, float sdf_res, uint64_
  * order_out[i] its position in the input (equal keys keep input order).  Either output may be NULL. */
 chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, uint64_t* keys_out, uint32_t* order_out);
 
+/* Self-test: the reciprocal the ray set-up uses in place of hipcc's IEEE division sequence (v_rcp_f32 + one Newton step in FMAs for
+ * operands in [2^-126, 2^126), the IEEE sequence elsewhere: chad_tsdf_amd/csrc/device_math.hpp) against 1.0f / x for ALL 2^32 f32 bit
+ * patterns, on the device.  out[0] = inputs inside the fast range, out[1] = of those, results that differ (must be 0), out[2] = inputs of
+ * the whole f32 range for which the function the kernels call differs from the quotient (must be 0), out[3] = inputs OUTSIDE the range
+ * for which the fast sequence alone would be wrong (why the range test exists).  Bit-exact voxel lists (octree.hpp:92-118) rest on this. */
+chad_status chad_selftest_reciprocal(uint64_t out[4]);
+
 /* Stage entries for the CPU tests of the sparse multi-GPU exchange (no device needed): the host arithmetic every rank runs on the words
  * it has all-gathered (chad_tsdf_amd/csrc/exchange_plan.hpp).  chad_exchange_splitters: heads[world][65] -- per rank its block count
  * (low 32 bits of word 0; bit 32: two payload words per voxel) and 64 sample keys of its sorted list -- -> the world - 1 splitter keys

@@ -313,3 +313,20 @@ def test_overflow_of_a_closed_submap_stays_reported(chad):
     m.insert(small, far)
     m.sync()                                                       # nothing reported any more
     m.close()
+
+
+def test_fast_reciprocal_equals_the_ieee_quotient_for_every_float(chad):
+    """The ray set-up's four reciprocals (octree.hpp:92-93: glm::normalize and 1 / dir) are v_rcp_f32 + one Newton step where that is
+    the correctly rounded quotient and hipcc's IEEE sequence elsewhere (device_math.hpp).  The claim is checked here by enumeration:
+    all 2^32 bit patterns on the device, the library's own inline functions against `1.0f / x`."""
+    import ctypes as C
+
+    from chad_tsdf_amd import _lib
+
+    out = (C.c_uint64 * 4)()
+    _lib.check(_lib.load().chad_selftest_reciprocal(out), "selftest")
+    in_range, bad_fast, bad_any, bad_outside = list(out)
+    assert in_range == 2 * 252 * (1 << 23)      # both signs, biased exponents 1 .. 252, every mantissa
+    assert bad_fast == 0, f"{bad_fast} inputs inside [2^-126, 2^126) where rcp + Newton is not the IEEE quotient"
+    assert bad_any == 0, f"{bad_any} inputs where the kernels' reciprocal differs from 1.0f / x"
+    assert bad_outside > 0                      # outside the range the fast sequence IS wrong somewhere: the range test is needed
