@@ -549,7 +549,7 @@ def main():
             # takes 2 to 200+ ms depending on the box, and round 3's leg -- 59 GB of level growth by hipMalloc inside the 5 000 timed frames --
             # measured 0.29 ms per frame on the builder's boxes and 0.64 on the driver's.  cfg5.alloc below is the proof: calls the library
             # made between the two clock readings.  The warm-up (three roll-overs) makes the spare table and sizes the grow-only scratch.
-            pool = min(72 << 30, int(torch.cuda.mem_get_info()[0] * 0.45)) if dag_only else 0
+            pool = min(56 << 30, int(torch.cuda.mem_get_info()[0] * 0.45)) if dag_only else 0   # (the trajectory's levels peak at 53 GB inside it)
             m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22, dag_only=dag_only, dag_pool_bytes=pool)
             for k in range(min(36, frames_n)):
                 m5.insert(dev[k][0], dev[k][1], ready=True)

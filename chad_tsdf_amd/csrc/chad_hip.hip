@@ -452,7 +452,7 @@ chad_status ensure_aux_sort(chad_map* m, size_t n) {
     if (n <= m->aux_cap) return CHAD_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->close_stream) HIP_TRY(hipStreamSynchronize(m->close_stream));   // (the previous roll-over's sort)
-    size_t cap = std::max<size_t>(n, m->aux_cap * 2);
+    size_t cap = std::max<size_t>(n + n / 2, m->aux_cap * 2);   // (with room: the submaps of a trajectory differ by tens of per cent, and these seven allocations stall the device)
     cap = (cap + kSortTile - 1) / kSortTile * kSortTile;
     free_sort_buffers(m->aux_sort);
     m->aux_cap = 0;

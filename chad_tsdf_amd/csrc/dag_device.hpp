@@ -697,8 +697,13 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
     const size_t need_slots = 2 * (size_t(d.h_scalars[l].entries) + n) + 16;
     hipError_t e;
     if (need_slots > L.table_slots) {
+        // With the DAG's memory reserved up front (DeviceDag::pool) a growth is a rehash on the fold's stream and nothing else, so the table
+        // takes what keeps it between a quarter and half full; without a pool every growth is a hipMalloc that stalls the device (0.2 ms and
+        // more, box dependent), and the table takes room for three times as much again.  (cfg5's trajectory: 59 GB of levels with the
+        // generous policy, about half of it slack.)
+        const size_t room = d.pool.base ? 2 : 4;
         size_t slots = L.table_slots;
-        while (slots < 4 * need_slots) slots <<= 1;   // (room for three times as much again: growth stalls the fold -- an allocation, a rehash and a wait on the host's side, 0.2 ms and more)
+        while (slots < room * need_slots) slots <<= 1;
         slots = std::min<size_t>(slots, size_t(1) << 31);
         if (need_slots > (size_t(1) << 31)) return hipErrorOutOfMemory;   // (a table of 2^31 slots: a billion values in one level)
         uint32_t* bigger = nullptr;
@@ -714,7 +719,8 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
     const size_t need_words = size_t(d.h_scalars[l].size) + n * words_each + 16;
     if (need_words > L.raw_capacity) {
         size_t words = L.raw_capacity;
-        while (words < 2 * need_words) words += words / 2 + 1024;
+        if (d.pool.base) words = need_words + need_words / 2 + 4096;   // (a copy inside the pool, on the fold's stream: half as much room again)
+        else while (words < 2 * need_words) words += words / 2 + 1024;
         if (need_words + n >= (size_t(1) << 32)) return hipErrorOutOfMemory;   // addresses are 32 bits, as in the reference (levels.hpp:50, :117); the batch's pending marks lie above them
         words = std::min<size_t>(words, (size_t(1) << 32) - 1 - n);
         const size_t unit = cluster ? 8 : 4;
