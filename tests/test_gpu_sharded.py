@@ -343,3 +343,65 @@ def test_cfg5_sharded_dag_only_equals_one_gpu_word_for_word(tmp_path, world):
         per_rollover.append(sent / exchanges / 1e6)
     print(f"world {world}: MB handed to the exchange per roll-over and rank: {[round(b, 1) for b in per_rollover]} (last union: {union_blocks} blocks)")
     assert max(per_rollover) <= 80.0 and sum(per_rollover) / world <= 60.0
+
+
+def _mixed_stream():
+    """_stream() with one frame of 300 k points among the 20 k-point ones: in the scatter form a frame of more than 2^18 points adds to the
+    EXACT rows (two atomics per observation), the others to the staging words -- the rank that integrates it sends two words per voxel,
+    the other rank one."""
+    from chad_tsdf_amd import synth
+
+    out = []
+    for k in range(26):
+        pts, _ = synth.cfg3_frame(5 * k, 300_000 if k == 3 else 20_000)
+        out.append((pts, np.array([-12.0 + 0.25 * k, 0.1, 0.0], dtype=np.float32)))
+    return out
+
+
+def _mixed_rank(rank, world, port, outdir, update_mode):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chad_tsdf_amd.sharded import ShardedTSDFMap
+
+    sm = ShardedTSDFMap(0.05, 0.10, dag_only=True, dag_saturate_weights=True, update_mode=update_mode)
+    for k, (pts, pos) in enumerate(_mixed_stream()):
+        sm.insert(pts if k % world == rank else None, pos)
+    sm.merge_and_close()
+    sm.local.sync()
+    if rank == 0:
+        levels = {f"level{l}": sm.local.dag_level(l) for l in range(21)}
+        np.savez(os.path.join(outdir, "mixed_rank0_dag.npz"), roots=np.array([sm.local.dag_roots(s) for s in range(2)], np.uint32), **levels)
+    sm.local.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("update_mode", [1, 2])
+def test_sparse_exchange_with_exact_rows_and_weight_words(tmp_path, update_mode):
+    """The sparse exchange's other payload shapes: two words per voxel (a table whose exact rows are in use: every frame under the tiled
+    update, update_mode 2; under the scatter form, update_mode 1, only the rank that integrates the 300 k-point frame -- so the two ranks
+    send DIFFERENT widths) and the weight clusters travelling beside the signed-distance clusters (CHAD_FLAG_DAG_SATURATE_WEIGHTS).
+    Rank 0's DAG == the single GPU's, word for word."""
+    import torch.multiprocessing as mp
+
+    import chad_tsdf_amd
+
+    world = 2
+    mp.spawn(_mixed_rank, args=(world, 29571 + update_mode, str(tmp_path), update_mode), nprocs=world, join=True)
+    single = chad_tsdf_amd.TSDFMap(0.05, 0.10, dag_only=True, dag_saturate_weights=True, update_mode=update_mode)
+    for pts, pos in _mixed_stream():
+        single.insert(pts, pos)
+    single.close_submap()
+    single.finalize()
+    assert single.closed_submaps == 2
+    got = np.load(tmp_path / "mixed_rank0_dag.npz")
+    assert np.array_equal(got["roots"], np.array([single.dag_roots(s) for s in range(2)], np.uint32))
+    for l in range(21):
+        assert np.array_equal(got[f"level{l}"], single.dag_level(l)), f"level {l} differs from the single-GPU DAG"
+    assert len(single.dag_level(20)) > 1000
+    single.close()
