@@ -353,9 +353,9 @@ void free_sort_buffers(RadixSortBuffers& b) {
     (void)chad_free(b.keys[0]); (void)chad_free(b.keys[1]); (void)chad_free(b.idx[0]); (void)chad_free(b.idx[1]);
     (void)chad_free(b.points[0]); (void)chad_free(b.points[1]);
     (void)chad_free(b.hist_part); (void)chad_free(b.digit_base); (void)chad_free(b.tile_status);
-    const uint32_t resident = b.resident;
+    const uint32_t resident = b.resident, rest_limit = b.rest_limit;
     b = RadixSortBuffers{};
-    b.resident = resident;
+    b.resident = resident; b.rest_limit = rest_limit;
 }
 
 void free_frame_buffers(FrameSlot& f) {
@@ -1683,6 +1683,14 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->aux_sort.resident = m->aux_resident;
     if (std::getenv("CHAD_DEBUG_SORT_TICKETS")) m->sort_resident = 0u;   // experiments: every sort takes tickets
     for (uint32_t k = 0; k < m->n_slots; k++) m->slot[k].sort.resident = m->sort_resident / (m->serial ? 1u : m->n_slots);
+    {   // the catch-all of a frame's sort runs inside k_frame_gather: its participants must be resident THERE (that kernel's occupancy, three
+        // quarters of it, shared among the frames in flight; its grid is at most 2 048 workgroups) -- ADVICE r3
+        int per_cu8 = 0, per_cu9 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, k_frame_gather<kRadixBits>, 256, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu9, k_frame_gather<kWideBits>, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu8 = per_cu9 = 0; }
+        const uint32_t hosts = std::min<uint32_t>(2048u, uint32_t(std::max(0, std::min(per_cu8, per_cu9))) * m->cu_count * 3u / 4u) / (m->serial ? 1u : m->n_slots);
+        for (uint32_t k = 0; k < m->n_slots; k++) m->slot[k].sort.rest_limit = hosts;
+    }
     CREATE_TRY(chad_malloc(&m->d_cursor, 8));   // ([1]: k_table_keys' cursor on close_stream, beside whatever the map's stream compacts)
     if (times_anything(m))
         for (auto& set : m->ev) for (auto& e : set) CREATE_TRY(hipEventCreate(&e));

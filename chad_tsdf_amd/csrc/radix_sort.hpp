@@ -89,6 +89,9 @@ struct RadixSortBuffers {
     // RUNS (the host divides the kernel's real occupancy x CU count by the number of sorts in flight): grids up to this size
     // may take their tile from blockIdx and may end in grid barriers; larger ones take tickets.  0 = unknown: always tickets.
     uint32_t resident;
+    // ... and of the kernel that FOLLOWS a frame's sort and hosts its catch-all (k_frame_gather, radix_rest_points): that kernel's own
+    // occupancy share, so that the catch-all's participants are resident inside it too.  0 = no catch-all: every pass gets its launch.
+    uint32_t rest_limit;
 };
 // Per-sort side channels (all optional).
 struct RadixSortSignals {
@@ -497,22 +500,31 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
                                   const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits, FrameLauncher* recorder = nullptr, RadixRest* rest_out = nullptr) {
     if (rest_out) *rest_out = RadixRest{};
     if (n == 0) return;
+    // RadixSortSignals::dep (passes 5 and 6 skipped when their digits are functions of the top digit) is only sound for a sort that takes
+    // its own histograms (they compute the dep words), runs all eight passes and gives every pass its own launch (pass 7's launch
+    // re-zeroes the words): any other caller's request is dropped here rather than trusted
+    RadixSortSignals checked = sig;
+    if (checked.dep && !(hist_blocks == 0 && passes == uint32_t(kMaxPasses) && !(pass_limit && launch_passes && launch_passes < passes))) checked.dep = nullptr;
+    const RadixSortSignals& sig_ = checked;
     FrameLauncher eager;   // (the launches go through `recorder` when the caller records or replays its chain as a graph: frame_graph.hpp)
     eager.stream = stream;
-    FrameLauncher& L = recorder && !sig.pass_events ? *recorder : eager;
+    FrameLauncher& L = recorder && !sig_.pass_events ? *recorder : eager;
     const uint32_t tiles = radix_tiles(n);
     const bool all_resident = b.resident != 0u && tiles <= b.resident;
     uint32_t* ticket = b.tile_status + radix_status_words(tiles) - 64;
     if (hist_blocks == 0) {
         hipLaunchKernelGGL(k_radix_histograms, dim3(kHistBlocks), dim3(kSortThreads), 0, stream, b.keys[0], n, passes, pass_limit, b.hist_part, b.tile_status,
-                           uint32_t(radix_status_words(tiles)), sig.dep);
+                           uint32_t(radix_status_words(tiles)), sig_.dep);
     }
     // hist_blocks != 0: the caller's keys kernel has already added its digit counts into the striped totals (k_frame_keys)
     const uint32_t base_stripes = hist_blocks ? kBaseStripes : 1u;
     if (!hist_blocks) hipLaunchKernelGGL(k_radix_bases, dim3(passes * 4), dim3(4 * kRadix), 0, stream, b.hist_part, uint32_t(kHistBlocks), passes, pass_limit, b.digit_base);
     const bool hinted = pass_limit && launch_passes && launch_passes < passes && all_resident;
     // a grid too large to be resident at once: the hinted launches; whatever the frame needs beyond them is left to the caller's next kernel (RadixRest)
-    const bool with_rest = pass_limit && launch_passes && launch_passes < passes && !all_resident && b.resident != 0u && rest_out != nullptr;   // (nobody to take the rest: every pass gets its launch)
+    // (the catch-all's barrier needs its participants resident at once INSIDE the caller's next kernel: that kernel's own share of the
+    // chip bounds them too -- RadixSortBuffers::rest_limit, 0 = nobody can host a catch-all: every pass gets its launch)
+    const uint32_t rest_participants = std::min(std::min(tiles, b.resident), b.rest_limit);
+    const bool with_rest = pass_limit && launch_passes && launch_passes < passes && !all_resident && rest_participants != 0u && rest_out != nullptr;   // (nobody to take the rest: every pass gets its launch)
     const uint32_t launches = hinted || with_rest ? launch_passes : passes;
     for (uint32_t p = 0; p < launches; p++) {
         const bool to_limit = hinted && p + 1 == launches;
@@ -523,12 +535,12 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
         // behind the previous frame's -- 36-57 us of waiting per 200 k-point frame, scripts/timeline.py -- for a barrier that a
         // frame reaches only when its key has outgrown the hint.)
         auto launch = [&](auto kernel) {
-            if (sig.pass_events)
-                hipExtLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, sig.pass_events[2 * p], sig.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                                      to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
+            if (sig_.pass_events)
+                hipExtLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, sig_.pass_events[2 * p], sig_.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                                      to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig_);
             else
                 L(kernel, dim3(tiles), dim3(kSortThreads), 0, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                  to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig);
+                  to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig_);
         };
         if (digit_bits == uint32_t(kWideBits)) launch(k_radix_onesweep<P, kWideBits>); else launch(k_radix_onesweep<P, kRadixBits>);
     }
@@ -537,12 +549,12 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
             if (rest_out) {
                 rest_out->keys[0] = b.keys[0]; rest_out->keys[1] = b.keys[1]; rest_out->points[0] = pay[0]; rest_out->points[1] = pay[1];
                 rest_out->n = n; rest_out->first_pass = launches; rest_out->tiles = tiles; rest_out->base_stripes = base_stripes;
-                rest_out->participants = tiles < b.resident ? tiles : b.resident;
-                rest_out->digit_base = b.digit_base; rest_out->tile_status = b.tile_status; rest_out->tile_ticket = ticket; rest_out->first_src = first_src; rest_out->fault = sig.fault;
+                rest_out->participants = rest_participants;
+                rest_out->digit_base = b.digit_base; rest_out->tile_status = b.tile_status; rest_out->tile_ticket = ticket; rest_out->first_src = first_src; rest_out->fault = sig_.fault;
             }
         }
     }
-    if (sig.launches_out) *sig.launches_out = launches;
+    if (sig_.launches_out) *sig_.launches_out = launches;
 }
 inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream, uint32_t hist_blocks = 0,
                                uint32_t launch_passes = 0, const RadixSortSignals& sig = RadixSortSignals{}) {

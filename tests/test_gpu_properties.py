@@ -213,8 +213,9 @@ def test_thousands_of_observations_of_one_voxel_in_one_frame(chad, oracle):
 
 def test_three_frames_in_flight_all_outgrow_the_enqueued_sort_passes(chad):
     """Three consecutive large frames whose extent needs more sort passes than the previous frames' hint: their grids (489 tiles)
-    are too large to be resident beside each other, so each is finished by its catch-all launch (k_radix_onesweep_rest: a
-    resident-sized grid drawing tiles by ticket, grid barriers between the passes), all three in flight at once.
+    are too large to be resident beside each other, so each is finished by its catch-all (radix_rest_points, the prologue of the
+    k_frame_gather launch that follows the sort: as many of its workgroups as are certainly resident draw tiles by ticket, with a
+    barrier among them behind every pass), all three in flight at once.
     Device-resident, back to back, no synchronisation in between."""
     import torch
 
