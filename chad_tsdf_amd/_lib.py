@@ -128,6 +128,7 @@ SYMBOLS = {
     "chad_map_attach_comm": (_i32, [_vp, _vp]),
     "chad_map_merge_and_close": (_i32, [_vp, _vp]),
     "chad_map_finalize": (_i32, [_vp]),
+    "chad_map_dag_reserve": (_i32, [_vp, _vp, _vp]),
     "chad_map_dag_roots": (_i32, [_vp, _i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "chad_map_dag_level_words": (_i32, [_vp, C.c_uint32, C.POINTER(_sz)]),
     "chad_map_dag_level_copy": (_i32, [_vp, C.c_uint32, _vp, _sz]),

@@ -49,7 +49,7 @@ inline hipError_t chad_free(void* p) {
     return e;
 }
 
-// One reservation, handed out in pieces: first fit over a list of free ranges ordered by address, neighbours merged on release.  A few
+// One reservation, handed out in pieces: best fit over a list of free ranges ordered by address, neighbours merged on release.  A few
 // hundred allocations over a map's life (twenty-one levels, each doubling a dozen times): the list stays short.
 struct DevPool {
     char* base = nullptr;
@@ -76,15 +76,19 @@ struct DevPool {
     void* take(size_t bytes) {   // nullptr: no range of that length left
         if (!base) return nullptr;
         bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) & ~(kAlign - 1);
-        for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it) {
-            if (it->second < bytes) continue;
-            const size_t at = it->first, len = it->second;
-            free_ranges.erase(it);
-            if (len > bytes) free_ranges[at + bytes] = len - bytes;
-            used += bytes; peak = std::max(peak, used);
-            return base + at;
+        auto best = free_ranges.end();   // best fit: small requests fill small holes, the large ranges stay whole for the levels that grow into gigabytes
+        for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it)
+            if (it->second >= bytes && (best == free_ranges.end() || it->second < best->second)) best = it;
+        if (best == free_ranges.end()) return nullptr;
+        const size_t at = best->first, len = best->second;
+        free_ranges.erase(best);
+        used += bytes; peak = std::max(peak, used);
+        if (bytes >= cap / 32) {   // the few large stores are carved from the top of their range, the many small ones from the bottom: they meet last
+            if (len > bytes) free_ranges[at] = len - bytes;
+            return base + at + (len - bytes);
         }
-        return nullptr;
+        if (len > bytes) free_ranges[at + bytes] = len - bytes;
+        return base + at;
     }
     void give(void* p, size_t bytes) {
         bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) & ~(kAlign - 1);

@@ -2519,6 +2519,15 @@ chad_status chad_map_dag_level_copy(chad_map* m, uint32_t level, void* out, size
     return CHAD_OK;
 }
 
+chad_status chad_map_dag_reserve(chad_map* m, const uint64_t entries[CHAD_DAG_NODE_LEVELS + 1], const uint64_t words[CHAD_DAG_NODE_LEVELS + 1]) {
+    if (!m || !entries || !words) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    for (uint32_t l = 0; l <= kDagDepth; l++) {
+        if (entries[l] >= (1ull << 30) || words[l] >= (1ull << 32)) return fail(CHAD_ERR_INVALID_ARG, "a level of more than 2^30 values or 2^32 words");
+        m->ddag.hint_entries[l] = entries[l]; m->ddag.hint_words[l] = words[l];
+    }
+    return CHAD_OK;   // (takes effect when the DAG's stores are made: the first fold of a map, or the first after chad_map_reset)
+}
+
 chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
     if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);

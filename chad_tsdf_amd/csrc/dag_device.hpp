@@ -623,6 +623,7 @@ struct DeviceDag {
                                                // whole device -- the frames in flight too)
     size_t outgrown_bytes = 0;
     uint64_t growths = 0;                      // tables and stores that have been replaced by bigger ones so far
+    uint64_t hint_entries[kDagDepth + 1] = {}, hint_words[kDagDepth + 1] = {};   // chad_map_dag_reserve: what the levels are expected to hold in the end -- they are made that size
     bool ready = false;
 
     // a table or store for a level: from the pool while it lasts
@@ -677,6 +678,12 @@ inline hipError_t dag_device_init(DeviceDag& d, hipStream_t s) {
     for (uint32_t l = 0; l <= kDagDepth; l++) {
         DagLevelDev& L = d.level[l];
         L.table_slots = 1u << 19; L.raw_capacity = 1u << 19;   // (2 + 2..4 MB per level: a room-sized submap's 75 k cluster candidates fit without growing anything)
+        if (d.hint_entries[l] || d.hint_words[l]) {   // chad_map_dag_reserve: the level at its expected final size, from the start (a table at most half full)
+            uint64_t slots = L.table_slots;
+            while (slots < 2 * (d.hint_entries[l] + d.hint_entries[l] / 16) + 16 && slots < (1ull << 31)) slots <<= 1;
+            L.table_slots = uint32_t(slots);
+            L.raw_capacity = uint32_t(std::min<uint64_t>(std::max<uint64_t>(L.raw_capacity, d.hint_words[l] + d.hint_words[l] / 16 + 4096), (1ull << 32) - 1));
+        }
         if ((e = d.store_alloc(reinterpret_cast<void**>(&L.table), size_t(L.table_slots) * 4)) != hipSuccess) return e;
         if ((e = d.store_alloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4))) != hipSuccess) return e;
         if ((e = hipMemsetAsync(L.table, 0, size_t(L.table_slots) * 4, s)) != hipSuccess) return e;

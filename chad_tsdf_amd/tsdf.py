@@ -267,6 +267,23 @@ class TSDFMap:
         """Fold every closed submap that is not in the DAG yet into it (lazy; the dag_* calls do it themselves)."""
         _lib.check(self._lib.chad_map_finalize(self._h), "TSDFMap.finalize")
 
+    def dag_sizes(self):
+        """(entries u64 [21], words u64 [21]) of the DAG's levels as they stand: what dag_reserve() of a later map (or of this one after a
+        reset) takes."""
+        st = self.dag_stats()
+        words = np.zeros(21, dtype=np.uint64)
+        n = C.c_size_t()
+        for level in range(21):
+            _lib.check(self._lib.chad_map_dag_level_words(self._h, level, C.byref(n)), "TSDFMap.dag_sizes")
+            words[level] = n.value
+        return np.asarray(st["uniques"], dtype=np.uint64), words
+
+    def dag_reserve(self, entries, words):
+        """Make the DAG's levels their expected final size from the start (chad_map_dag_reserve)."""
+        e = np.ascontiguousarray(entries, dtype=np.uint64).reshape(21)
+        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(21)
+        _lib.check(self._lib.chad_map_dag_reserve(self._h, e.ctypes.data, w.ctypes.data), "TSDFMap.dag_reserve")
+
     def dag_roots(self, submap: int):
         """(root_addr_tsdf, root_addr_weight) of a closed submap -- submap.hpp:108-109."""
         rt, rw = C.c_uint32(), C.c_uint32()

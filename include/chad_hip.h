@@ -252,6 +252,12 @@ typedef struct chad_dag_stats {
                                      * NodeLevels in host memory; here Submap::finalize runs on the device, so the DAG lives there */
 } chad_dag_stats;
 chad_status chad_map_finalize(chad_map* map);
+/* Expected final size of the DAG's levels: entries[l] values (chad_dag_stats.uniques of an earlier run of the same kind of trajectory) and
+ * words[l] (chad_map_dag_level_words), l = 0..19 the node levels, 20 the leaf clusters.  The levels' stores and look-up tables are then
+ * made that size (plus a sixteenth) when the DAG is created -- the map's first fold, or the first after chad_map_reset -- and never grow
+ * on the way there: no copy, no rehash, and with chad_options.dag_pool_bytes no allocation either.  The counterpart of sizing
+ * VirtualArray's reservation (virtual_array.hpp:16-19) for the job at hand.  A level that outgrows its hint grows as usual. */
+chad_status chad_map_dag_reserve(chad_map* map, const uint64_t entries[21], const uint64_t words[21]);
 /* Submap::root_addr_tsdf / root_addr_weight (submap.hpp:108-109) of closed submap `submap`: addresses into level 0 */
 chad_status chad_map_dag_roots(chad_map* map, int32_t submap, uint32_t* root_tsdf, uint32_t* root_weight);
 chad_status chad_map_dag_level_words(chad_map* map, uint32_t level, size_t* words);

@@ -258,3 +258,39 @@ def test_block_key_order_near_and_far_from_the_origin(chad, oracle, offset):
     for k in range(closed):
         assert kept.dag_roots(k) == gone.dag_roots(k) == o.dag_roots(k)
     kept.close(); gone.close()
+
+
+def test_dag_pool_and_reserved_levels_allocate_nothing_and_change_nothing(chad):
+    """chad_options.dag_pool_bytes + chad_map_dag_reserve (the VirtualArray-style reservation, virtual_array.hpp:16-19): a trajectory of
+    roll-overs under CHAD_FLAG_DAG_ONLY runs a second time on the same map -- after chad_map_reset, its levels made their final size
+    from the start inside the pool -- without a single hipMalloc / hipFree and without a level growing, and builds the same DAG word
+    for word as a plain map that grows its levels by hipMalloc."""
+    from chad_tsdf_amd import synth
+
+    frames = [(synth.cfg3_frame(5 * k, 20_000)[0], np.array([-12.0 + 0.6 * k, 0.1, 0.0], np.float32)) for k in range(40)]   # a roll-over every nine frames
+    plain = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    pooled = chad.TSDFMap(0.05, 0.10, dag_only=True, dag_pool_bytes=256 << 20)
+    for pts, pos in frames:
+        plain.insert(pts, pos); pooled.insert(pts, pos)
+    plain.close_submap(); pooled.close_submap()
+    plain.finalize(); pooled.finalize()
+    want = [plain.dag_level(l) for l in range(21)]
+    roots = [plain.dag_roots(s) for s in range(plain.closed_submaps)]
+    assert all(np.array_equal(pooled.dag_level(l), want[l]) for l in range(21))
+    first = pooled.pipeline_times()
+    assert first["dag_pool_bytes"] == 256 << 20 and 0 < first["dag_pool_peak"] <= first["dag_pool_bytes"]
+    entries, words = pooled.dag_sizes()
+    assert int(words[20]) == len(want[20]) and int(entries[20]) > 100
+    pooled.reset()
+    pooled.dag_reserve(entries, words)
+    pooled.sync(); pooled.pipeline_times()
+    for pts, pos in frames:
+        pooled.insert(pts, pos)
+    pooled.close_submap()
+    pooled.finalize()
+    again = pooled.pipeline_times()
+    assert again["mallocs"] == 0 and again["frees"] == 0 and again["level_growths"] == 0, again
+    assert again["folds_completed"] == len(roots) and again["step_b_ms"] > 0
+    assert all(np.array_equal(pooled.dag_level(l), want[l]) for l in range(21))
+    assert [pooled.dag_roots(s) for s in range(len(roots))] == roots
+    plain.close(); pooled.close()
