@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -703,6 +704,10 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
     const bool cluster = l == kDagDepth;
     const size_t need_slots = 2 * (size_t(d.h_scalars[l].entries) + n) + 16;
     hipError_t e;
+    static const bool report = std::getenv("CHAD_DEBUG_DAG_GROWTH") != nullptr;   // which level grows, and why (stderr)
+    if (report && (need_slots > L.table_slots || size_t(d.h_scalars[l].size) + n * words_each + 16 > L.raw_capacity))
+        std::fprintf(stderr, "chad: DAG level %u grows: %zu candidates x %u words; table %u slots (needs %zu), store %u words (needs %zu); entries %u, size %u\n", l, n, words_each,
+                     L.table_slots, need_slots, L.raw_capacity, size_t(d.h_scalars[l].size) + n * words_each + 16, d.h_scalars[l].entries, d.h_scalars[l].size);
     if (need_slots > L.table_slots) {
         // With the DAG's memory reserved up front (DeviceDag::pool) a growth is a rehash on the fold's stream and nothing else, so the table
         // takes what keeps it between a quarter and half full; without a pool every growth is a hipMalloc that stalls the device (0.2 ms and
@@ -896,6 +901,7 @@ inline hipError_t dag_fold_advance(DeviceDag& d, DagFold& f, hipStream_t s, bool
     for (uint32_t l = 0; l <= kDagDepth; l++) {
         const size_t entries = d.h_scalars[l].entries - before[l].entries, words = d.h_scalars[l].size - before[l].size;
         if (!entries) continue;
+        if (d.hint_entries[l] || d.hint_words[l]) continue;   // (a level made its expected final size needs no room "for one more submap like the last": if the hint was too small it grows when a fold really needs it)
         if ((e = dag_level_reserve(d, l, entries + entries / 2, uint32_t((words + entries - 1) / entries) + 1u, s)) != hipSuccess) return e;
     }
     return hipSuccess;

@@ -256,7 +256,9 @@ chad_status chad_map_finalize(chad_map* map);
  * words[l] (chad_map_dag_level_words), l = 0..19 the node levels, 20 the leaf clusters.  The levels' stores and look-up tables are then
  * made that size (plus a sixteenth) when the DAG is created -- the map's first fold, or the first after chad_map_reset -- and never grow
  * on the way there: no copy, no rehash, and with chad_options.dag_pool_bytes no allocation either.  The counterpart of sizing
- * VirtualArray's reservation (virtual_array.hpp:16-19) for the job at hand.  A level that outgrows its hint grows as usual. */
+ * VirtualArray's reservation (virtual_array.hpp:16-19) for the job at hand.  A level that outgrows its hint grows as usual -- and a
+ * fold asks for room for the worst case of the submap in hand (every candidate a new value, nine words per node candidate) on top of
+ * what the level holds: for small DAGs pass a hint with that room in it. */
 chad_status chad_map_dag_reserve(chad_map* map, const uint64_t entries[21], const uint64_t words[21]);
 /* Submap::root_addr_tsdf / root_addr_weight (submap.hpp:108-109) of closed submap `submap`: addresses into level 0 */
 chad_status chad_map_dag_roots(chad_map* map, int32_t submap, uint32_t* root_tsdf, uint32_t* root_weight);
