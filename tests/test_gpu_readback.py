@@ -247,6 +247,48 @@ def test_mesh_of_the_reference_demo_sphere(chad, tmp_path, from_dag):
     m.close()
 
 
+def test_mesh_vertices_on_cell_edges_are_the_marching_cubes_vertices_of_the_references_grid(chad, oracle):
+    """f3, what can be pinned of the triangulation without LVR2: the VERTEX SET.  Whatever case table a marching-cubes box uses (LVR2's
+    FastBox::getSurface, called at lvr2.cpp:247), its vertices are the points where sd = 0 crosses one of the twelve edges of a complete
+    cell, placed by linear interpolation between the edge's two query points -- a definition that involves no table.  Computed here in
+    f64 from the ORACLE's ChadGrid (lvr2.cpp:15-133 restated: cells, corner values in the vertex order of lvr2.cpp:92-102), that set
+    must be exactly the set of the device mesh's vertices that lie on cell edges (the marching tetrahedra of mesh_kernels.hpp add
+    vertices on face and body diagonals, which no marching-cubes mesh has; a cube's twelve edges are edges of the Kuhn split too).
+    A restated definition, not upstream's output: "agreement with the oracle", like the grid itself."""
+    from scipy.spatial import cKDTree
+
+    res, trunc = 0.05, 0.10
+    pts, pos = sphere_scan(400_000)
+    m = chad.TSDFMap(res, trunc, mesh_from_dag=True)
+    m.insert(pts, pos)
+    mc, sd, w = m.export_leaves()
+    m.close_submap()
+    o = oracle.OracleMap(res, trunc)
+    o.close_submap_from_leaves(mc, sd, w)
+    codes, corners, _ = o.chad_grid(0)
+    low = chad.tsdf.decode_morton(codes).astype(np.float64)                       # lowest corner of every complete cell, in voxels
+    off = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float64)   # lvr2.cpp:92-102
+    edges = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+    want = []
+    d = corners.astype(np.float64)
+    for a, b in edges:
+        cross = (d[:, a] < 0) != (d[:, b] < 0)                                     # inside = negative signed distance (behind the surface)
+        t = d[cross, a] / (d[cross, a] - d[cross, b])
+        pa, pb = (low[cross] + off[a]) * res, (low[cross] + off[b]) * res
+        want.append(pa + (pb - pa) * t[:, None])
+    want = np.unique(np.round(np.concatenate(want), 7), axis=0)                    # an edge belongs to up to four cells
+    v, tri = m.mesh(0)
+    v = v.astype(np.float64)
+    on_lattice = np.abs(v / res - np.round(v / res)) < 1e-4
+    on_edge = on_lattice.sum(axis=1) >= 2                                          # two coordinates on the voxel lattice: a cell edge
+    assert 10_000 < len(want) and 0.3 < on_edge.mean() < 0.9
+    far_from_mesh = cKDTree(v[on_edge]).query(want)[0]
+    far_from_want = cKDTree(want).query(v[on_edge])[0]
+    assert far_from_mesh.max() < 5e-6, f"{(far_from_mesh >= 5e-6).sum()} marching-cubes vertices have no counterpart in the mesh"
+    assert far_from_want.max() < 5e-6, f"{(far_from_want >= 5e-6).sum()} mesh vertices on cell edges are no marching-cubes vertices"
+    m.close()
+
+
 @pytest.mark.parametrize("scene", ["sphere", "cfg2"])
 def test_mesh_grid_is_the_references_chad_grid(chad, oracle, scene):
     """f3, the half that IS reference code: ChadGrid's constructor (lvr2.cpp:15-133) walks the submap's DAG, makes a query point per
