@@ -36,4 +36,7 @@ echo "cfg5 done"
 # ... and the same trajectory kept as its DAG only (CHAD_FLAG_DAG_ONLY: the closing table straight to cluster words, the fold on the device)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cfg5dag_trace" -- python3 scripts/cfg5_dagonly.py --frames 110 > "$out/cfg5dag_trace.log" 2>&1
 echo "cfg5 dag-only done"
+# ... and a frame-sharded map's SPARSE exchange at cfg5's scale (one process, a silent second rank: scripts/exchange_trace.py)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cfg5xchg_trace" -- python3 scripts/exchange_trace.py --frames 110 > "$out/cfg5xchg_trace.log" 2>&1
+echo "cfg5 exchange done"
 python3 scripts/summarise_profiles.py "$out" "$tag"

@@ -114,3 +114,6 @@ if glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursi
 dag = sorted(glob.glob(os.path.join(src, "cfg5dag_trace", "**", "*kernel_stats.csv"), recursive=True))
 if dag:
     shutil.copy(dag[-1], os.path.join(prof, f"{tag}_cfg5_dagonly_kernel_stats.csv"))
+xchg = sorted(glob.glob(os.path.join(src, "cfg5xchg_trace", "**", "*kernel_stats.csv"), recursive=True))
+if xchg:
+    shutil.copy(xchg[-1], os.path.join(prof, f"{tag}_cfg5_exchange_kernel_stats.csv"))
