@@ -107,26 +107,39 @@ k_xchg_pack(MapView m, const uint32_t* __restrict__ slot_sorted, const uint64_t*
     const bool pack_only = table_pack_only(m);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t r = wave; r < nb; r += waves) {
-        uint32_t d = 0;
-        for (uint32_t k = 1; k < world; k++) d = r >= first_block[k] ? k : d;
-        const uint32_t first = first_block[d], n_d = first_block[d + 1] - first, i = r - first;
-        char* base = send + slices.off[d];
-        uint64_t* keys = reinterpret_cast<uint64_t*>(base);
-        uint64_t* masks = keys + n_d;
-        uint32_t* firsts = reinterpret_cast<uint32_t*>(masks + n_d);
-        uint64_t* payload = reinterpret_cast<uint64_t*>(base + 16 * size_t(n_d) + xchg_pad8(4 * size_t(n_d)));
-        const uint64_t bits = mask[r];
-        const uint32_t w0 = prefix[r] - prefix[first];
-        if (lane == 0) { keys[i] = keys_sorted[r]; masks[i] = bits; firsts[i] = w0; }
-        if ((bits >> lane) & 1ull) {
-            const size_t at = size_t(slot_sorted[r]) * 64 + lane;
-            const size_t j = size_t(w0) + uint32_t(__popcll(bits & ((1ull << lane) - 1ull)));
+    // sixty-four blocks per turn: every lane gathers ITS block's place in the slices (destination, index there, first payload word) and
+    // writes its header words; then the wave copies the blocks' voxels one block after the other, a lane per voxel (a wave doing all of
+    // that for one block at a time spent its time in half a dozen dependent loads per block)
+    for (uint32_t r0 = wave * 64u; r0 < nb; r0 += waves * 64u) {
+        const uint32_t r = r0 + lane;
+        uint32_t slot = 0, w_lo = 0, w_hi = 0, mask_lo = 0, mask_hi = 0;
+        if (r < nb) {
+            uint32_t d = 0;
+            for (uint32_t k = 1; k < world; k++) d = r >= first_block[k] ? k : d;
+            const uint32_t first = first_block[d], n_d = first_block[d + 1] - first, i = r - first;
+            char* base = send + slices.off[d];
+            uint64_t* keys = reinterpret_cast<uint64_t*>(base);
+            uint64_t* masks = keys + n_d;
+            uint32_t* firsts = reinterpret_cast<uint32_t*>(masks + n_d);
+            const uint64_t bits = mask[r];
+            const uint32_t w0 = prefix[r] - prefix[first];
+            keys[i] = keys_sorted[r]; masks[i] = bits; firsts[i] = w0;
+            const uint64_t word0 = (uint64_t(base - send) + 16 * size_t(n_d) + xchg_pad8(4 * size_t(n_d))) / 8 + uint64_t(w0) * (wide ? 2u : 1u);   // the block's first payload word, counted from `send`
+            slot = slot_sorted[r]; w_lo = uint32_t(word0); w_hi = uint32_t(word0 >> 32); mask_lo = uint32_t(bits); mask_hi = uint32_t(bits >> 32);
+        }
+        uint64_t* words = reinterpret_cast<uint64_t*>(send);
+        const uint32_t here = min(64u, nb - r0);
+        for (uint32_t j = 0; j < here; j++) {
+            const uint64_t bits = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(mask_lo), int(j)))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(mask_hi), int(j)))) << 32);
+            if (!((bits >> lane) & 1ull)) continue;
+            const uint64_t word0 = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(w_lo), int(j)))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(w_hi), int(j)))) << 32);
+            const size_t at = size_t(uint32_t(__builtin_amdgcn_readlane(int(slot), int(j)))) * 64 + lane;
+            const size_t k = uint32_t(__popcll(bits & ((1ull << lane) - 1ull)));
             if (wide) {
                 long long units; uint32_t cnt;
                 voxel_totals(m, at, &units, &cnt, pack_only);
-                payload[2 * j] = uint64_t(units); payload[2 * j + 1] = cnt;
-            } else payload[j] = m.brick_pack[at];   // (a pack-only table: the staging word is all there is)
+                words[word0 + 2 * k] = uint64_t(units); words[word0 + 2 * k + 1] = cnt;
+            } else words[word0 + k] = m.brick_pack[at];   // (a pack-only table: the staging word is all there is)
         }
     }
 }
@@ -142,20 +155,34 @@ k_xchg_accumulate(const char* __restrict__ slice, uint32_t n_s, uint32_t wide, c
     const uint64_t* payload = reinterpret_cast<const uint64_t*>(slice + 16 * size_t(n_s) + xchg_pad8(4 * size_t(n_s)));
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t b = wave; b < n_s; b += waves) {
-        const uint64_t key = keys[b], bits = masks[b];
-        uint32_t lo = 0, hi = n_union;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (union_keys[mid] < key) lo = mid + 1; else hi = mid; }
-        if (lo >= n_union || union_keys[lo] != key) continue;   // cannot happen: the union holds every slice's keys
-        if (!((bits >> lane) & 1ull)) continue;
-        const size_t j = size_t(firsts[b]) + uint32_t(__popcll(bits & ((1ull << lane) - 1ull)));
-        long long units; uint32_t cnt;
-        if (wide) { units = (long long)payload[2 * j]; cnt = uint32_t(payload[2 * j + 1]); }
-        else unpack_staged(payload[j], &units, &cnt);
-        const size_t at = size_t(lo) * 64 + lane;
-        acc_sum[at] += units;
-        const uint32_t before = acc_cnt[at];
-        acc_cnt[at] = (((before & ~kPoisonedCount) + (cnt & ~kPoisonedCount)) & ~kPoisonedCount) | ((before | cnt) & kPoisonedCount);
+    // sixty-four blocks per turn: every lane looks ITS block up in the union (a wave searching for one block at a time spent ten
+    // microseconds per block in twenty dependent loads -- 0.74 ms per million-block slice, rocprofv3), then the wave adds the blocks' voxels
+    // one block after the other, a lane per voxel
+    for (uint32_t b0 = wave * 64u; b0 < n_s; b0 += waves * 64u) {
+        const uint32_t mine = b0 + lane;
+        uint32_t row = ~0u, first = 0, mask_lo = 0, mask_hi = 0;
+        if (mine < n_s) {
+            const uint64_t key = keys[mine], bits = masks[mine];
+            uint32_t lo = 0, hi = n_union;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (union_keys[mid] < key) lo = mid + 1; else hi = mid; }
+            if (lo < n_union && union_keys[lo] == key) row = lo;   // (always: the union holds every slice's keys)
+            first = firsts[mine]; mask_lo = uint32_t(bits); mask_hi = uint32_t(bits >> 32);
+        }
+        const uint32_t here = min(64u, n_s - b0);
+        for (uint32_t j = 0; j < here; j++) {
+            const uint32_t r = uint32_t(__builtin_amdgcn_readlane(int(row), int(j)));
+            const uint64_t bits = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(mask_lo), int(j)))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(mask_hi), int(j)))) << 32);
+            const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(first), int(j)));
+            if (r == ~0u || !((bits >> lane) & 1ull)) continue;
+            const size_t at_word = size_t(f) + uint32_t(__popcll(bits & ((1ull << lane) - 1ull)));
+            long long units; uint32_t cnt;
+            if (wide) { units = (long long)payload[2 * at_word]; cnt = uint32_t(payload[2 * at_word + 1]); }
+            else unpack_staged(payload[at_word], &units, &cnt);
+            const size_t at = size_t(r) * 64 + lane;
+            acc_sum[at] += units;
+            const uint32_t before = acc_cnt[at];
+            acc_cnt[at] = (((before & ~kPoisonedCount) + (cnt & ~kPoisonedCount)) & ~kPoisonedCount) | ((before | cnt) & kPoisonedCount);
+        }
     }
 }
 
