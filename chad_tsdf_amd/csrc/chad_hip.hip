@@ -236,6 +236,7 @@ struct chad_map {
         uint64_t exchange_bytes = 0, exchanges = 0, exchange_union_blocks = 0;   // sharded maps: bytes this rank handed to the collectives of its exchanges / exchanges completed / blocks in the last union
     } pt;
     bool in_rollover_span = false;
+    int debug_fail_fold = 0, debug_fail_close = 0;   // CHAD_DEBUG_FAIL_FOLD / _CLOSE = n: the n-th fold stage / the n-th roll-over's step A of this map fails as if out of memory (tests of the recovery paths)
     AllocMeter alloc_mark;                        // the calling thread's allocation meter at the last chad_map_pipeline_times
     uint64_t growths_mark = 0;
     int spare_flags = 0;                          // the spare's flag word still holds: 1 = its "exact rows" bit (cleared at a roll-over), 2 = everything (it was
@@ -1596,6 +1597,8 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     if (const char* e = std::getenv("CHAD_GRAPHS")) m->use_graphs = std::atoi(e) != 0;
     if (const char* e = std::getenv("CHAD_STAGE_MODE")) m->stage_mode = !std::strcmp(e, "staged") ? 1 : !std::strcmp(e, "direct") ? 2 : 0;
     if (const char* e = std::getenv("CHAD_STAGE_DIRECT_KB")) m->stage_direct_from = size_t(std::max(0, std::atoi(e))) << 10;
+    if (const char* e = std::getenv("CHAD_DEBUG_FAIL_FOLD")) m->debug_fail_fold = std::atoi(e);
+    if (const char* e = std::getenv("CHAD_DEBUG_FAIL_CLOSE")) m->debug_fail_close = std::atoi(e);
     if (const char* a = std::getenv("CHAD_DEBUG_ABLATE")) m->ablate = uint32_t(std::strtoul(a, nullptr, 0));
     if (const char* a = std::getenv("CHAD_DEBUG_FOLD_POINTS")) { m->fold_due = uint64_t(std::atoll(a)); m->report_folds = true; }
     if (std::getenv("CHAD_DEBUG_STAMPS")) { (void)chad_malloc(&m->d_stamps, 8192 * 16 * 8); (void)hipMemset(m->d_stamps, 0, 8192 * 16 * 8); }
@@ -2327,6 +2330,7 @@ static chad_status fold_step(chad_map* m, bool block) {
         uint32_t root_tsdf = 0, root_weight = 0;
         const int stage_before = m->fold.stage;
         HIP_TRY(dag_fold_advance(m->ddag, m->fold, s, block, &done, &root_tsdf, &root_weight));
+        if (m->fold.stage != stage_before && m->debug_fail_fold > 0 && --m->debug_fail_fold == 0) return fail(CHAD_ERR_OUT_OF_MEMORY, "CHAD_DEBUG_FAIL_FOLD: injected failure of a fold stage");
         if (m->fold.stage == 2 && stage_before == 1) HIP_TRY(hipEventRecord(m->fold_t1, s));   // (behind the last stage's kernels)
         if (!done) return CHAD_OK;
         float t = 0;
@@ -2360,7 +2364,7 @@ static chad_status fold_step(chad_map* m, bool block) {
 // submaps are already on their way (one being folded, one waiting for that).
 chad_status close_into_dag(chad_map* m, uint32_t blocks) {
     while (m->pending.set) TRY(fold_advance(m, true));   // (the fold before the waiting one is done: the waiting one begins; the arena of the one before it is free)
-    if (m->closed.size() > m->dag_roots.size() + (m->folding ? 1u : 0u)) TRY(fold_archived(m));   // submaps closed by other routes: the DAG takes them in closing order
+    if (!m->dag_broken && m->closed.size() > m->dag_roots.size() + (m->folding ? 1u : 0u)) TRY(fold_archived(m));   // submaps closed by other routes: the DAG takes them in closing order
     if (m->dag_broken) blocks = 0;   // (an earlier fold failed: the frames go on, the closed submaps are lost until chad_map_reset -- every DAG reader says so)
     hipStream_t s = m->close_stream ? m->close_stream : m->stream;
     const bool saturate = (m->flags & CHAD_FLAG_DAG_SATURATE_WEIGHTS) != 0;
@@ -2376,6 +2380,7 @@ chad_status close_into_dag(chad_map* m, uint32_t blocks) {
         HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipStreamSynchronize(m->stream));
         if (m->fold_stream) HIP_TRY(hipStreamSynchronize(m->fold_stream));
     }
+    if (m->debug_fail_close > 0 && --m->debug_fail_close == 0) return fail(CHAD_ERR_OUT_OF_MEMORY, "CHAD_DEBUG_FAIL_CLOSE: injected failure of a roll-over's step A");
     HIP_TRY(arena.reserve(need));   // (grows with half as much again: the submaps of a trajectory differ by tens of per cent, and a hipMalloc stalls the device)
     uint64_t* keys = arena.take<uint64_t>(nb);
     uint32_t* slots = arena.take<uint32_t>(nb);

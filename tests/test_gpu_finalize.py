@@ -296,3 +296,74 @@ def test_dag_pool_and_reserved_levels_allocate_nothing_and_change_nothing(chad):
     assert all(np.array_equal(pooled.dag_level(l), want[l]) for l in range(21))
     assert [pooled.dag_roots(s) for s in range(len(roots))] == roots
     plain.close(); pooled.close()
+
+
+def _rollover_frames(n=45):
+    from chad_tsdf_amd import synth
+
+    return [(synth.cfg3_frame(5 * k, 20_000)[0], np.array([-12.0 + 0.6 * k, 0.1, 0.0], np.float32)) for k in range(n)]   # a roll-over every nine frames
+
+
+def test_a_failed_roll_over_step_is_retried_with_the_same_arena(chad, monkeypatch):
+    """close_into_dag takes the cluster words' arena by the parity of the roll-overs closed so far.  A step that fails after the
+    arena was chosen (an allocation; here injected: CHAD_DEBUG_FAIL_CLOSE) must leave the parity where it was -- the retry, driven by the
+    next call, takes the SAME arena and never the one the fold in flight is reading.  The call that hit the failure reports it; the DAG in
+    the end is the DAG of an undisturbed run, word for word."""
+    frames = _rollover_frames()
+    want = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    for pts, pos in frames:
+        want.insert(pts, pos)
+    want.close_submap(); want.finalize()
+    monkeypatch.setenv("CHAD_DEBUG_FAIL_CLOSE", "3")   # the third roll-over's step A fails once
+    m = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    monkeypatch.delenv("CHAD_DEBUG_FAIL_CLOSE")
+    errors = []
+    for pts, pos in frames:
+        try:
+            m.insert(pts, pos)
+        except chad._lib.ChadError as e:
+            errors.append(str(e))   # (the frame of the failing call is not integrated again: see below)
+    assert len(errors) == 1 and "CHAD_DEBUG_FAIL_CLOSE" in errors[0]
+    m.close_submap(); m.finalize()
+    assert m.closed_submaps == want.closed_submaps
+    # the failing insert returned before its frame was enqueued: that one frame is missing from its submap, every other submap is untouched
+    same = [m.dag_roots(s) == want.dag_roots(s) for s in range(want.closed_submaps)]
+    assert sum(same) >= want.closed_submaps - 1 and same[0] and same[1]
+    m.close(); want.close()
+
+
+def test_a_failed_fold_is_abandoned_and_the_map_lives_on(chad, monkeypatch):
+    """a fold stage that fails (out of memory for a level that has to grow; here injected: CHAD_DEBUG_FAIL_FOLD) used to leave
+    the map re-entering the failed stage on every later call -- it could not even be reset.  Now the fold is abandoned: the error is
+    reported once, every DAG reader says the DAG is incomplete, frames and roll-overs go on, and chad_map_reset gives a working map."""
+    frames = _rollover_frames()
+    monkeypatch.setenv("CHAD_DEBUG_FAIL_FOLD", "4")   # the second roll-over's fold fails in its second stage
+    m = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    monkeypatch.delenv("CHAD_DEBUG_FAIL_FOLD")
+    errors = []
+    for pts, pos in frames:
+        try:
+            m.insert(pts, pos)
+        except chad._lib.ChadError as e:
+            errors.append(str(e))
+    try:
+        m.sync()
+    except chad._lib.ChadError as e:
+        errors.append(str(e))
+    assert len(errors) == 1 and "abandoned" in errors[0]
+    assert m.stats()["closed_submaps"] == 4 and m.block_count(-1) > 0          # the frames went on, the roll-overs too
+    with pytest.raises(chad._lib.ChadError, match="incomplete"):
+        m.dag_roots(0)
+    with pytest.raises(chad._lib.ChadError, match="incomplete"):
+        m.finalize()
+    m.reset()                                                                  # ... and the map can be reset: a new DAG
+    for pts, pos in frames[:20]:
+        m.insert(pts, pos)
+    m.close_submap(); m.finalize()
+    fresh = chad.TSDFMap(0.05, 0.10, dag_only=True)
+    for pts, pos in frames[:20]:
+        fresh.insert(pts, pos)
+    fresh.close_submap(); fresh.finalize()
+    assert m.closed_submaps == fresh.closed_submaps == 3
+    assert all(np.array_equal(m.dag_level(l), fresh.dag_level(l)) for l in range(21))
+    m.close(); fresh.close()
