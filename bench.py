@@ -300,10 +300,17 @@ def main():
         algo = {"k_frame_bounds": 12 * N, "k_frame_keys": 20 * N, "k_frame_gather": 24 * N, "k_frame_normals": 32 * N, "k_update": algo_bytes}
         kernels, total_ms = [], 0.0
         for name, (ms, launches) in kt.items():
-            b = algo.get(name, 48 * N)   # a sort pass moves key + float4 point: (8 + 16) B read + written (SURVEY's 24 N per pass is key + index)
+            # a sort pass: SURVEY.md 8(d) counts (8 B key + 4 B index) read + written = 24 N; this design's pass carries the point itself
+            # (8 B key + 16 B float4 read + written = 48 N; the first pass reads the raw 12-byte point: 44 N) -- both are reported
+            b = algo.get(name, 24 * N)
             total_ms += ms
-            kernels.append({"kernel": name, "ms": round(ms, 4), "algorithmic_bytes": b, "GBps": round(b / ms / 1e6, 1) if ms > 0 else None,
-                            "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4) if ms > 0 else None})
+            entry = {"kernel": name, "ms": round(ms, 4), "algorithmic_bytes": b, "GBps": round(b / ms / 1e6, 1) if ms > 0 else None,
+                     "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+            if name.startswith("k_radix"):
+                moved = (44 if name.endswith("[0]") else 48) * N
+                entry["moved_bytes"] = moved
+                entry["frac_of_moved_bytes"] = round(moved / ms / 1e6 / HBM_PEAK_GBS, 4) if ms > 0 else None
+            kernels.append(entry)
         out["roofline"]["kernels"] = kernels
         out["roofline"]["kernel_ms_sum_serial"] = round(total_ms, 4)
         upd_serial = kt.get("k_update", (0.0, 0))[0]
