@@ -549,6 +549,18 @@ def main():
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
 
+        def dag_bytes_for(entries, words):
+            """HBM the DAG's levels take when chad_map_dag_reserve makes them this size (dag_device.hpp, dag_device_init: a look-up table at most
+            half full over a sixteenth more than the expected entries, a store a sixteenth larger than the expected words)."""
+            total = 0
+            for level in range(21):
+                slots = 1 << 19
+                while slots < 2 * (int(entries[level]) + int(entries[level]) // 16) + 16:
+                    slots <<= 1
+                store = max(1 << 19, int(words[level]) + int(words[level]) // 16 + 4096)
+                total += slots * 4 + store * (8 if level == 20 else 4)
+            return total
+
         def run_cfg5(frames_n, dag_only):
             # The map at the size this trajectory needs (2^22 blocks: no table doubling inside the timed region), and the DAG's memory reserved
             # up front (chad_options.dag_pool_bytes: the levels' stores and tables live inside one reservation -- the counterpart of the
@@ -556,19 +568,19 @@ def main():
             # takes 0.03 to 30 ms per GB depending on the box (one 11.9 GB hipMalloc: 0.37 ms on one box of this round, 334 ms on the next), and
             # round 3's leg -- 59 GB of level growth by hipMalloc inside the 5 000 timed frames -- measured 0.29 ms per frame on the builder's
             # boxes and 0.64 on the driver's.  cfg5.alloc is the proof: calls the library made between the two clock readings.
-            # Two passes over the trajectory, both timed: the FIRST with the levels growing inside the pool (copies and rehashes on the
-            # fold's stream, no allocation unless the pool fragments), the SECOND -- the leg's ms_per_frame -- after chad_map_reset with the
-            # levels made their final size from the start (chad_map_dag_reserve with the first pass's sizes: what a deployment that knows its
-            # trajectories does).  The 36-frame warm-up makes the spare table and sizes the grow-only scratch.
-            pool = min(64 << 30, int(torch.cuda.mem_get_info()[0] * 0.45)) if dag_only else 0
-            m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22, dag_only=dag_only, dag_pool_bytes=pool)
-            for k in range(min(36, frames_n)):
-                m5.insert(dev[k][0], dev[k][1], ready=True)
-            m5.sync()
-            if dag_only:
-                m5.finalize()
-            passes = []
-            for p in range(2 if dag_only else 1):
+            # Two maps, two timed passes over the trajectory: the FIRST with a generous pool and the levels growing inside it (copies and
+            # rehashes on the fold's stream, no allocation unless the pool fragments); the SECOND -- the leg's ms_per_frame -- a map whose pool
+            # is sized for the levels at their final size, made that size from the start (chad_map_dag_reserve with the first pass's sizes:
+            # what a deployment that knows its trajectories does).  Each map's 36-frame warm-up makes its spare table and sizes its scratch.
+            def one_pass(pool, sizes):
+                m5 = TSDFMap(c5["res"], c5["trunc"], time_update=True, update_mode=args.update_mode, max_points=c5["n"], max_blocks=1 << 22, dag_only=dag_only, dag_pool_bytes=pool)
+                if sizes is not None:
+                    m5.dag_reserve(*sizes)
+                for k in range(min(36, frames_n)):
+                    m5.insert(dev[k][0], dev[k][1], ready=True)
+                m5.sync()
+                if dag_only:
+                    m5.finalize()
                 m5.reset(); m5.sync(); m5.stats(); m5.host_times(); m5.pipeline_times()
                 t1 = time.perf_counter()
                 for k in range(frames_n):
@@ -578,10 +590,17 @@ def main():
                 if dag_only:
                     m5.finalize()   # every closed submap is in the DAG when the clock stops (the reference finalizes at the roll-over: tsdf.cpp:53)
                 t5 = time.perf_counter() - t1
-                passes.append((t5, t_host, m5.host_times(), m5.pipeline_times()))
-                if dag_only and p == 0:
-                    m5.dag_reserve(*m5.dag_sizes())   # (takes effect when the reset DAG is made again)
-            return m5, passes
+                return m5, (t5, t_host, m5.host_times(), m5.pipeline_times())
+
+            if not dag_only:
+                m5, only = one_pass(0, None)
+                return m5, [only]
+            m_first, first = one_pass(min(64 << 30, int(torch.cuda.mem_get_info()[0] * 0.45)), None)
+            sizes = m_first.dag_sizes()
+            m_first.close()
+            need = dag_bytes_for(*sizes)
+            m5, second = one_pass(need + need // 32 + (64 << 20), sizes)
+            return m5, [first, second]
 
         m5, passes5 = run_cfg5(n5, True)
         (t5_first, _, _, p5_first), (t5, t5_host, h5, p5) = passes5
