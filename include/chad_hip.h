@@ -205,8 +205,16 @@ chad_status chad_map_close_submap_with_blocks_device(chad_map* map, const uint64
  * Use: every rank creates a communicator and attaches it to its map; then EVERY rank calls the same insert / close_submap /
  * save sequence with the same positions (points are only read on the rank that owns the frame: insert k of the stream
  * belongs to rank k % world; the others may pass n = 0).  The 5 m roll-over rule (tsdf.cpp:46-61) sees every pose on every
- * rank, so all ranks reach the exchange at the same frame: all-gather of block keys, sorted union, all-reduce(sum) of the i64
- * sums and u32 counts over the union (RCCL over xGMI), every rank archives the merged submap. */
+ * rank, so all ranks reach the exchange at the same frame.  What the exchange is depends on what the map keeps of a closed submap:
+ *   archives kept (default)   all-gather of block keys, sorted union, all-reduce(sum) of the i64 sums and u32 counts over the union
+ *                             (RCCL over xGMI): EVERY rank archives the merged submap;
+ *   CHAD_FLAG_DAG_ONLY        the sparse exchange: block keys, 64-bit voxel masks and one word per touched voxel travel point to point
+ *                             (ncclSend / ncclRecv) to the owner of a Morton key range -- G - 1 splitters drawn from samples of every
+ *                             rank's sorted keys --, every rank turns its range into leaf-cluster words (submap.hpp:70-99), rank 0
+ *                             concatenates the ranges and folds the submap into the DAG: Submap::finalize runs ONCE per submap, and
+ *                             the DAG lives on rank 0 only (chad_map_dag_* fail on the other ranks with a message).
+ * Every wait of an exchange is bounded (CHAD_COMM_TIMEOUT_S, default 120 s): a peer that never arrives is an error, not a hang; a
+ * failed exchange is reported once, its submap comes out empty, and the communicator is dead from then on. */
 typedef struct chad_comm chad_comm;
 enum { CHAD_COMM_ID_BYTES = 128 };
 /* RCCL transport.  Rank 0 makes an id (ncclGetUniqueId) and hands the bytes to the other ranks over any channel the
