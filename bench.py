@@ -427,8 +427,8 @@ def main():
                            + (f"; frames round-robin over {world} ranks, block partials merged ({comm.transport}) at every submap close" if world > 1 else ""),
                "scaling": "strong", "n_gpus": world, "ms_per_frame": round(t_stream / args.stream_frames * 1e3, 4),
                "points_per_s": round(args.stream_frames * c3["n"] / t_stream), "host_enqueue_ms_per_frame": round(t_host / args.stream_frames * 1e3, 4),
-               # the host's side of an insert call on this rank, in microseconds per call: its own work (bookkeeping + launches, or one graph
-               # submit), and the time it waited for the device to hand a frame slot back (three frames in flight: the device's pace)
+               # the host's side of an insert call on this rank, in microseconds per call: its own work (bookkeeping + launches),
+               # and the time it waited for the device to hand a frame slot back (three frames in flight: the device's pace)
                "host_us_per_insert": {"work": round(h3["us_host_work"], 2), "wait_for_device": round(h3["us_wait"], 2), "calls": h3["inserts"]},
                "closed_submaps": int(s3["closed_submaps"]), "live_blocks": int(s3["blocks"]), "hash_load": round(s3["blocks"] / s3["hash_capacity"], 5),
                "overflow": int(s3["overflow"])}

@@ -25,7 +25,7 @@
 #include "dag.hpp"
 #include "dag_device.hpp"
 #include "exchange_kernels.hpp"
-#include "frame_graph.hpp"
+#include "launcher.hpp"
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
 #include "merge_kernels.hpp"
@@ -113,16 +113,7 @@ enum Stage { T_BEGIN = 0, T_CALC, T_SORT, T_NORM, T_UPD, T_COUNT };
 // idle) and then the update.  Updates of different frames commute (sums and counts, added atomically), so the streams
 // need no ordering among themselves.  What does need the map to itself -- clearing it, a roll-over, growth, an export --
 // waits for the updates enqueued so far and makes the later ones wait for it (exclusive_begin / exclusive_end below).
-// what a recorded chain of preparation kernels depends on besides its arguments: grids, kernels and buffers
-struct FrameShape {
-    uint32_t count = 0, digit_bits = 0, sort_launches = 0;
-    size_t cap_points = 0;
-    bool operator==(const FrameShape& o) const { return count == o.count && digit_bits == o.digit_bits && sort_launches == o.sort_launches && cap_points == o.cap_points; }
-};
-
 struct FrameSlot {
-    FrameLauncher chain;                // the slot's preparation chain: launched kernel by kernel, or recorded and replayed as a hipGraph (frame_graph.hpp)
-    FrameShape chain_shape;             // ... the shape it was recorded for
     hipStream_t prep = nullptr;
     hipEvent_t update_done = nullptr;   // recorded on `prep` behind its last update when somebody has to wait for it (updates_done)
     bool tail_unrecorded = false;       // frames have been enqueued on `prep` since update_done was last recorded
@@ -157,11 +148,6 @@ struct chad_map {
     uint32_t* d_consumed = nullptr;           // (its device address)
     RadixSortBuffers aux_sort{};        // block-key sorter of exports and of Submap::finalize (never a frame slot's: those belong to frames in flight)
     size_t aux_cap = 0;
-    bool use_graphs = false;            // CHAD_GRAPHS=1: replay a slot's preparation chain as a hipGraph when the frame shape repeats.  Off by default: measured
-                                        // (scripts/graph_ab.py, ROCm 7.2) the replay with every node's arguments replaced costs the host as much as the seven
-                                        // launches it stands for -- 26.9 against 24.5 us of host work per 200 k-point insert, 20.6 against 25.1 at 20 k points --
-                                        // and the streams are paced by the device anyway (the host waits 21-23 us per cfg3 insert for a frame slot)
-    FrameShape last_shape;              // shape of the previous insert's frame (a chain is recorded when a shape turns up twice in a row)
     // host time of the insert path, cumulative (chad_map_host_times): in the insert calls altogether / of that, waiting for the device to
     // hand a frame slot back (prepare_slot: the bound of three frames in flight) / of that, in the H2D copy of chad_map_insert
     double host_insert_s = 0, host_wait_s = 0, host_copy_s = 0;
@@ -360,7 +346,6 @@ void free_sort_buffers(RadixSortBuffers& b) {
 }
 
 void free_frame_buffers(FrameSlot& f) {
-    f.chain.destroy();   // (its nodes name the buffers)
     if (f.h_stage) (void)hipHostFree(f.h_stage);
     f.h_stage = nullptr;
     (void)chad_free(f.d_xyz);
@@ -1445,9 +1430,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             LAUNCH_TIMED(m, CHAD_KERNEL_NORMALS, k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
                          reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
         } else {
-            // The chain of preparation kernels, every launch through the slot's FrameLauncher: launched one by one, or -- when the
-            // frame has the shape of the one recorded for this slot (same size, digit width, pass count, buffers) -- replayed as a
-            // hipGraph with this frame's arguments (frame_graph.hpp: one submit instead of six to eight).
+            // the chain of preparation kernels, on the slot's stream
             auto chain = [&](FrameLauncher& L) {
                 L(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
                 L(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.digit_base, f.sort.tile_status,
@@ -1459,26 +1442,9 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                 L(k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
                   reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
             };
-            const FrameShape shape{count, digit_bits, hint, f.cap_points};
-            FrameLauncher& L = f.chain;
+            FrameLauncher L;
             L.stream = prep;
-            bool submitted = false;
-            if (m->use_graphs && L.recorded() && f.chain_shape == shape) {
-                L.begin_update();
-                chain(L);
-                hipError_t e = hipSuccess;
-                submitted = L.end_update_and_launch(&e);
-                if (submitted) HIP_TRY(e);
-                else L.destroy();   // another kernel or grid than recorded (the sort's residency share has changed ...): forget the recording
-            } else if (m->use_graphs && shape == m->last_shape) {   // the second frame of this shape in a row: worth recording
-                if (L.begin_build() == hipSuccess) {
-                    chain(L);
-                    if (L.end_build() == hipSuccess) { f.chain_shape = shape; HIP_TRY(hipGraphLaunch(L.exec, prep)); submitted = true; }
-                }
-                if (!submitted) { (void)hipGetLastError(); L.destroy(); }
-            }
-            if (!submitted) { L.mode = FrameLauncher::kEager; chain(L); }
-            m->last_shape = shape;
+            chain(L);
         }
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
@@ -1594,7 +1560,6 @@ chad_status chad_map_create(float sdf_res, float sdf_trunc, const chad_options* 
     m->update_mode = o.update_mode <= CHAD_UPDATE_TILED ? o.update_mode : CHAD_UPDATE_AUTO;
     m->fixed_capacity = (o.flags & CHAD_FLAG_FIXED_CAPACITY) != 0;
     m->dag_on_host = std::getenv("CHAD_DEBUG_DAG_HOST") != nullptr;
-    if (const char* e = std::getenv("CHAD_GRAPHS")) m->use_graphs = std::atoi(e) != 0;
     if (const char* e = std::getenv("CHAD_STAGE_MODE")) m->stage_mode = !std::strcmp(e, "staged") ? 1 : !std::strcmp(e, "direct") ? 2 : 0;
     if (const char* e = std::getenv("CHAD_STAGE_DIRECT_KB")) m->stage_direct_from = size_t(std::max(0, std::atoi(e))) << 10;
     if (const char* e = std::getenv("CHAD_DEBUG_FAIL_FOLD")) m->debug_fail_fold = std::atoi(e);

@@ -17,7 +17,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
-#include "frame_graph.hpp"
+#include "launcher.hpp"
 
 namespace chadhip {
 
@@ -506,7 +506,7 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     RadixSortSignals checked = sig;
     if (checked.dep && !(hist_blocks == 0 && passes == uint32_t(kMaxPasses) && !(pass_limit && launch_passes && launch_passes < passes))) checked.dep = nullptr;
     const RadixSortSignals& sig_ = checked;
-    FrameLauncher eager;   // (the launches go through `recorder` when the caller records or replays its chain as a graph: frame_graph.hpp)
+    FrameLauncher eager;   // (the launches go through the caller's launcher where it has one)
     eager.stream = stream;
     FrameLauncher& L = recorder && !sig_.pass_events ? *recorder : eager;
     const uint32_t tiles = radix_tiles(n);

@@ -155,7 +155,7 @@ chad_status chad_map_kernel_times(chad_map* map, chad_kernel_times* out);
 /* Host time of the insert path since the last call (the counters restart): the calls of chad_map_insert* altogether; of that, the time
  * spent waiting for the device to hand a frame slot back (at most three frames are in flight: a host that runs ahead waits here -- that
  * wait is the device's pace, not host work); of that, the host-to-device copy inside chad_map_insert.  insert_s - wait_s - copy_s is
- * what the host itself needs per insert: pose bookkeeping, the launches (or the one graph submit, frame_graph.hpp). */
+ * what the host itself needs per insert: pose bookkeeping and the launches. */
 typedef struct chad_host_times { uint64_t inserts; double insert_s, wait_s, copy_s; } chad_host_times;
 chad_status chad_map_host_times(chad_map* map, chad_host_times* out);
 const char* chad_kernel_name(int32_t id);
