@@ -257,18 +257,37 @@ def main():
     # From here on: extra legs.  Whatever happens in them -- an exception, a collective that never returns on a node this build has never
     # run on -- the contract's line above must still be printed: a leg that raises is recorded as {"error": ...}, and a watchdog prints what
     # there is and ends the process if the legs take longer than --leg-timeout seconds altogether (every rank has the same watchdog).
+    import copy
     import threading
 
+    contract_line = copy.deepcopy(out)   # complete as it stands: what the watchdog prints if `out` cannot be serialised while a leg is writing to it
+    running = {"leg": "start"}           # which extra leg is running (recorded in the line when the watchdog fires)
+
+    def enter(leg):
+        running["leg"] = leg
+
     def give_up():
-        out["watchdog"] = f"the extra legs did not finish within {args.leg_timeout} s: this line carries what was measured until then"
-        if rank == 0:
-            print(json.dumps(out), flush=True)
-        os._exit(0)
+        # Timer thread.  Print the line, then end the process with a NON-ZERO code: a leg that hangs (a collective that never returns, a
+        # stuck kernel) must not look like a successful run.  The main thread may be adding keys to `out` at this moment: serialise a
+        # snapshot, retry if the dictionary changed under it, fall back to the contract's fields alone -- and exit whatever happens.
+        try:
+            note = {"watchdog": f"the extra legs did not finish within {args.leg_timeout} s (running: {running['leg']}): this line carries what was measured until then",
+                    "watchdog_leg": running["leg"]}
+            line = None
+            for _ in range(20):
+                try:
+                    line = json.dumps(dict(out, **note))
+                    break
+                except RuntimeError:   # dictionary changed size during iteration
+                    time.sleep(0.01)
+            if line is None:
+                line = json.dumps(dict(contract_line, **note))
+            if rank == 0:
+                print(line, flush=True)
+        finally:
+            os._exit(3)
 
-    watchdog = threading.Timer(args.leg_timeout, give_up)
-    watchdog.daemon = True
-    watchdog.start()
-
+    enter("hbm_copy")
     # ---- the box's achievable HBM rate (a device-to-device copy beside the 8 TB/s spec figure) ----------------
     if rank == 0:
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")   # 1 GiB
@@ -286,6 +305,7 @@ def main():
         out["roofline"]["hbm_copy_GBps_this_box"] = round(copy_gbs, 1)   # read + write bytes of a 1 GiB device-to-device copy: what a pure stream reaches here
         out["roofline"]["frac_of_copy_rate"] = round(achieved / copy_gbs, 5) if copy_gbs > 0 else None
 
+    enter("per_kernel")
     # ---- per-kernel durations: a serial pass, every kernel launched with its own pair of dispatch time stamps --------------
     if rank == 0:
         mk = TSDFMap(res, trunc, time_kernels=True, update_mode=args.update_mode, max_points=args.points)
@@ -322,6 +342,7 @@ def main():
                            "ms_mc_sort": round(sum(v[0] for k, v in kt.items() if k.startswith("k_radix")) + kt.get("k_frame_gather", (0, 0))[0], 4),
                            "ms_norm_est": round(kt.get("k_frame_normals", (0, 0))[0], 4), "ms_oct_upd": round(upd_serial, 4), "ms_total": round(total_ms, 4)}
 
+    enter("large_frame / pcie_inclusive")
     if rank == 0 and world == 1 and extras:
         # a frame large enough for the traffic to matter: 4 M points of the same room (the 40 % target is out of reach at 29 MB per launch)
         big_pts, big_pos = synth.cfg2_frame(4_000_000, seed=77)
@@ -461,6 +482,7 @@ def main():
         del dev
         return leg
 
+    enter("cfg4" if world > 1 else "cfg3")
     if extras and args.stream_frames > 0:
         try:
             out["cfg4" if world > 1 else "cfg3"] = stream_leg()
@@ -533,12 +555,14 @@ def main():
         local.close()
         return leg
 
+    enter("cfg5_sharded")
     if extras and world > 1 and args.sharded_outdoor_frames > 0:
         try:
             out["cfg5_sharded"] = sharded_outdoor_leg()
         except Exception as e:  # noqa: BLE001
             out["cfg5_sharded"] = {"error": f"{type(e).__name__}: {e}"}
 
+    enter("cfg5")
     # ---- cfg5: BASELINE config 5's trajectory on one GPU -------------------------------------------------------------------
     if outdoor:
         c5 = synth.CFG5
@@ -654,6 +678,7 @@ def main():
         mk5.close()
         del dev
 
+    enter("finalize / cpu_baseline")
     # ---- the row behind the path and the CPU baseline, outside every timed region ---------------------
     if rank == 0 and world == 1:
         mf = TSDFMap(res, trunc, update_mode=args.update_mode, max_points=args.points)
@@ -719,6 +744,13 @@ def main():
             out["finalize"]["levels_identical"] = bool(all(np.array_equal(mf.dag_level(l), o.dag_level(l)) for l in range(21)))
         mf.close()
 
+    # `value` above is WEAK scaling (every rank integrates its own frames): a SCALE run over N reads about N x by construction.  The strong-
+    # scaling figure BASELINE.json's north_star asks for is the cfg4 leg's: the SAME 500-frame stream on N GPUs against one GPU of the same job.
+    cfg4 = out.get("cfg4") if world > 1 else None
+    out["strong_scaling"] = ({"workload": "cfg4: the 500-frame cfg3 stream dealt frame-round-robin over the ranks, one block-partial exchange per submap close",
+                              "n_gpus": world, "speedup_vs_1gpu": cfg4.get("speedup_vs_1gpu"), "ms_per_frame": cfg4.get("ms_per_frame"),
+                              "one_gpu_same_job_ms_per_frame": cfg4.get("one_gpu_same_job_ms_per_frame")}
+                             if isinstance(cfg4, dict) and "speedup_vs_1gpu" in cfg4 else None)
     watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)

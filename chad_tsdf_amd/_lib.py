@@ -74,6 +74,8 @@ class KernelTimes(C.Structure):
 
 class DagStats(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("reserved", C.c_uint32),
         ("submaps", C.c_uint64),
         ("uniques", C.c_uint32 * 21),
         ("dupes", C.c_uint32 * 21),
@@ -93,6 +95,7 @@ class PipelineTimes(C.Structure):   # chad_pipeline_times
         ("dag_pool_bytes", C.c_uint64), ("dag_pool_used", C.c_uint64), ("dag_pool_peak", C.c_uint64),
         ("exchanges", C.c_uint64), ("exchange_bytes", C.c_uint64), ("exchange_union_blocks", C.c_uint64),
         ("comm_world", C.c_uint32), ("comm_transport", C.c_uint32),
+        ("comm_p2p_calls", C.c_uint64),
     ]
 
 

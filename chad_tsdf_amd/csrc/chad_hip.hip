@@ -25,7 +25,6 @@
 #include "dag.hpp"
 #include "dag_device.hpp"
 #include "exchange_kernels.hpp"
-#include "launcher.hpp"
 #include "frame_kernels.hpp"
 #include "map_kernels.hpp"
 #include "merge_kernels.hpp"
@@ -1422,7 +1421,7 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
             uint32_t pass_launches = 0;
             if (times_kernels(m)) { sig.pass_events = &m->kev[m->ktimed_end % chad_map::kKernelRing][2 * CHAD_KERNEL_SORT_PASS0]; sig.launches_out = &pass_launches; }
             RadixRest rest;
-            radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, nullptr, &rest);
+            radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, &rest);
             if (times_kernels(m)) m->kev_launched[m->ktimed_end % chad_map::kKernelRing] |= ((1u << pass_launches) - 1u) << CHAD_KERNEL_SORT_PASS0;
             LAUNCH_TIMED(m, CHAD_KERNEL_GATHER, gather_kernel, gather_grid, dim3(256), 0, prep, m->recip, f.d_hdr, f.d_part, (const uint64_t*)f.sort.keys[0], (const uint64_t*)f.sort.keys[1],
                          points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block, rest);
@@ -1431,20 +1430,15 @@ chad_status insert_device(chad_map* m, FrameSlot& f, const float* d_xyz, size_t 
                          reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
         } else {
             // the chain of preparation kernels, on the slot's stream
-            auto chain = [&](FrameLauncher& L) {
-                L(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
-                L(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.digit_base, f.sort.tile_status,
-                  uint32_t(radix_status_words(radix_tiles(count))), m->view.brick_count, m->d_live_blocks, digit_bits);
-                RadixRest rest;   // (the sort's catch-all, if its grid calls for one, is the gather kernel's prologue)
-                radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, &L, &rest);
-                L(gather_kernel, gather_grid, dim3(256), 0, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.keys[1], points0, points1, reinterpret_cast<uint2*>(f.d_seg), item_start,
-                  list_stride, sig.consumed, sig.seq, big_block, rest);
-                L(k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
-                  reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), item_start);
-            };
-            FrameLauncher L;
-            L.stream = prep;
-            chain(L);
+            hipLaunchKernelGGL(k_frame_bounds, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_part, f.sort.digit_base);
+            hipLaunchKernelGGL(k_frame_keys, dim3(kFrameBlocks), dim3(256), 0, prep, d_xyz, count, pos, m->recip, f.d_hdr, f.d_part, f.sort.keys[0], f.sort.digit_base, f.sort.tile_status,
+                               uint32_t(radix_status_words(radix_tiles(count))), (const uint32_t*)m->view.brick_count, m->d_live_blocks, digit_bits);
+            RadixRest rest;   // (the sort's catch-all, if its grid calls for one, is the gather kernel's prologue)
+            radix_sort_points_enqueue(f.sort, d_xyz, count, kMaxPasses, &f.d_hdr->sort_passes, prep, kFrameBlocks, hint, sig, digit_bits, &rest);
+            hipLaunchKernelGGL(gather_kernel, gather_grid, dim3(256), 0, prep, m->recip, f.d_hdr, (const FramePartial*)f.d_part, (const uint64_t*)f.sort.keys[0], (const uint64_t*)f.sort.keys[1], points0, points1,
+                               reinterpret_cast<uint2*>(f.d_seg), item_start, list_stride, sig.consumed, sig.seq, big_block, rest);
+            hipLaunchKernelGGL(k_frame_normals, dim3(normal_groups), dim3(64 * kNormalWaves), 0, prep, reinterpret_cast<float4*>(f.sort.points[0]), reinterpret_cast<float4*>(f.sort.points[1]), m->recip,
+                               reinterpret_cast<const uint2*>(f.d_seg), list_stride, f.d_hdr, pos, f.d_normals, m->ablate, big_block, std::min(big_groups, normal_groups / 2u), (const uint4*)item_start);
         }
         if (times_stages(m)) record(m, T_NORM, prep);
     } else {
@@ -2004,7 +1998,7 @@ chad_status chad_map_pipeline_times(chad_map* m, chad_pipeline_times* out) {
     t.alloc_s = now.seconds - m->alloc_mark.seconds;
     t.dag_pool_bytes = m->ddag.pool.cap; t.dag_pool_used = m->ddag.pool.used; t.dag_pool_peak = m->ddag.pool.peak;
     t.exchanges = m->pt.exchanges; t.exchange_bytes = m->pt.exchange_bytes; t.exchange_union_blocks = m->pt.exchange_union_blocks;
-    if (m->comm) { t.comm_world = uint32_t(m->comm->transport_world()); t.comm_transport = m->comm->nccl ? 1u : 2u; }
+    if (m->comm) { t.comm_world = uint32_t(m->comm->transport_world()); t.comm_transport = m->comm->nccl ? 1u : 2u; t.comm_p2p_calls = m->comm->p2p_calls; }
     std::memcpy(out, &t, t.struct_size);
     m->pt = chad_map::PipelineTimes{};
     m->alloc_mark = now; m->growths_mark = m->ddag.growths;
@@ -2501,8 +2495,12 @@ chad_status chad_map_dag_reserve(chad_map* m, const uint64_t entries[CHAD_DAG_NO
 chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
     if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(m->device);
+    if (out->struct_size < 2 * sizeof(uint32_t)) return fail(CHAD_ERR_INVALID_ARG, "chad_dag_stats.struct_size not set");
     TRY(finalize_closed(m));
-    std::memset(out, 0, sizeof(*out));
+    chad_dag_stats filled{};
+    filled.struct_size = uint32_t(std::min<size_t>(out->struct_size, sizeof(filled)));
+    chad_dag_stats* const caller = out;
+    out = &filled;
     out->submaps = m->dag_roots.size();
     if (!m->dag_on_host && m->ddag.ready)
         for (uint32_t l = 0; l <= kDagDepth; l++) { out->uniques[l] = uint32_t(m->ddag.h_scalars[l].uniques); out->dupes[l] = uint32_t(m->ddag.h_scalars[l].dupes); }
@@ -2517,6 +2515,7 @@ chad_status chad_map_dag_stats(chad_map* m, chad_dag_stats* out) {
         if (!m->ddag.pool.owns(L.table)) out->device_bytes += size_t(L.table_slots) * 4;
         if (!m->ddag.pool.owns(L.raw)) out->device_bytes += size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4);
     }
+    std::memcpy(caller, &filled, filled.struct_size);   // (an older, shorter caller gets the fields it knows)
     return CHAD_OK;
 }
 

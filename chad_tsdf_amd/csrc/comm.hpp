@@ -80,6 +80,7 @@ inline RcclApi& rccl() { static RcclApi api; return api; }
 }  // namespace chadhip
 
 struct chad_comm {
+    static constexpr size_t kCallbackStagingLimit = size_t(16) << 30;   // bytes of host memory the callback transport may stage at once
     int32_t rank = 0, world = 1;
     int device = 0;
     void* nccl = nullptr;                         // ncclComm_t (RCCL transport)
@@ -91,6 +92,7 @@ struct chad_comm {
     bool no_shortcut = false;                     // CHAD_DEBUG_COMM_NO_SHORTCUT: a one-rank communicator goes through its transport as well
                                                   // (tests: the RCCL calls themselves on a one-GPU box)
     bool exchanges() const { return world > 1 || no_shortcut; }
+    uint64_t p2p_calls = 0;                       // exchange_slices calls that went through ncclSend / ncclRecv (chad_pipeline_times: tests read it)
     bool dead = false;                            // abort() has been called: every later collective fails at once
     void abort() {
         if (nccl && !dead && chadhip::rccl().comm_abort) { (void)chadhip::rccl().comm_abort(nccl); nccl = nullptr; }
@@ -126,25 +128,32 @@ struct chad_comm {
         if (dead) return false;
         const char* src = static_cast<const char*>(send);
         char* dst = static_cast<char*>(recv);
-        if (p.send_bytes[rank] && hipMemcpyAsync(dst + p.recv_off[rank], src + p.send_off[rank], p.send_bytes[rank], hipMemcpyDeviceToDevice, stream) != hipSuccess) { error = "exchange_slices: local copy failed"; return false; }
-        if (world == 1) return true;
+        // a one-rank RCCL communicator that is not short-cut (CHAD_DEBUG_COMM_NO_SHORTCUT) sends its own slice to ITSELF through the grouped
+        // ncclSend / ncclRecv below -- RCCL allows a rank to be its own peer inside a group -- so that the product transport's symbols, dtype
+        // and grouping run on the one GPU a test box has
+        const bool self_through_rccl = nccl && no_shortcut && world == 1;
+        if (!self_through_rccl && p.send_bytes[rank] && hipMemcpyAsync(dst + p.recv_off[rank], src + p.send_off[rank], p.send_bytes[rank], hipMemcpyDeviceToDevice, stream) != hipSuccess) { error = "exchange_slices: local copy failed"; return false; }
+        if (world == 1 && !self_through_rccl) return true;
         if (nccl) {
             chadhip::RcclApi& api = chadhip::rccl();
             if (!api.send || !api.recv || !api.group_start || !api.group_end) { error = "librccl.so.1 lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd"; return false; }
             int r = api.group_start();
             for (int peer = 0; peer < world && !r; peer++) {
-                if (peer == rank) continue;
+                if (peer == rank && !self_through_rccl) continue;
+                const size_t to_recv = peer == rank ? p.send_bytes[rank] : p.recv_bytes[peer];   // (a rank's slice for itself has one size)
                 if (p.send_bytes[peer]) r = api.send(src + p.send_off[peer], p.send_bytes[peer], chadhip::RcclApi::kInt8, peer, nccl, stream);
-                if (!r && p.recv_bytes[peer]) r = api.recv(dst + p.recv_off[peer], p.recv_bytes[peer], chadhip::RcclApi::kInt8, peer, nccl, stream);
+                if (!r && to_recv) r = api.recv(dst + p.recv_off[peer], to_recv, chadhip::RcclApi::kInt8, peer, nccl, stream);
             }
             const int e = api.group_end();
             if (r || e) { error = std::string("ncclSend / ncclRecv: ") + api.get_error_string(r ? r : e); return false; }
+            p2p_calls++;
             return true;
         }
         const size_t pad = (std::max<size_t>(p.longest_send, 8) + 7) & ~size_t(7);
         size_t mine = 0;
         for (int r = 0; r < world; r++) mine = std::max(mine, p.send_off[r] + p.send_bytes[r]);
         if (mine > pad) { error = "exchange_slices: a send buffer longer than the plan's longest"; return false; }
+        if (pad > kCallbackStagingLimit / size_t(world + 1)) { error = "exchange_slices: the callback transport stages whole send buffers through host memory and this exchange is too large for that (a rehearsal path: use RCCL)"; return false; }
         host.resize(pad * size_t(world + 1));
         if (mine && (hipMemcpyAsync(host.data(), send, mine, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)) { error = "exchange_slices: staging copy failed"; return false; }
         if (gather(user, host.data(), host.data() + pad, pad) != 0) { error = "exchange_slices: all_gather callback failed"; return false; }

@@ -13,6 +13,7 @@
 namespace chadhip {
 
 constexpr uint32_t kXSamples = 64;            // sample keys per rank the splitters are drawn from
+constexpr uint64_t kXMaxRankBlocks = 1ull << 30;   // blocks one rank may announce for one range, and for all ranges together (a table of 2^30 blocks would be 1.4 TB)
 constexpr uint32_t kXHeadWords = kXSamples + 1;   // a rank's head: [block count (low 32 bits) | payload width flag (bit 32)], then its samples
 
 inline size_t xchg_pad8_host(size_t bytes) { return (bytes + 7) & ~size_t(7); }
@@ -62,14 +63,23 @@ struct ExchangePlan {
 inline bool xchg_slice_plan(const uint64_t* matrix, const uint32_t* wide_of, uint32_t world, uint32_t me, ExchangePlan& plan) {
     auto slice = [&](uint32_t from, uint32_t to) { return xchg_slice_bytes(matrix[(size_t(from) * world + to) * 2], matrix[(size_t(from) * world + to) * 2 + 1], wide_of[from] ? 2u : 1u); };
     plan = ExchangePlan{};
+    // every entry of the matrix, not only this rank's column: the other entries come from the peers and decide offsets (peer_off) and, for
+    // the callback transport, a host allocation (longest_send).  A rank's blocks for all ranges together are the blocks of its table.
+    for (uint32_t a = 0; a < world; a++) {
+        uint64_t row_blocks = 0;
+        for (uint32_t b = 0; b < world; b++) {
+            const uint64_t blocks = matrix[(size_t(a) * world + b) * 2], words = matrix[(size_t(a) * world + b) * 2 + 1];
+            if (blocks >= kXMaxRankBlocks || words > blocks * 64) return false;
+            row_blocks += blocks;
+        }
+        if (row_blocks >= kXMaxRankBlocks) return false;
+    }
     size_t send_total = 0, recv_total = 0;
     for (uint32_t r = 0; r < world; r++) {
-        const uint64_t blocks = matrix[(size_t(r) * world + me) * 2], words = matrix[(size_t(r) * world + me) * 2 + 1];
-        if (blocks >= (1ull << 30) || words > blocks * 64) return false;
         plan.send_off[r] = send_total; plan.send_bytes[r] = slice(me, r); send_total += plan.send_bytes[r];
         plan.recv_off[r] = recv_total; plan.recv_bytes[r] = slice(r, me); recv_total += plan.recv_bytes[r];
         size_t before = 0, whole = 0;
-        for (uint32_t d = 0; d < world; d++) { if (d < me) before += slice(r, d); whole += slice(r, d); }
+        for (uint32_t d = 0; d < world; d++) { if (d < me) before += slice(r, d); whole += slice(r, d); }   // (bounded: kXMaxRankBlocks * 1044 bytes per rank, far from wrapping)
         plan.peer_off[r] = before; plan.longest_send = std::max(plan.longest_send, whole);
     }
     return true;

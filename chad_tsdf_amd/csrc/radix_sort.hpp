@@ -17,7 +17,6 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
-#include "launcher.hpp"
 
 namespace chadhip {
 
@@ -497,7 +496,7 @@ __device__ __forceinline__ void radix_rest_points(const RadixRest& r, uint32_t l
 template <class P>
 inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* const pay[2], uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
                                   uint32_t hist_blocks, uint32_t launch_passes, const void* first_src,
-                                  const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits, FrameLauncher* recorder = nullptr, RadixRest* rest_out = nullptr) {
+                                  const RadixSortSignals& sig = RadixSortSignals{}, uint32_t digit_bits = kRadixBits, RadixRest* rest_out = nullptr) {
     if (rest_out) *rest_out = RadixRest{};
     if (n == 0) return;
     // RadixSortSignals::dep (passes 5 and 6 skipped when their digits are functions of the top digit) is only sound for a sort that takes
@@ -506,9 +505,6 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
     RadixSortSignals checked = sig;
     if (checked.dep && !(hist_blocks == 0 && passes == uint32_t(kMaxPasses) && !(pass_limit && launch_passes && launch_passes < passes))) checked.dep = nullptr;
     const RadixSortSignals& sig_ = checked;
-    FrameLauncher eager;   // (the launches go through the caller's launcher where it has one)
-    eager.stream = stream;
-    FrameLauncher& L = recorder && !sig_.pass_events ? *recorder : eager;
     const uint32_t tiles = radix_tiles(n);
     const bool all_resident = b.resident != 0u && tiles <= b.resident;
     uint32_t* ticket = b.tile_status + radix_status_words(tiles) - 64;
@@ -539,8 +535,8 @@ inline void radix_sort_enqueue_as(const RadixSortBuffers& b, typename P::T* cons
                 hipExtLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, sig_.pass_events[2 * p], sig_.pass_events[2 * p + 1], 0u, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
                                       to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig_);
             else
-                L(kernel, dim3(tiles), dim3(kSortThreads), 0, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
-                  to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig_);
+                hipLaunchKernelGGL(kernel, dim3(tiles), dim3(kSortThreads), 0, stream, b.keys[0], pay[0], b.keys[1], pay[1], n, p,
+                                   to_limit ? 1u : 0u, tiles, b.digit_base, base_stripes, b.tile_status, ticket, pass_limit, first_src, all_resident ? 0u : 1u, sig_);
         };
         if (digit_bits == uint32_t(kWideBits)) launch(k_radix_onesweep<P, kWideBits>); else launch(k_radix_onesweep<P, kRadixBits>);
     }
@@ -561,8 +557,8 @@ inline void radix_sort_enqueue(const RadixSortBuffers& b, uint32_t n, uint32_t p
     radix_sort_enqueue_as<IndexPayload>(b, b.idx, n, passes, pass_limit, stream, hist_blocks, launch_passes, nullptr, sig);
 }
 inline void radix_sort_points_enqueue(const RadixSortBuffers& b, const float* xyz, uint32_t n, uint32_t passes, const uint32_t* pass_limit, hipStream_t stream,
-                                      uint32_t hist_blocks, uint32_t launch_passes, const RadixSortSignals& sig, uint32_t digit_bits, FrameLauncher* recorder, RadixRest* rest_out) {
-    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, sig, digit_bits, recorder, rest_out);
+                                      uint32_t hist_blocks, uint32_t launch_passes, const RadixSortSignals& sig, uint32_t digit_bits, RadixRest* rest_out) {
+    radix_sort_enqueue_as<PointPayload>(b, b.points, n, passes, pass_limit, stream, hist_blocks, launch_passes, xyz, sig, digit_bits, rest_out);
 }
 // Workgroups of a pass kernel the device holds at once: the kernel's real occupancy (registers, LDS) x CU count, with a quarter
 // held back (the runtime's answer can exceed what the hardware admits by one per CU -- MI355X_MICROARCH.md, Residency).

@@ -373,7 +373,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
 
 inline uint32_t tile_reach(float res, float trunc) {
     const float r = std::ceil(trunc / res) + 1.0f;
-    return r < 2.0f ? 2u : (r > float(kMaxReach) ? kMaxReach : uint32_t(r));   // (at least 2: the read-back of step 2 wants two cells of every brick inside the tile along x)
+    return r < 2.0f ? 2u : (r > float(kMaxReach) ? kMaxReach : uint32_t(r));   // (at least 2: the read-back wants two cells of every brick inside the tile along x)
 }
 
 // Launch shape of the update kernel for one map: fixed by its resolution and truncation distance (the tile's reach) and by the
@@ -381,7 +381,7 @@ inline uint32_t tile_reach(float res, float trunc) {
 // different devices, or created from different threads, do not share state.
 struct TileLaunch {
     uint32_t reach = 0, lds = 0;
-    uint32_t groups = 0, groups_stamped = 0;   // persistent workgroups: as many as are resident at once (registers and LDS decide), on every CU
+    uint32_t groups = 0, groups_stamped = 0;   // k_update_tiled: persistent workgroups, as many as are resident at once (registers and LDS decide), on every CU
 };
 inline TileLaunch tile_launch_shape(float res, float trunc, uint32_t cu_count) {
     TileLaunch t;
@@ -398,6 +398,7 @@ inline TileLaunch tile_launch_shape(float res, float trunc, uint32_t cu_count) {
     // every workgroup finds its first item in FrameHeader::first_item (kFirstItems entries)
     t.groups = std::min<uint32_t>(cu_count * per_cu[0], kFirstItems);
     t.groups_stamped = std::min<uint32_t>(cu_count * per_cu[1], kFirstItems);
+
     return t;
 }
 

@@ -300,6 +300,7 @@ class TSDFMap:
 
     def dag_stats(self) -> dict:
         st = _lib.DagStats()
+        st.struct_size = C.sizeof(_lib.DagStats)
         _lib.check(self._lib.chad_map_dag_stats(self._h, C.byref(st)), "TSDFMap.dag_stats")
         return {"submaps": int(st.submaps), "uniques": list(st.uniques), "dupes": list(st.dupes), "ms_device": st.ms_device, "ms_host": st.ms_host, "device_bytes": int(st.device_bytes)}
 

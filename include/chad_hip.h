@@ -180,6 +180,7 @@ typedef struct chad_pipeline_times {
     uint64_t dag_pool_bytes, dag_pool_used, dag_pool_peak;
     uint64_t exchanges, exchange_bytes, exchange_union_blocks;
     uint32_t comm_world, comm_transport; /* ranks of the attached communicator as the TRANSPORT reports them (ncclCommCount for RCCL; 0 = none attached) / 1 RCCL, 2 callbacks */
+    uint64_t comm_p2p_calls;             /* point-to-point steps of the attached communicator that went through a group of ncclSend / ncclRecv (since it was created) */
 } chad_pipeline_times;
 chad_status chad_map_pipeline_times(chad_map* map, chad_pipeline_times* out);
 
@@ -251,6 +252,8 @@ chad_status chad_map_merge_and_close(chad_map* map, chad_comm* comm);
  * uint64 words); word 0 of every level is reserved (levels.hpp:52,118). */
 enum { CHAD_DAG_NODE_LEVELS = 20, CHAD_DAG_CLUSTER_LEVEL = 20 };
 typedef struct chad_dag_stats {
+    uint32_t struct_size;           /* set to sizeof(chad_dag_stats) before the call: the library fills no more than that */
+    uint32_t reserved;
     uint64_t submaps;               /* closed submaps folded into the DAG so far */
     uint32_t uniques[21], dupes[21]; /* NodeLevel::_uniques_n/_dupes_n per level (levels.hpp:88); [20] = leaf clusters (levels.hpp:136) */
     float ms_device, ms_host;       /* of the last chad_map_finalize that had work: device time (key sort, cluster kernel, the fold of the levels; under CHAD_FLAG_DAG_ONLY the fold alone) /

@@ -38,17 +38,19 @@ def test_struct_layouts_match_header(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "chad_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(chad_options), offsetof(chad_options, stream),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(chad_options), offsetof(chad_options, stream),'
         ' offsetof(chad_options, update_mode), sizeof(chad_stats), offsetof(chad_stats, sort_passes), offsetof(chad_stats, ms_total),'
         ' offsetof(chad_options, dag_pool_bytes), sizeof(chad_pipeline_times), offsetof(chad_pipeline_times, alloc_s),'
-        ' offsetof(chad_pipeline_times, comm_transport), sizeof(chad_dag_stats));return 0;}\n')
+        ' offsetof(chad_pipeline_times, comm_transport), sizeof(chad_dag_stats), offsetof(chad_pipeline_times, comm_p2p_calls),'
+        ' offsetof(chad_dag_stats, submaps), offsetof(chad_dag_stats, device_bytes));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_lib.Options), _lib.Options.stream.offset, _lib.Options.update_mode.offset,
             ctypes.sizeof(_lib.Stats), _lib.Stats.sort_passes.offset, _lib.Stats.ms_total.offset,
             _lib.Options.dag_pool_bytes.offset, ctypes.sizeof(_lib.PipelineTimes), _lib.PipelineTimes.alloc_s.offset,
-            _lib.PipelineTimes.comm_transport.offset, ctypes.sizeof(_lib.DagStats)]
+            _lib.PipelineTimes.comm_transport.offset, ctypes.sizeof(_lib.DagStats), _lib.PipelineTimes.comm_p2p_calls.offset,
+            _lib.DagStats.submaps.offset, _lib.DagStats.device_bytes.offset]
     assert got == want
 
 

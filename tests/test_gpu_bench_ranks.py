@@ -1,0 +1,32 @@
+"""bench.py with two ranks: the N > 1 path of the contract's command (the driver starts it on an 8-GPU node; this build has only ever had
+one GPU), rehearsed with two gloo ranks sharing the one GPU -- so that the cfg4 / cfg5_sharded legs and the strong-scaling field cannot
+rot unseen.  The callback transport stands in for RCCL here (RCCL refuses two ranks on one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_with_two_gloo_ranks_prints_the_strong_scaling_legs():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--points", "200000",
+           "--stream-frames", "30", "--sharded-outdoor-frames", "22", "--cpu-seconds", "0", "--leg-timeout", "240"]
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and "watchdog" not in line
+    cfg4 = line["cfg4"]
+    assert "error" not in cfg4 and cfg4["scaling"] == "strong" and cfg4["n_gpus"] == 2 and cfg4["speedup_vs_1gpu"] > 0
+    sharded = line["cfg5_sharded"]
+    assert "error" not in sharded and sharded["speedup_vs_1gpu"] > 0
+    strong = line["strong_scaling"]
+    assert strong["n_gpus"] == 2 and strong["speedup_vs_1gpu"] == cfg4["speedup_vs_1gpu"]
+    # the transport saw both ranks
+    assert sharded["ranks_seen_by_transport"] == 2

@@ -367,3 +367,29 @@ def test_a_failed_fold_is_abandoned_and_the_map_lives_on(chad, monkeypatch):
     assert m.closed_submaps == fresh.closed_submaps == 3
     assert all(np.array_equal(m.dag_level(l), fresh.dag_level(l)) for l in range(21))
     m.close(); fresh.close()
+
+
+def test_dag_stats_carries_its_size(chad):
+    """chad_dag_stats.struct_size: a caller that does not set it is refused (never a write past its structure), a shorter -- older --
+    structure gets the fields it knows."""
+    import ctypes as C
+
+    from chad_tsdf_amd import _lib
+
+    m = chad.TSDFMap(0.05, 0.10)
+    pts, pos = synth.cfg2_frame(20_000)
+    m.insert(pts, pos)
+    m.close_submap()
+    st = _lib.DagStats()
+    assert m._lib.chad_map_dag_stats(m._h, C.byref(st)) == _lib.ERR_INVALID_ARG
+    raw = (C.c_uint8 * (C.sizeof(_lib.DagStats) + 16))()
+    C.memset(raw, 0xAB, len(raw))
+    short = _lib.DagStats.submaps.offset + 8   # struct_size, reserved, submaps
+    C.cast(raw, C.POINTER(C.c_uint32))[0] = short
+    _lib.check(m._lib.chad_map_dag_stats(m._h, C.cast(raw, C.POINTER(_lib.DagStats))), "dag_stats")
+    got = _lib.DagStats.from_buffer_copy(bytes(raw)[:C.sizeof(_lib.DagStats)])
+    assert got.struct_size == short and got.submaps == 1
+    assert all(b == 0xAB for b in bytes(raw)[short:]), "the library wrote past the caller's size"
+    assert m.dag_stats()["submaps"] == 1 and m.dag_stats()["uniques"][20] > 0
+    m.close()
+

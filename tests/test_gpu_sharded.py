@@ -118,6 +118,49 @@ def test_one_rank_rccl_communicator_goes_through_rccl(monkeypatch):
     lib.chad_comm_destroy(comm)
 
 
+def test_one_rank_rccl_sparse_exchange_goes_through_send_and_recv(monkeypatch):
+    """The sparse exchange's point-to-point step on the RCCL transport, on the one GPU there is: under CHAD_DEBUG_COMM_NO_SHORTCUT a
+    one-rank communicator sends its own slice to itself through ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd (comm.hpp,
+    exchange_slices) -- the symbols, the int8 dtype and the grouping of the product transport execute, stage 2's slices and stage 4's
+    ranges alike.  The map keeps closed submaps as their DAG only (what makes the exchange the sparse one); rank 0's DAG must be the
+    plain map's, word for word."""
+    import ctypes as C
+
+    import chad_tsdf_amd
+    from chad_tsdf_amd import _lib
+
+    lib = _lib.load()
+    monkeypatch.setenv("CHAD_DEBUG_COMM_NO_SHORTCUT", "1")
+    uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    _lib.check(lib.chad_comm_unique_id(uid), "unique_id")
+    comm = C.c_void_p()
+    _lib.check(lib.chad_comm_create_rccl(uid, 0, 1, C.byref(comm)), "create_rccl")
+    monkeypatch.delenv("CHAD_DEBUG_COMM_NO_SHORTCUT")
+
+    class Handle:
+        handle = comm
+
+    plain = chad_tsdf_amd.TSDFMap(0.05, 0.10, dag_only=True)
+    shard = chad_tsdf_amd.TSDFMap(0.05, 0.10, dag_only=True)
+    shard.attach_comm(Handle)
+    for pts, pos in _stream():
+        plain.insert(pts, pos)
+        shard.insert(pts, pos)
+    plain.close_submap()
+    shard.close_submap()
+    plain.sync(); shard.sync()
+    assert plain.closed_submaps == shard.closed_submaps == 2
+    times = shard.pipeline_times()
+    assert times["comm_transport"] == 1 and times["comm_world"] == 1
+    assert times["comm_p2p_calls"] >= 4, times   # two submaps, two point-to-point steps each
+    assert [shard.dag_roots(s) for s in (0, 1)] == [plain.dag_roots(s) for s in (0, 1)]
+    for level in range(21):
+        assert np.array_equal(shard.dag_level(level), plain.dag_level(level)), f"level {level}"
+    shard.attach_comm(None)
+    shard.close(); plain.close()
+    lib.chad_comm_destroy(comm)
+
+
 def _cfg4_rank(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
