@@ -287,6 +287,10 @@ def main():
         finally:
             os._exit(3)
 
+    watchdog = threading.Timer(args.leg_timeout, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
     enter("hbm_copy")
     # ---- the box's achievable HBM rate (a device-to-device copy beside the 8 TB/s spec figure) ----------------
     if rank == 0:
