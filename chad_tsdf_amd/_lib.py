@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libchad_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_CAPACITY, ERR_HIP = range(6)
-FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS, FLAG_DAG_ONLY, FLAG_TIME_KERNELS, FLAG_MESH_FROM_DAG, FLAG_SPACE_CARVING = 1, 2, 4, 8, 16, 32, 64, 128, 256
+FLAG_VERBOSE, FLAG_TIMING, FLAG_TIME_UPDATE, FLAG_FIXED_CAPACITY, FLAG_DAG_SATURATE_WEIGHTS, FLAG_DAG_ONLY, FLAG_TIME_KERNELS, FLAG_MESH_FROM_DAG, FLAG_SPACE_CARVING, FLAG_MESH_TETRAHEDRA = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 QUERY_LEAF, QUERY_TRILINEAR = 0, 1
 KERNEL_COUNT = 13
 DAG_NODE_LEVELS, DAG_CLUSTER_LEVEL = 20, 20
@@ -151,6 +151,7 @@ SYMBOLS = {
     "chad_map_query_sd_device": (_i32, [_vp, _vp, _sz, _i32, _vp, _vp]),
     "chad_map_raycast": (_i32, [_vp, _vp, _vp, _sz, _f32, _vp]),
     "chad_map_mesh": (_i32, [_vp, _i32, _vp, _sz, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "chad_map_mesh_normals": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_mesh_cells": (_i32, [_vp, _i32, _vp, _vp, _sz, C.POINTER(_sz)]),
     "chad_map_save_mesh": (_i32, [_vp, _i32, C.c_char_p]),
     "chad_map_submap_positions": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz)]),

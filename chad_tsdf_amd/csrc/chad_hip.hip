@@ -234,7 +234,7 @@ struct chad_map {
     std::vector<chad_iter*> iterators;            // the iterators handed out and not yet destroyed: chad_map_destroy cuts them loose
     // the last mesh extracted (chad_map_mesh is called twice: sizes, then data)
     int32_t mesh_submap = INT32_MIN;
-    std::vector<float> mesh_vertices;
+    std::vector<float> mesh_vertices, mesh_normals;   // (normals: per vertex, lvr2.cpp:296-297)
     std::vector<uint32_t> mesh_triangles;
     // Roll-over without a pipeline stall: the active table is swapped for an empty spare one of the same size and is
     // archived (counted, compacted into a dense closed submap, cleared) on the map's stream behind the frames, the host
@@ -2575,6 +2575,14 @@ static void apply_submap_pose(const chad_map* m, int32_t submap, float p[3]) {
     p[2] = T[6] * x + T[7] * y + T[8] * z + T[11];
 }
 
+// n <- R n (a direction: no translation)
+static void apply_submap_rotation(const chad_map* m, int32_t submap, float n[3]) {
+    if (submap < 0 || size_t(submap) >= m->closed_pose.size()) return;
+    const std::array<float, 12>& T = m->closed_pose[size_t(submap)];
+    const float x = n[0], y = n[1], z = n[2];
+    n[0] = T[0] * x + T[1] * y + T[2] * z; n[1] = T[3] * x + T[4] * y + T[5] * z; n[2] = T[6] * x + T[7] * y + T[8] * z;
+}
+
 chad_status chad_map_iter_begin(chad_map* m, int32_t submap, chad_iter** out) {
     if (!m || !out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
@@ -2755,6 +2763,26 @@ void weld_mesh(const std::vector<float>& soup, std::vector<float>& vertices, std
     }
 }
 
+// What the reference saves with its mesh (lvr2.cpp:296-313: calcFaceNormals, calcVertexNormals, SimpleFinalizer::setNormalData): a normal
+// per vertex -- the normalised sum of the unit normals of the faces around it (a face without area contributes nothing; a vertex
+// without faces gets (0, 0, 0)).
+void mesh_vertex_normals(const std::vector<float>& vertices, const std::vector<uint32_t>& triangles, std::vector<float>& normals) {
+    normals.assign(vertices.size(), 0.0f);
+    for (size_t t = 0; t + 3 <= triangles.size(); t += 3) {
+        const float* a = &vertices[3 * size_t(triangles[t])], *b = &vertices[3 * size_t(triangles[t + 1])], *c = &vertices[3 * size_t(triangles[t + 2])];
+        const double ux = double(b[0]) - a[0], uy = double(b[1]) - a[1], uz = double(b[2]) - a[2], vx = double(c[0]) - a[0], vy = double(c[1]) - a[1], vz = double(c[2]) - a[2];
+        double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+        const double len = std::sqrt(nx * nx + ny * ny + nz * nz);
+        if (!(len > 0.0)) continue;
+        nx /= len; ny /= len; nz /= len;
+        for (int k = 0; k < 3; k++) { float* n = &normals[3 * size_t(triangles[t + k])]; n[0] += float(nx); n[1] += float(ny); n[2] += float(nz); }
+    }
+    for (size_t v = 0; v + 3 <= normals.size(); v += 3) {
+        const double len = std::sqrt(double(normals[v]) * normals[v] + double(normals[v + 1]) * normals[v + 1] + double(normals[v + 2]) * normals[v + 2]);
+        if (len > 0.0) { normals[v] = float(normals[v] / len); normals[v + 1] = float(normals[v + 1] / len); normals[v + 2] = float(normals[v + 2] / len); }
+    }
+}
+
 // sorted block keys and per-voxel means (NaN = no leaf) of a submap on the device
 chad_status mesh_source(chad_map* m, int32_t submap, DevBuf& keys_sorted, DevBuf& means, uint32_t* blocks_out) {
     TRY(finish_closing(m, true));   // (a roll-over still in progress: its archive may be released right behind it, CHAD_FLAG_DAG_ONLY)
@@ -2804,12 +2832,18 @@ chad_status extract_mesh(chad_map* m, int32_t submap) {
     DevBuf keys, means;
     uint32_t nb = 0;
     TRY(mesh_source(m, submap, keys, means, &nb));
-    m->mesh_vertices.clear(); m->mesh_triangles.clear();
+    m->mesh_vertices.clear(); m->mesh_triangles.clear(); m->mesh_normals.clear();
     m->mesh_submap = submap;
     if (!nb) return CHAD_OK;
+    const bool cubes = !(m->flags & CHAD_FLAG_MESH_TETRAHEDRA);
     DevBuf counts, d_total;
     HIP_TRY(counts.alloc(size_t(nb) * 4)); HIP_TRY(d_total.alloc(4));
-    hipLaunchKernelGGL((k_mesh_bricks<false>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, m->res, counts.as<uint32_t>(), (float*)nullptr);
+    auto bricks = [&](auto write, float* out) {
+        constexpr bool kWrite = decltype(write)::value;
+        if (cubes) hipLaunchKernelGGL((k_mesh_bricks<kWrite, true>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, m->res, counts.as<uint32_t>(), out);
+        else hipLaunchKernelGGL((k_mesh_bricks<kWrite, false>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, m->res, counts.as<uint32_t>(), out);
+    };
+    bricks(std::false_type{}, nullptr);
     hipLaunchKernelGGL(k_unique_offsets, dim3(1), dim3(256), 0, m->stream, counts.as<uint32_t>(), nb, d_total.as<uint32_t>());
     uint32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, d_total.p, 4, hipMemcpyDeviceToHost, m->stream));
@@ -2817,12 +2851,13 @@ chad_status extract_mesh(chad_map* m, int32_t submap) {
     if (!total) return CHAD_OK;
     DevBuf soup;
     HIP_TRY(soup.alloc(size_t(total) * 36));
-    hipLaunchKernelGGL((k_mesh_bricks<true>), grid_for(size_t(nb) * 64, 256, 8192), dim3(256), 0, m->stream, keys.as<uint64_t>(), means.as<float>(), nb, m->res, counts.as<uint32_t>(), soup.as<float>());
+    bricks(std::true_type{}, soup.as<float>());
     HIP_TRY(hipGetLastError());
     std::vector<float> host(size_t(total) * 9);
     HIP_TRY(hipMemcpyAsync(host.data(), soup.p, host.size() * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     weld_mesh(host, m->mesh_vertices, m->mesh_triangles);
+    mesh_vertex_normals(m->mesh_vertices, m->mesh_triangles, m->mesh_normals);
     return CHAD_OK;
 }
 
@@ -2839,6 +2874,18 @@ chad_status chad_map_mesh(chad_map* m, int32_t submap, float* vertices, size_t v
     }
     if (triangles && triangle_capacity >= *triangle_count) std::memcpy(triangles, m->mesh_triangles.data(), m->mesh_triangles.size() * 4);
     if ((vertices && vertex_capacity < *vertex_count) || (triangles && triangle_capacity < *triangle_count)) return fail(CHAD_ERR_INVALID_ARG, "mesh buffers too small");
+    return CHAD_OK;
+}
+
+chad_status chad_map_mesh_normals(chad_map* m, int32_t submap, float* normals, size_t vertex_capacity, size_t* vertex_count) {
+    if (!m || !vertex_count) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(m->device);
+    TRY(extract_mesh(m, submap));
+    *vertex_count = m->mesh_normals.size() / 3;
+    if (!normals) return CHAD_OK;
+    if (vertex_capacity < *vertex_count) return fail(CHAD_ERR_INVALID_ARG, "mesh buffers too small");
+    std::memcpy(normals, m->mesh_normals.data(), m->mesh_normals.size() * 4);
+    for (size_t v = 0; v < *vertex_count; v++) apply_submap_rotation(m, submap, normals + 3 * v);   // (loop closure: the submap's corrected pose turns the normals with it)
     return CHAD_OK;
 }
 
@@ -2878,11 +2925,15 @@ chad_status chad_map_save_mesh(chad_map* m, int32_t submap, const char* filename
     std::FILE* f = std::fopen(filename, "wb");
     if (!f) return fail(CHAD_ERR_INVALID_ARG, std::string("cannot open ") + filename);
     const size_t nv = m->mesh_vertices.size() / 3, nt = m->mesh_triangles.size() / 3;
+    // vertices carry their normals, as the model the reference saves does (lvr2.cpp:309-313: SimpleFinalizer with setNormalData)
     std::fprintf(f, "ply\nformat binary_little_endian 1.0\ncomment chad_tsdf mesh: sd = 0 surface of submap %d, res %g trunc %g\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\n"
-                    "element face %zu\nproperty list uchar uint vertex_indices\nend_header\n", submap, double(m->res), double(m->trunc), nv, nt);
-    std::vector<float> posed(m->mesh_vertices);
-    for (size_t v = 0; v < nv; v++) apply_submap_pose(m, submap, posed.data() + 3 * v);
-    bool ok = nv == 0 || std::fwrite(posed.data(), 12, nv, f) == nv;
+                    "property float nx\nproperty float ny\nproperty float nz\nelement face %zu\nproperty list uchar uint vertex_indices\nend_header\n", submap, double(m->res), double(m->trunc), nv, nt);
+    std::vector<float> posed(nv * 6);
+    for (size_t v = 0; v < nv; v++) {
+        std::memcpy(&posed[6 * v], &m->mesh_vertices[3 * v], 12); std::memcpy(&posed[6 * v + 3], &m->mesh_normals[3 * v], 12);
+        apply_submap_pose(m, submap, &posed[6 * v]); apply_submap_rotation(m, submap, &posed[6 * v + 3]);
+    }
+    bool ok = nv == 0 || std::fwrite(posed.data(), 24, nv, f) == nv;
     std::vector<unsigned char> faces(nt * 13);
     for (size_t t = 0; t < nt; t++) { faces[13 * t] = 3; std::memcpy(&faces[13 * t + 1], &m->mesh_triangles[3 * t], 12); }
     ok = ok && (nt == 0 || std::fwrite(faces.data(), 13, nt, f) == nt);

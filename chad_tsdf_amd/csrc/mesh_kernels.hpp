@@ -5,11 +5,17 @@
 //   * a cell is the cube spanned by eight such points (vertex order of lvr2.cpp:89-98), and cells with a missing corner are
 //     culled (lvr2.cpp:115-129);
 //   * the iso-surface sd = 0 is triangulated inside every complete cell.
-// The triangulation here is marching TETRAHEDRA over the cell's Kuhn split (six tetrahedra around the diagonal v0-v6, the same
-// in every cell, so neighbouring cells agree on their shared face and the mesh is watertight by construction; no 256-entry case
-// table, no ambiguous cases) instead of LVR2's marching-cubes boxes.  Every mesh vertex lies on a grid edge and is computed
-// from that edge's two corners in a canonical order, so the cells around an edge produce bit-identical coordinates and the
-// host welds vertices by their bits.  Triangles are oriented towards increasing signed distance (towards the sensor side).
+// Two triangulations.  The default is MARCHING CUBES as LVR2's FastBox family does it (lvr2.cpp:246-251 calls BoxT::getSurface per
+// cell): the cell's case index has bit i set where corner i's distance is positive (FastBox::getIndex), the 256-case table of
+// Lorensen & Cline / Bourke (marching_cubes_table.inc, generated and checked by scripts/mc_table_check.py) names up to five
+// triangles by the cell edges their corners lie on, and a corner is placed by linear interpolation along its edge.  LVR2 itself is
+// absent from this image, so this is agreement with the published algorithm, held against a restatement in the oracle -- not
+// against LVR2's output; BilinearFastBox::optimizePlanarFaces (lvr2.cpp:262), which moves vertices afterwards, is not modelled.
+// The other (CHAD_FLAG_MESH_TETRAHEDRA; rounds 2-4's only one) is marching TETRAHEDRA over the cell's Kuhn split (six tetrahedra
+// around the diagonal v0-v6, the same in every cell, so neighbouring cells agree on their shared face and the mesh is watertight
+// by construction; no case table, no ambiguous faces).  Either way every mesh vertex on a grid edge is computed from that edge's
+// two corners in a canonical order, so the cells around an edge produce bit-identical coordinates and the host welds vertices by
+// their bits, and triangles face increasing signed distance (the sensor's side).
 // One wave per brick: the 5x5x5 corner values of its 4x4x4 cells (own brick + up to seven neighbours) staged in LDS, lane = cell.
 // Two passes over the same code: count triangles per brick, (scan,) write.
 #pragma once
@@ -98,9 +104,13 @@ k_mesh_cells(const uint64_t* __restrict__ keys, const float* __restrict__ sd, ui
 
 struct MeshVertex { float x, y, z; };
 
+#include "marching_cubes_table.inc"
+// the two corners of cell edge e (the numbering the table uses: 0-3 around the bottom face, 4-7 around the top face, 8-11 the verticals)
+static __device__ const signed char kCubeEdgeA[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, kCubeEdgeB[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+
 // kWrite false: tri_count[k] = triangles of brick k.  kWrite true: tri_count holds the exclusive scan; triangles are written to
 // out (9 floats each).
-template <bool kWrite>
+template <bool kWrite, bool kCubes>
 __global__ void __launch_bounds__(256)
 k_mesh_bricks(const uint64_t* __restrict__ keys, const float* __restrict__ sd, uint32_t bricks, float res, uint32_t* __restrict__ tri_count, float* __restrict__ out) {
     __shared__ float corner[4][128];       // per wave: value at corner (x, y, z), x, y, z in 0..4: index x + 5 y + 25 z
@@ -133,8 +143,13 @@ k_mesh_bricks(const uint64_t* __restrict__ keys, const float* __restrict__ sd, u
             const float qx = float(base.x + cx + kVx[q]) * res, qy = float(base.y + cy + kVy[q]) * res, qz = float(base.z + cz + kVz[q]) * res;
             return MeshVertex{px + (qx - px) * t, py + (qy - py) * t, pz + (qz - pz) * t};
         };
-        uint32_t mine = 0;
-        if (complete) {
+        uint32_t mine = 0, cube_case = 0;
+        if (complete && kCubes) {
+#pragma unroll
+            for (int v = 0; v < 8; v++) cube_case |= val[v] > 0.0f ? 1u << v : 0u;   // FastBox::getIndex: a corner in front of the surface sets its bit
+            while (kMarchingCubes[cube_case][3 * mine] >= 0) mine++;                  // (a row holds at most five triangles: index 15 is always -1)
+        }
+        if (complete && !kCubes) {
 #pragma unroll
             for (int t = 0; t < 6; t++) {
                 int inside = 0;
@@ -151,6 +166,15 @@ k_mesh_bricks(const uint64_t* __restrict__ keys, const float* __restrict__ sd, u
         if (!kWrite) { if (lane == 0) tri_count[k] = total; continue; }
         if (!mine) continue;
         float* dst = out + (size_t(tri_count[k]) + (incl - mine)) * 9;
+        if (kCubes) {   // the table's triangles as they stand: all of them face the corners whose bit is set -- increasing signed distance
+            for (uint32_t t = 0; t < mine; t++) {
+                const signed char* e = &kMarchingCubes[cube_case][3 * t];
+                const MeshVertex a = edge_point(kCubeEdgeA[e[0]], kCubeEdgeB[e[0]]), b = edge_point(kCubeEdgeA[e[1]], kCubeEdgeB[e[1]]), c = edge_point(kCubeEdgeA[e[2]], kCubeEdgeB[e[2]]);
+                dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = b.x; dst[4] = b.y; dst[5] = b.z; dst[6] = c.x; dst[7] = c.y; dst[8] = c.z;
+                dst += 9;
+            }
+            continue;
+        }
         auto emit = [&](MeshVertex a, MeshVertex b, MeshVertex c, float gx, float gy, float gz) {
             // orient towards increasing signed distance: (b - a) x (c - a) . g >= 0
             const float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = c.x - a.x, vy = c.y - a.y, vz = c.z - a.z;

@@ -23,7 +23,7 @@ class TSDFMap:
     def __init__(self, sdf_res: float = 0.05, sdf_trunc: float = 0.1, *, device: int = -1, max_blocks: int = 0,
                  max_points: int = 0, stream: int = 0, verbose: bool = False, timing: bool = False, time_update: bool = False, fixed_capacity: bool = False, update_mode: int = 0,
                  dag_saturate_weights: bool = False, dag_only: bool = False, time_kernels: bool = False, mesh_from_dag: bool = False, space_carving: bool = False,
-                 dag_pool_bytes: int = 0):
+                 dag_pool_bytes: int = 0, mesh_tetrahedra: bool = False):
         self._lib = _lib.load()
         self._sdf_res = float(sdf_res)
         self._sdf_trunc = float(sdf_trunc)
@@ -33,7 +33,7 @@ class TSDFMap:
         opt.max_blocks = max_blocks
         opt.max_points = max_points
         opt.stream = stream or None
-        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.FLAG_MESH_FROM_DAG if mesh_from_dag else 0) | (_lib.FLAG_SPACE_CARVING if space_carving else 0)
+        opt.flags = (_lib.FLAG_VERBOSE if verbose else 0) | (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_TIME_UPDATE if time_update else 0) | (_lib.FLAG_FIXED_CAPACITY if fixed_capacity else 0) | (_lib.FLAG_DAG_SATURATE_WEIGHTS if dag_saturate_weights else 0) | (_lib.FLAG_DAG_ONLY if dag_only else 0) | (_lib.FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.FLAG_MESH_FROM_DAG if mesh_from_dag else 0) | (_lib.FLAG_SPACE_CARVING if space_carving else 0) | (_lib.FLAG_MESH_TETRAHEDRA if mesh_tetrahedra else 0)
         opt.update_mode = update_mode
         opt.dag_pool_bytes = dag_pool_bytes
         handle = C.c_void_p()
@@ -152,6 +152,14 @@ class TSDFMap:
         r = np.ascontiguousarray(rotation, dtype=np.float32).reshape(9)
         t = np.ascontiguousarray(translation, dtype=np.float32).reshape(3)
         _lib.check(self._lib.chad_map_set_submap_pose(self._h, submap, r.ctypes.data, t.ctypes.data), "TSDFMap.set_submap_pose")
+
+    def mesh_normals(self, submap: int = 0):
+        """Unit normal per vertex of mesh(submap) (f32 [V,3]): the normalised sum of the adjacent faces' unit normals (lvr2.cpp:296-297)."""
+        nv = C.c_size_t()
+        _lib.check(self._lib.chad_map_mesh_normals(self._h, submap, None, 0, C.byref(nv)), "TSDFMap.mesh_normals")
+        n = np.empty((nv.value, 3), dtype=np.float32)
+        _lib.check(self._lib.chad_map_mesh_normals(self._h, submap, n.ctypes.data, nv.value, C.byref(nv)), "TSDFMap.mesh_normals")
+        return n
 
     def mesh(self, submap: int = 0):
         """(vertices f32 [V,3], triangles u32 [T,3]) of the sd = 0 surface of a submap (closed: >= 0; active: -1)."""

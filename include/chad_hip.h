@@ -71,6 +71,8 @@ enum {
                                        the voxels it crosses before its truncation band -- the traversal of octree.hpp:100-152 on
                                        [position, p - trunc * dir], without that segment's last voxel -- one observation of +sdf_trunc, where they
                                        already hold a leaf; nothing is created.  Frames then run one after the other; not with chad_map_attach_comm */
+    CHAD_FLAG_MESH_TETRAHEDRA = 512u, /* chad_map_mesh / save triangulate by marching tetrahedra (six per cell, no case table, watertight by
+                                         construction: rounds 2-4's triangulation) instead of marching cubes (the default: what LVR2's boxes do) */
     CHAD_FLAG_DAG_ONLY = 32u /* a closed submap is folded into the DAG as soon as its archive is complete and its dense brick copy
                                 is released: device memory then holds the active submap only (long trajectories), as the reference
                                 keeps nothing but the DAG of a closed submap (tsdf.cpp:53-54).  Closed submaps are then read back with
@@ -322,14 +324,20 @@ chad_status chad_map_raycast(chad_map* map, const float* origins, const float* d
 
 /* ---- Mesh: what TSDFMap::save produces through LVR2 in the reference (tsdf.cpp:85 -> lvr2.cpp:275-321).
  * The grid is the reference's (lvr2.cpp:15-133: a query point per leaf at its voxel corner, cells = cubes of eight query points,
- * cells with a missing corner culled); the sd = 0 surface inside each cell is triangulated on the device by marching tetrahedra
- * (six per cell) -- LVR2 is not available, so there is nothing to be bit-compatible with: this row is parity-unpinned.
+ * cells with a missing corner culled); the sd = 0 surface inside each cell is triangulated on the device by MARCHING CUBES as LVR2's
+ * boxes do it (lvr2.cpp:246-251: BoxT::getSurface per cell) -- case index bit i = corner i's distance is positive, the published
+ * 256-case table, corners placed by linear interpolation along their cell edge -- or, with CHAD_FLAG_MESH_TETRAHEDRA, by marching
+ * tetrahedra.  LVR2 is not available here: this is agreement with the published algorithm (held against the oracle's restatement of
+ * it), not with LVR2's output, and BilinearFastBox::optimizePlanarFaces (lvr2.cpp:262) is not modelled -- the row stays parity-unpinned.
  * submap >= 0: a closed submap (the reference meshes _submaps.front()); < 0: the active one.  Vertices: 3 floats each, welded
  * (every vertex once); triangles: 3 vertex indices each, oriented towards increasing signed distance (the sensor's side).
  * Call with NULL buffers for the sizes. */
 chad_status chad_map_mesh(chad_map* map, int32_t submap, float* vertices, size_t vertex_capacity, uint32_t* triangles, size_t triangle_capacity,
                           size_t* vertex_count, size_t* triangle_count);
-chad_status chad_map_save_mesh(chad_map* map, int32_t submap, const char* filename);   /* binary little-endian PLY */
+/* ... and a unit normal per vertex of that mesh (3 floats each, the order of chad_map_mesh's vertices): the normalised sum of the unit
+ * normals of the faces around the vertex -- what the reference stores with the model it saves (lvr2.cpp:296-297, 309-313). */
+chad_status chad_map_mesh_normals(chad_map* map, int32_t submap, float* normals, size_t vertex_capacity, size_t* vertex_count);
+chad_status chad_map_save_mesh(chad_map* map, int32_t submap, const char* filename);   /* binary little-endian PLY: x y z nx ny nz per vertex, triangles */
 /* Stage read-back for parity: the grid itself, i.e. what ChadGrid's constructor (lvr2.cpp:15-133) leaves in m_cells / m_queryPoints before
  * LVR2 triangulates it -- the COMPLETE cells (all eight corners hold a leaf, lvr2.cpp:115-129), ascending by the Morton code of their
  * lowest corner (MortonCode(cell_chunk)._value, lvr2.cpp:105); corners[8 * c + i] = signed distance of the query point at vertex i

@@ -773,6 +773,43 @@ size_t oracle_chad_grid(void* h, uint32_t submap, uint64_t* codes, float* corner
     return g.cells.size();
 }
 
+// Marching cubes over ChadGrid's complete cells -- what LVR2's FastReconstruction does with them (lvr2.cpp:246-251: BoxT::getSurface per
+// cell).  LVR2 is a third-party dependency absent from this image (cmake/lvr2.cmake:10, release 25.1.0), so this restates the PUBLISHED
+// algorithm its FastBox family implements, not LVR2's code: the case index has bit i set where corner i's distance is positive
+// (FastBox::getIndex), the 256-case table of Lorensen & Cline as tabulated by Bourke (marching_cubes_table.inc, the oracle's own copy,
+// generated and checked by scripts/mc_table_check.py) lists up to five triangles by the cell edges their corners lie on, and a corner
+// is placed by linear interpolation between its edge's two query points.  BilinearFastBox::optimizePlanarFaces (lvr2.cpp:262) is not
+// modelled.  Positions in f32 with the interpolation written from the edge's first corner in (z, y, x) order, as the device's
+// kernel writes it.  triangles: 9 floats each, in cell order then table order; returns their number, writes at most cap.
+#include "marching_cubes_table.inc"
+size_t oracle_marching_cubes(const uint64_t* codes, const float* corners, size_t cells, float res, float* triangles, size_t cap) {
+    static const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};   // lvr2.cpp:92-102
+    static const int edge_a[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, edge_b[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+    size_t count = 0;
+    for (size_t c = 0; c < cells; c++) {
+        const float* val = corners + 8 * c;
+        int32_t bx, by, bz;
+        morton_decode(codes[c], bx, by, bz);
+        uint32_t index = 0;
+        for (int v = 0; v < 8; v++) if (val[v] > 0.0f) index |= 1u << v;
+        for (int t = 0; kOracleMarchingCubes[index][t] >= 0; t += 3, count++) {
+            if (count >= cap) continue;
+            for (int k = 0; k < 3; k++) {
+                const int e = kOracleMarchingCubes[index][t + k];
+                int p = edge_a[e], q = edge_b[e];
+                if (oz[p] * 4 + oy[p] * 2 + ox[p] > oz[q] * 4 + oy[q] * 2 + ox[q]) std::swap(p, q);
+                const float sp = val[p], sq = val[q];
+                const float w = sp / (sp - sq);
+                const float px = float(bx + ox[p]) * res, py = float(by + oy[p]) * res, pz = float(bz + oz[p]) * res;
+                const float qx = float(bx + ox[q]) * res, qy = float(by + oy[q]) * res, qz = float(bz + oz[q]) * res;
+                float* out = triangles + 9 * count + 3 * k;
+                out[0] = px + (qx - px) * w; out[1] = py + (qy - py) * w; out[2] = pz + (qz - pz) * w;
+            }
+        }
+    }
+    return count;
+}
+
 // ---- stage-level entry points for unit parity tests ----
 // morton.hpp:21-28,59-80: codes of n points (no D2 filtering: callers pass valid points)
 void oracle_morton_codes(const float* xyz, size_t n, float res, uint64_t* out) {

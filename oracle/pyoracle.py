@@ -69,6 +69,8 @@ def lib():
         L.oracle_map_close_submap_from_leaves.argtypes = [vp, vp, vp, vp, sz]
         L.oracle_chad_grid.restype = sz
         L.oracle_chad_grid.argtypes = [vp, C.c_uint32, vp, vp, sz, vp]
+        L.oracle_marching_cubes.restype = sz
+        L.oracle_marching_cubes.argtypes = [vp, vp, sz, C.c_float, vp, sz]
         _lib = L
     return _lib
 
@@ -162,6 +164,17 @@ class OracleMap:
         corners = np.empty((n, 8), dtype=np.float32)
         lib().oracle_chad_grid(self._h, submap, _p(codes), _p(corners), n, _p(qp))
         return codes, corners, int(qp[0])
+
+    @staticmethod
+    def marching_cubes(codes: np.ndarray, corners: np.ndarray, res: float) -> np.ndarray:
+        """Triangle soup f32 [T, 3, 3] of marching cubes over complete cells (codes u64 [C], corners f32 [C, 8]): the published algorithm LVR2's
+        FastBox implements (case bit i = corner i's distance positive, the 256-case table, linear interpolation along cell edges)."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        corners = np.ascontiguousarray(corners, dtype=np.float32)
+        n = lib().oracle_marching_cubes(_p(codes), _p(corners), len(codes), res, None, 0)
+        out = np.empty((n, 3, 3), dtype=np.float32)
+        assert lib().oracle_marching_cubes(_p(codes), _p(corners), len(codes), res, _p(out), n) == n
+        return out
 
     @property
     def finalize_ms(self) -> float:

@@ -207,20 +207,21 @@ def edge_use(tri):
     return e, key, count, inv
 
 
-@pytest.mark.parametrize("from_dag", [False, True])
-def test_mesh_of_the_reference_demo_sphere(chad, tmp_path, from_dag):
+@pytest.mark.parametrize("from_dag,tetrahedra", [(False, False), (True, False), (False, True), (True, True)])
+def test_mesh_of_the_reference_demo_sphere(chad, tmp_path, from_dag, tetrahedra):
     """f3 by properties (LVR2 is absent: parity-unpinned).  The reference's demo (main.cpp:9-39): points on a 5 m sphere around
-    the sensor, TSDFMap(0.05, 0.1), insert, save("mesh.ply").  The mesh: every vertex within one voxel of r = 5 m; a 2-manifold
-    with boundary (every edge in one or two triangles, used once per direction when shared); consistently oriented towards the
-    sensor; all of the sphere covered; the PLY holds exactly that mesh."""
+    the sensor, TSDFMap(0.05, 0.1), insert, save("mesh.ply").  The mesh -- marching cubes by default, marching tetrahedra on request:
+    every vertex within one voxel of r = 5 m; a 2-manifold with boundary (every edge in one or two triangles, used once per direction
+    when shared); consistently oriented towards the sensor; all of the sphere covered; a unit normal per vertex, towards the sensor;
+    the PLY holds exactly that mesh, normals included (lvr2.cpp:296-313)."""
     res, trunc = 0.05, 0.10
     pts, pos = sphere_scan()
-    m = chad.TSDFMap(res, trunc, mesh_from_dag=from_dag)
+    m = chad.TSDFMap(res, trunc, mesh_from_dag=from_dag, mesh_tetrahedra=tetrahedra)
     m.insert(pts, pos)
     path = str(tmp_path / "mesh.ply")
     m.save(path)                                               # closes the submap, finalizes, reconstructs submap 0 (tsdf.cpp:76-86)
     v, tri = m.mesh(0)
-    assert len(v) > 100_000 and len(tri) > 200_000 and tri.max() < len(v)
+    assert len(v) > 100_000 and len(tri) > (200_000 if tetrahedra else 150_000) and tri.max() < len(v)
     r = np.linalg.norm(v.astype(np.float64), axis=1)
     assert np.abs(r - 5.0).max() < res and np.abs(r - 5.0).mean() < 0.25 * res
     assert len(np.unique(v, axis=0)) == len(v)                 # welded: every vertex once
@@ -237,18 +238,67 @@ def test_mesh_of_the_reference_demo_sphere(chad, tmp_path, from_dag):
     inward = np.einsum("ij,ij->i", normal, -(a + b + c)) > 0           # towards the sensor at the centre (increasing sd)
     assert area[inward].sum() / area.sum() > 0.9999
     assert abs(area.sum() / (4 * np.pi * 25.0) - 1.0) < 0.05            # the whole sphere, once
-    # the file: binary little-endian PLY with these vertices and faces
+    # a normal per vertex: the normalised sum of the unit normals of the faces around it (lvr2.cpp:296-297), pointing at the sensor
+    vn = m.mesh_normals(0)
+    assert vn.shape == v.shape
+    unit = normal / np.maximum(np.linalg.norm(normal, axis=1), 1e-300)[:, None]
+    summed = np.zeros_like(v, dtype=np.float64)
+    for k in range(3):
+        np.add.at(summed, tri[:, k], unit)
+    summed /= np.maximum(np.linalg.norm(summed, axis=1), 1e-300)[:, None]
+    assert np.abs(vn - summed).max() < 1e-4
+    assert np.abs(np.linalg.norm(vn.astype(np.float64), axis=1) - 1.0).max() < 1e-5
+    towards_sensor = -np.einsum("ij,ij->i", vn.astype(np.float64), v.astype(np.float64)) / np.linalg.norm(v.astype(np.float64), axis=1)
+    assert towards_sensor.min() > 0.5 and towards_sensor.mean() > 0.98
+    # the file: binary little-endian PLY with these vertices, their normals and the faces
     raw = open(path, "rb").read()
     head, body = raw.split(b"end_header\n", 1)
     assert b"element vertex %d" % len(v) in head and b"element face %d" % len(tri) in head and b"binary_little_endian" in head
-    assert np.array_equal(np.frombuffer(body[: 12 * len(v)], "<f4").reshape(-1, 3), v)
-    faces = np.frombuffer(body[12 * len(v):], np.dtype([("n", "u1"), ("i", "<u4", 3)]))
+    assert head.index(b"property float z") < head.index(b"property float nx") < head.index(b"property float nz") < head.index(b"element face")
+    rows = np.frombuffer(body[: 24 * len(v)], "<f4").reshape(-1, 6)
+    assert np.array_equal(rows[:, :3], v) and np.array_equal(rows[:, 3:], vn)
+    faces = np.frombuffer(body[24 * len(v):], np.dtype([("n", "u1"), ("i", "<u4", 3)]))
     assert len(faces) == len(tri) and np.all(faces["n"] == 3) and np.array_equal(faces["i"], tri)
     m.close()
 
 
+def test_mesh_is_marching_cubes_over_the_references_grid(chad, oracle):
+    """f3: the default triangulation against the oracle's restatement of what LVR2's boxes do with ChadGrid's cells (lvr2.cpp:246-251) --
+    the published marching-cubes algorithm: case bit i = corner i's distance positive (FastBox::getIndex), the 256-case table
+    (scripts/mc_table_check.py checks every case of it), corners by linear interpolation along cell edges.  Grid AND triangulation from
+    the oracle (ChadGrid over its own NodeLevels, then oracle_marching_cubes); mesh from the device, read through the DAG as the reference
+    reads it: the two must be the same set of oriented triangles, coordinate bits included (triangles that lose a corner to the welding --
+    a surface through a grid point -- are dropped on both sides).  Agreement with the published algorithm, not with LVR2's output:
+    LVR2 is absent, and BilinearFastBox::optimizePlanarFaces (lvr2.cpp:262) is not modelled."""
+    res, trunc = 0.05, 0.10
+    for pts, pos in (sphere_scan(400_000), synth.cfg2_frame(300_000)):
+        m = chad.TSDFMap(res, trunc, mesh_from_dag=True)
+        m.insert(pts, pos)
+        mc, sd, w = m.export_leaves()
+        m.close_submap()
+        o = oracle.OracleMap(res, trunc)
+        o.close_submap_from_leaves(mc, sd, w)
+        codes, corners, _ = o.chad_grid(0)
+        want = o.marching_cubes(codes, corners, res) + np.float32(0.0)   # (-0 -> +0: the same place)
+        v, tri = m.mesh(0)
+        got = v[tri] + np.float32(0.0)
+        assert len(got) > 50_000
+        # every vertex as its index among all distinct vertices; a triangle as its three indices, rotated so that the smallest comes first
+        both = np.concatenate([got.reshape(-1, 3), want.reshape(-1, 3)]).view(np.uint32)
+        _, index = np.unique(both, axis=0, return_inverse=True)
+        index = index.reshape(-1, 3)
+        index = index[(index[:, 0] != index[:, 1]) & (index[:, 1] != index[:, 2]) & (index[:, 0] != index[:, 2])]   # (only `want` still has such)
+        first = np.argmin(index, axis=1)
+        rolled = np.stack([index[np.arange(len(index)), (first + k) % 3] for k in range(3)], axis=1)
+        g, w_ = rolled[:len(got)], rolled[len(got):]
+        order = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        assert len(g) == len(got) and len(w_) == len(g), (len(got), len(w_))
+        assert np.array_equal(order(g), order(w_))
+        m.close()
+
+
 def test_mesh_vertices_on_cell_edges_are_the_marching_cubes_vertices_of_the_references_grid(chad, oracle):
-    """f3, what can be pinned of the triangulation without LVR2: the VERTEX SET.  Whatever case table a marching-cubes box uses (LVR2's
+    """f3 with CHAD_FLAG_MESH_TETRAHEDRA, what can be pinned of that triangulation: the VERTEX SET.  Whatever case table a marching-cubes box uses (LVR2's
     FastBox::getSurface, called at lvr2.cpp:247), its vertices are the points where sd = 0 crosses one of the twelve edges of a complete
     cell, placed by linear interpolation between the edge's two query points -- a definition that involves no table.  Computed here in
     f64 from the ORACLE's ChadGrid (lvr2.cpp:15-133 restated: cells, corner values in the vertex order of lvr2.cpp:92-102), that set
@@ -259,7 +309,7 @@ def test_mesh_vertices_on_cell_edges_are_the_marching_cubes_vertices_of_the_refe
 
     res, trunc = 0.05, 0.10
     pts, pos = sphere_scan(400_000)
-    m = chad.TSDFMap(res, trunc, mesh_from_dag=True)
+    m = chad.TSDFMap(res, trunc, mesh_from_dag=True, mesh_tetrahedra=True)
     m.insert(pts, pos)
     mc, sd, w = m.export_leaves()
     m.close_submap()
