@@ -90,17 +90,26 @@ struct DevPool {
         if (len > bytes) free_ranges[at + bytes] = len - bytes;
         return base + at;
     }
-    void give(void* p, size_t bytes) {
+    // A range goes back -- and may be handed out again at once: the caller guarantees that every access to it was enqueued on ONE stream
+    // and that the next user's accesses are enqueued on that stream too (DeviceDag::pool_stream says which; store_alloc waits for an event
+    // when a level is first touched from another stream).  false: `p` is not a range this pool handed out -- nothing is changed (the caller
+    // reports it; a double release or a foreign pointer would otherwise corrupt the free list silently).
+    bool give(void* p, size_t bytes) {
         bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) & ~(kAlign - 1);
+        if (!owns(p)) return false;
         size_t at = size_t(static_cast<char*>(p) - base), len = bytes;
-        used -= bytes;
+        if (at % kAlign || at + bytes > cap || bytes > used) return false;
         auto next = free_ranges.lower_bound(at);
+        if (next != free_ranges.end() && next->first < at + bytes) return false;                                             // overlaps the free range behind it
+        if (next != free_ranges.begin()) { auto prev = std::prev(next); if (prev->first + prev->second > at) return false; }   // ... or the one in front: already free
+        used -= bytes;
         if (next != free_ranges.begin()) {
             auto prev = std::prev(next);
             if (prev->first + prev->second == at) { at = prev->first; len += prev->second; free_ranges.erase(prev); }
         }
         if (next != free_ranges.end() && at + len == next->first) { len += next->second; free_ranges.erase(next); }
         free_ranges[at] = len;
+        return true;
     }
     void reset() {   // everything handed out is dead (the DAG was thrown away)
         free_ranges.clear();

@@ -273,6 +273,8 @@ struct chad_map {
     // every rank turns its range into cluster words and rank 0 folds the submap -- once.  Five stages (sparse_stages), polled like the dense ones.
     static constexpr uint32_t kMergeHostWords = 4096;   // merge_host: [0, 1024) heads of all ranks | [1024, 1040) splitters | [1056, 1568) the G x G matrix | [1600, 1616) union sizes | [1632] this rank's
     bool closing_sparse = false;
+    hipEvent_t comm_wait_event = nullptr;         // the exchange's event being waited for, and since when (comm_wait: CHAD_COMM_TIMEOUT_S)
+    std::chrono::steady_clock::time_point comm_wait_since{};
     bool dag_remote = false;                      // this rank's closed submaps were folded on rank 0: it holds no DAG of its own
     struct SparseExchange {
         uint32_t nb = 0, wide = 0, n_union = 0, recv_blocks = 0;
@@ -701,16 +703,24 @@ chad_status merge_begin(chad_map* m, chad_comm* c) {
 // down -- the share is dropped, its table cleared and kept as the spare, an empty submap stands in for the lost one so that submap
 // indices stay aligned with their poses -- so that this rank reports the error once instead of re-entering the stage on every later
 // insert.  The remaining collectives of the exchange are NOT issued: the peers' next collective waits for this rank (RCCL's own
-// watchdog, NCCL_TIMEOUT, ends that wait); a failed exchange is fatal for the sharded map as a whole.
+// watchdog, NCCL_TIMEOUT, ends that wait, or their own CHAD_COMM_TIMEOUT_S): ANY failure of a stage on one rank -- a purely local one
+// like its scratch not fitting included -- is fatal for the sharded map as a whole (INTEGRATION.md says so).
 static void merge_abort(chad_map* m) {
     if (!m->closing) return;
+    const bool sparse = m->closing_sparse, not_rank0 = m->closing_comm && m->closing_comm->rank != 0;
     if (chad_comm* c = m->closing_comm) c->abort();   // (RCCL: a collective stuck on the stream is killed with its communicator; the communicator is dead from here on)
     m->closing_sparse = false;
+    m->comm_wait_event = nullptr;
     enqueue_clear(m->closing_view, m->stream);
     (void)hipGetLastError();
     m->spare_flags = std::max(m->spare_flags, 1);
     Submap lost;
-    if (alloc_submap(lost, 0) != CHAD_OK) { free_submap(lost); (void)hipGetLastError(); }
+    if (sparse) {
+        // the sparse exchange keeps no bricks of a closed submap: the lost one is a released place holder like every other, and on the
+        // ranks that hold no DAG so are its roots -- a dense archive here would later be folded into a stray DAG of this rank's own
+        lost.released = true;
+        if (not_rank0) { m->dag_roots.push_back({0u, 0u}); m->dag_remote = true; }
+    } else if (alloc_submap(lost, 0) != CHAD_OK) { free_submap(lost); (void)hipGetLastError(); }
     m->closed.push_back(lost);
     m->spare = m->closing_view; m->has_spare = true;
     m->closing_view = MapView{}; m->closing = false; m->closing_comm = nullptr; m->merge_stage = 0;
@@ -723,18 +733,21 @@ static double comm_timeout_s() {
     static const double limit = std::getenv("CHAD_COMM_TIMEOUT_S") ? std::atof(std::getenv("CHAD_COMM_TIMEOUT_S")) : 120.0;
     return limit;
 }
+// The clock runs from the first look at an event, and a look that does not block applies the limit too: a rank that keeps inserting
+// (every insert polls the exchange) notices a silent peer after the same time as one that waits.
 static chad_status comm_wait(chad_map* m, hipEvent_t ev, bool block) {
-    (void)m;
-    if (!block) return CHAD_OK;
-    const auto t0 = std::chrono::steady_clock::now();
+    if (m->comm_wait_event != ev) { m->comm_wait_event = ev; m->comm_wait_since = std::chrono::steady_clock::now(); }
     for (uint32_t polls = 0;; polls++) {
         const hipError_t e = hipEventQuery(ev);
-        if (e == hipSuccess) return CHAD_OK;
+        if (e == hipSuccess) { m->comm_wait_event = nullptr; return CHAD_OK; }
         (void)hipGetLastError();
         if (e != hipErrorNotReady) HIP_TRY(e);
-        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (comm_timeout_s() > 0 && waited > comm_timeout_s())
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - m->comm_wait_since).count();
+        if (comm_timeout_s() > 0 && waited > comm_timeout_s()) {
+            m->comm_wait_event = nullptr;
             return fail(CHAD_ERR_HIP, "a stage of the exchange did not complete within " + std::to_string(int(comm_timeout_s())) + " s (a peer that never issued its collective?)");
+        }
+        if (!block) return CHAD_OK;
         if (polls > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }

@@ -627,21 +627,34 @@ struct DeviceDag {
     uint64_t hint_entries[kDagDepth + 1] = {}, hint_words[kDagDepth + 1] = {};   // chad_map_dag_reserve: what the levels are expected to hold in the end -- they are made that size
     bool ready = false;
 
-    // a table or store for a level: from the pool while it lasts
-    hipError_t store_alloc(void** out, size_t bytes) {
-        if (void* p = pool.take(bytes)) { *out = p; return hipSuccess; }
+    // A range of the pool that a level gives up for a bigger one is free for the NEXT allocation at once: what makes that safe is stream
+    // order -- whoever gets the range writes it with work enqueued BEHIND the copy / rehash that still reads it.  The levels are touched
+    // from two streams (the fold's, and the map's for submaps folded start to finish): the stream of the last retirement is remembered with
+    // an event behind it, and an allocation made for work on another stream makes that stream wait for the event first.
+    hipStream_t retired_on = nullptr;
+    hipEvent_t retired_event = nullptr;
+    bool retired_any = false, pool_corrupt = false;   // pool_corrupt: a range was given back that the pool never handed out (reported by the next fold)
+    // a table or store for a level, to be used by work on stream `s`: from the pool while it lasts
+    hipError_t store_alloc(void** out, size_t bytes, hipStream_t s) {
+        if (void* p = pool.take(bytes)) {
+            if (retired_any && s != retired_on) { const hipError_t e = hipStreamWaitEvent(s, retired_event, 0); if (e != hipSuccess) { (void)pool.give(p, bytes); return e; } }
+            *out = p;
+            return hipSuccess;
+        }
         return chad_malloc(out, bytes);
     }
-    // ... given up for a bigger one: a range of the pool is free for the NEXT allocation at once (whoever gets it writes it with work enqueued
-    // behind the copy / rehash that still reads it: every access to a level is enqueued on the fold's stream)
-    void store_retire(void* p, size_t bytes) {
+    // ... given up for a bigger one; the last work that reads it has been enqueued on stream `s`
+    void store_retire(void* p, size_t bytes, hipStream_t s) {
         if (!p) return;
-        if (pool.owns(p)) pool.give(p, bytes);
-        else { outgrown.push_back(p); outgrown_bytes += bytes; }
+        if (pool.owns(p)) {
+            if (!pool.give(p, bytes)) { pool_corrupt = true; return; }
+            if (!retired_event && hipEventCreateWithFlags(&retired_event, hipEventDisableTiming) != hipSuccess) { retired_event = nullptr; (void)hipGetLastError(); }
+            if (retired_event && hipEventRecord(retired_event, s) == hipSuccess) { retired_on = s; retired_any = true; }
+        } else { outgrown.push_back(p); outgrown_bytes += bytes; }
     }
     void store_free(void* p, size_t bytes) {   // (never used by the device, or the device is idle)
         if (!p) return;
-        if (pool.owns(p)) pool.give(p, bytes); else (void)chad_free(p);
+        if (pool.owns(p)) { if (!pool.give(p, bytes)) pool_corrupt = true; } else (void)chad_free(p);
     }
     void free_outgrown() {   // (the device is idle: nothing is folding, nothing reads a level)
         for (void* p : outgrown) (void)chad_free(p);
@@ -656,7 +669,8 @@ struct DeviceDag {
         }
         free_outgrown();
         pool.reset();
-        if (pool_too) pool.release();
+        retired_any = false; pool_corrupt = false;
+        if (pool_too) { pool.release(); if (retired_event) (void)hipEventDestroy(retired_event); retired_event = nullptr; }
         if (pool_too) {   // (a reset keeps the fold's scratch and the few scalars: a map that is reset and filled again allocates nothing)
             (void)chad_free(d_scalars); (void)chad_free(d_total); (void)chad_free(d_hist); (void)chad_free(arena);
             if (h_small) (void)hipHostFree(h_small);
@@ -685,8 +699,8 @@ inline hipError_t dag_device_init(DeviceDag& d, hipStream_t s) {
             L.table_slots = uint32_t(slots);
             L.raw_capacity = uint32_t(std::min<uint64_t>(std::max<uint64_t>(L.raw_capacity, d.hint_words[l] + d.hint_words[l] / 16 + 4096), (1ull << 32) - 1));
         }
-        if ((e = d.store_alloc(reinterpret_cast<void**>(&L.table), size_t(L.table_slots) * 4)) != hipSuccess) return e;
-        if ((e = d.store_alloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4))) != hipSuccess) return e;
+        if ((e = d.store_alloc(reinterpret_cast<void**>(&L.table), size_t(L.table_slots) * 4, s)) != hipSuccess) return e;
+        if ((e = d.store_alloc(&L.raw, size_t(L.raw_capacity) * (l == kDagDepth ? 8 : 4), s)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(L.table, 0, size_t(L.table_slots) * 4, s)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(L.raw, 0, l == kDagDepth ? 8 : 4, s)) != hipSuccess) return e;   // address 0: the reserved word (levels.hpp:52, :118)
         d.h_scalars[l] = DagScalars{};
@@ -704,6 +718,7 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
     const bool cluster = l == kDagDepth;
     const size_t need_slots = 2 * (size_t(d.h_scalars[l].entries) + n) + 16;
     hipError_t e;
+    if (d.pool_corrupt) return hipErrorInvalidValue;   // (a range went back to the pool that it never handed out: its free list is not to be trusted)
     static const bool report = std::getenv("CHAD_DEBUG_DAG_GROWTH") != nullptr;   // which level grows, and why (stderr)
     if (report && (need_slots > L.table_slots || size_t(d.h_scalars[l].size) + n * words_each + 16 > L.raw_capacity))
         std::fprintf(stderr, "chad: DAG level %u grows: %zu candidates x %u words; table %u slots (needs %zu), store %u words (needs %zu); entries %u, size %u\n", l, n, words_each,
@@ -719,12 +734,12 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
         slots = std::min<size_t>(slots, size_t(1) << 31);
         if (need_slots > (size_t(1) << 31)) return hipErrorOutOfMemory;   // (a table of 2^31 slots: a billion values in one level)
         uint32_t* bigger = nullptr;
-        if ((e = d.store_alloc(reinterpret_cast<void**>(&bigger), slots * 4)) != hipSuccess) return e;
+        if ((e = d.store_alloc(reinterpret_cast<void**>(&bigger), slots * 4, s)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(bigger, 0, slots * 4, s)) != hipSuccess) { d.store_free(bigger, slots * 4); return e; }
         if (cluster) hipLaunchKernelGGL(k_dag_rehash<false>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
         else hipLaunchKernelGGL(k_dag_rehash<true>, dag_grid(L.table_slots), dim3(256), 0, s, L.table, L.table_slots, L.raw, bigger, uint32_t(slots - 1));
         // (no wait, no hipFree: what follows on this stream comes behind the rehash, and nothing else reads a level while a fold is in flight)
-        d.store_retire(L.table, size_t(L.table_slots) * 4);
+        d.store_retire(L.table, size_t(L.table_slots) * 4, s);
         d.growths++;
         L.table = bigger; L.table_slots = uint32_t(slots);
     }
@@ -737,9 +752,9 @@ inline hipError_t dag_level_reserve(DeviceDag& d, uint32_t l, size_t n, uint32_t
         words = std::min<size_t>(words, (size_t(1) << 32) - 1 - n);
         const size_t unit = cluster ? 8 : 4;
         void* bigger = nullptr;
-        if ((e = d.store_alloc(&bigger, words * unit)) != hipSuccess) return e;
+        if ((e = d.store_alloc(&bigger, words * unit, s)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(bigger, L.raw, size_t(d.h_scalars[l].size) * unit, hipMemcpyDeviceToDevice, s)) != hipSuccess) { d.store_free(bigger, words * unit); return e; }
-        d.store_retire(L.raw, size_t(L.raw_capacity) * unit);
+        d.store_retire(L.raw, size_t(L.raw_capacity) * unit, s);
         d.growths++;
         L.raw = bigger; L.raw_capacity = uint32_t(words);
     }
