@@ -32,6 +32,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cfg5_trace" -- pyt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/cfg5_fetch" -- python3 $O > "$out/cfg5_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/cfg5_write" -- python3 $O > "$out/cfg5_write.log" 2>&1
 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/cfg5_tcc" -- python3 $O > "$out/cfg5_tcc.log" 2>&1
+# (round 5) ... and its reads by request size, as for cfg2: FETCH_SIZE alone only brackets them on this chip
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$out/cfg5_rdreq" -- python3 $O > "$out/cfg5_rdreq.log" 2>&1
 echo "cfg5 done"
 # ... and the same trajectory kept as its DAG only (CHAD_FLAG_DAG_ONLY: the closing table straight to cluster words, the fold on the device)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cfg5dag_trace" -- python3 scripts/cfg5_dagonly.py --frames 110 > "$out/cfg5dag_trace.log" 2>&1

@@ -93,8 +93,11 @@ if glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursi
     stats5 = sorted(glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursive=True))[-1]
     shutil.copy(stats5, os.path.join(prof, f"{tag}_cfg5_kernel_stats.csv"))
     per5 = collections.defaultdict(dict)
-    for group in ("cfg5_fetch", "cfg5_write", "cfg5_tcc"):
-        f = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))[-1]
+    for group in ("cfg5_fetch", "cfg5_write", "cfg5_tcc", "cfg5_rdreq"):
+        found = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
+        if not found:
+            continue
+        f = found[-1]
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("chadhip::", "").replace("void ", "")
@@ -108,7 +111,14 @@ if glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursi
     for r in csv.DictReader(open(stats5)):
         print(f'{r["Name"].split("(")[0][:60]:60s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"]) / 1e3:8.2f} us  {r["Percentage"]:>6s}%')
     u5 = [k for k in per5 if k.startswith("k_update_tiled<false")]
-    if u5: print("cfg5 update kernel counters per launch:", json.dumps(per5[u5[0]]))
+    if u5:
+        c5 = per5[u5[0]]
+        if "TCC_EA0_RDREQ_128B_sum" in c5:   # bytes read, from the request sizes (the same arithmetic as cfg2's traffic figure)
+            c5["read_bytes_from_request_sizes"] = 32 * c5.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * c5.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * c5.get("TCC_EA0_RDREQ_128B_sum", 0)
+            if "WRITE_SIZE" in c5:
+                c5["hbm_bytes_per_launch"] = c5["read_bytes_from_request_sizes"] + c5["WRITE_SIZE"] * 1024   # (WRITE_SIZE in KiB)
+        json.dump(per5, open(os.path.join(prof, f"{tag}_cfg5_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
+        print("cfg5 update kernel counters per launch:", json.dumps(c5))
 
 # the same trajectory kept as its DAG only (scripts/cfg5_dagonly.py under the kernel trace)
 dag = sorted(glob.glob(os.path.join(src, "cfg5dag_trace", "**", "*kernel_stats.csv"), recursive=True))
