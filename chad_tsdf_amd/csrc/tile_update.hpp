@@ -148,20 +148,6 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     };
     uint32_t applied = 0;
 
-    // lane = voxel v of a brick (Morton order of the low 6 code bits).  This wave's bricks: (bx, by) = 0..3 x 0..3 in
-    // slab bz = wave; brick b sits at voxel offset 4 * (b - 1) from the super block's corner.
-    const int vx = int((lane & 1u) | ((lane >> 2) & 2u)), vy = int(((lane >> 1) & 1u) | ((lane >> 3) & 2u)), vz = int(((lane >> 2) & 1u) | ((lane >> 4) & 2u));
-    const int tz = 4 * int(wave) + vz + R - 4;
-    const int slab_cell = (vx + R - 4) + D * (vy + R - 4) + D * D * tz;   // this lane's cell in brick (0, 0) of the slab
-    uint32_t lane_valid = 0;   // bit bx + 4 * by: this lane's voxel of that brick lies inside the tile
-    for (int b = 0; b < 16; b++) {
-        const int tx = 4 * (b & 3) + vx + R - 4, ty = 4 * (b >> 2) + vy + R - 4;
-        if (uint32_t(tx) < uint32_t(D) && uint32_t(ty) < uint32_t(D) && uint32_t(tz) < uint32_t(D)) lane_valid |= 1u << b;
-    }
-    // cell of this lane's voxel in brick b of the slab.  For a voxel outside the tile the address is meaningless but
-    // harmless (DS reads beyond the workgroup's allocation return zero; every use is masked by lane_valid)
-    auto cell_of = [&](int b) { return uint32_t(slab_cell + 4 * ((b & 3) + D * (b >> 2))); };
-
     const uint32_t group = blockIdx.x % kWorkGroups;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t_begin = 0, items_done = 0;
     if (kStamps) { t_begin = stamp_now(); }
@@ -169,27 +155,24 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
     // everything a wave holds about an item before it starts on it
     if (blockIdx.x >= nitems) record = make_uint4(0u, 0u, 0u, 0u);   // length 0: no more work
     float4 q_first = make_float4(0, 0, 0, 0), n_first = make_float4(0, 0, 0, 0);            // its first chunk's point and normal for this lane
-    uint64_t my_key = kEmptyKey;                                                            // lanes 0..15: key of their brick
-    uint32_t my_slot = 0;
     auto prefetch = [&](const uint4& rec) {
         const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.x))), len = uint32_t(__builtin_amdgcn_readfirstlane(int(rec.y)));
         const uint32_t k = lane * ((len + 63u) >> 6) + wave;   // chunk `wave` of the item (see the walk)
         if (k < len) { q_first = pts[first + k]; n_first = normals[first + k]; }
-        if (lane < 16u && len) {
-            // key of brick (bx, by, wave): the corner's code with -4 / 0 / +4 / +8 voxels added per axis, in interleaved
-            // ("dilated") arithmetic -- a subtraction borrows through the zero gaps of the masked operand, an addition
-            // carries through gaps filled with ones; the corner is a multiple of 8, so +4 just sets a bit.  The four
-            // candidates per axis are wave-uniform (scalar unit); a lane only selects.
-            const uint64_t code = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(rec.z)))) | (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(rec.w)))) << 32);
-            constexpr uint64_t kMx = 0x1249249249249249ull, kMy = kMx << 1, kMz = kMx << 2;
-            const uint64_t xd = code & kMx, yd = code & kMy, zd = code & kMz;
-            const uint64_t x0 = (xd - (1ull << 6)) & kMx, x2 = xd | (1ull << 6), x3 = ((xd | ~kMx) + (1ull << 9)) & kMx;
-            const uint64_t y0 = (yd - (1ull << 7)) & kMy, y2 = yd | (1ull << 7), y3 = ((yd | ~kMy) + (1ull << 10)) & kMy;
-            const uint64_t zs = wave == 0u ? (zd - (1ull << 8)) & kMz : wave == 1u ? zd : wave == 2u ? zd | (1ull << 8) : ((zd | ~kMz) + (1ull << 11)) & kMz;
-            const uint32_t bx = lane & 3u, by = (lane >> 2) & 3u;
-            my_key = (bx == 0u ? x0 : bx == 1u ? xd : bx == 2u ? x2 : x3) | (by == 0u ? y0 : by == 1u ? yd : by == 2u ? y2 : y3) | zs;
-            my_slot = hash_block(my_key, m.hash_mask);
-        }
+    };
+    // key of brick (bx, by, wave) = lane of the super block at `code`: the corner's code with -4 / 0 / +4 / +8 voxels added per axis, in
+    // interleaved ("dilated") arithmetic -- a subtraction borrows through the zero gaps of the masked operand, an addition carries
+    // through gaps filled with ones; the corner is a multiple of 8, so +4 just sets a bit.  The four candidates per axis are
+    // wave-uniform (scalar unit); a lane only selects.  (Worked out behind the walk, from the code in scalar registers: held in vector
+    // registers across the walk -- as until round 5 -- it is three of the registers that stand between this kernel and a sixth wave per SIMD.)
+    auto brick_key = [&](uint64_t code, uint32_t l) {
+        constexpr uint64_t kMx = 0x1249249249249249ull, kMy = kMx << 1, kMz = kMx << 2;
+        const uint64_t xd = code & kMx, yd = code & kMy, zd = code & kMz;
+        const uint64_t x0 = (xd - (1ull << 6)) & kMx, x2 = xd | (1ull << 6), x3 = ((xd | ~kMx) + (1ull << 9)) & kMx;
+        const uint64_t y0 = (yd - (1ull << 7)) & kMy, y2 = yd | (1ull << 7), y3 = ((yd | ~kMy) + (1ull << 10)) & kMy;
+        const uint64_t zs = wave == 0u ? (zd - (1ull << 8)) & kMz : wave == 1u ? zd : wave == 2u ? zd | (1ull << 8) : ((zd | ~kMz) + (1ull << 11)) & kMz;
+        const uint32_t bx = l & 3u, by = (l >> 2) & 3u;
+        return (bx == 0u ? x0 : bx == 1u ? xd : bx == 2u ? x2 : x3) | (by == 0u ? y0 : by == 1u ? yd : by == 2u ? y2 : y3) | zs;
     };
     prefetch(record);
     uint32_t turn = 0;  // first lane of the last wave: ticket of the item after the current one (in flight during the walk)
@@ -281,8 +264,10 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
         if (kStamps) { const unsigned long long t1 = stamp_now(); ph[1] += t1 - t0; t0 = t1; }
 
         // step 2: which of this wave's 16 bricks received observations (four reads in flight at a time)
-        const uint64_t this_key = my_key;
-        const uint32_t this_slot = my_slot;
+        uint32_t lane_here = lane;
+        asm volatile("" : "+v"(lane_here));   // (what follows is worked out per item, behind the walk: hoisted out of the loop it would live in registers across it)
+        const uint64_t this_key = lane_here < 16u ? brick_key(corner_code, lane_here) : kEmptyKey;
+        const uint32_t this_slot = hash_block(this_key, m.hash_mask);
         // Only "does any cell of the brick hold something" is asked here, so the lanes need not sit on their voxels: 16 lanes per
         // brick, one per (y, z) row of four cells along x, four bricks (bx = 0..3 of one by) per pass -- 4 passes instead of 16, no
         // branches, all reads in flight together (the voxel-per-lane form compiled to sixteen dependent LDS round trips under
@@ -290,7 +275,7 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
         // rim along x reads its cells inside (two at least, for reach >= 2), some of them twice.
         uint32_t touched = 0;
         {
-            const int rx = 4 * int(lane >> 4) + R - 4, ry = int(lane & 3u) + R - 4, rz = 4 * int(wave) + int((lane >> 2) & 3u) + R - 4;
+            const int rx = 4 * int(lane_here >> 4) + R - 4, ry = int(lane_here & 3u) + R - 4, rz = 4 * int(wave) + int((lane_here >> 2) & 3u) + R - 4;
             const int lo = max(rx, 0), hi = min(rx + 3, D - 1);
             const uint32_t zero_at = tile_base + 8u * cells;
             const uint32_t row_a = tile_base + 8u * uint32_t(lo + D * ry + D * D * rz), delta_b = 8u * uint32_t(max(hi - 1 - lo, 0));
@@ -333,13 +318,20 @@ k_update_tiled(const float4* __restrict__ points0, const float4* __restrict__ po
         asm volatile("" : "+v"(q_first.x), "+v"(q_first.y), "+v"(q_first.z), "+v"(n_first.x), "+v"(n_first.y), "+v"(n_first.z));
         if (kStamps) { asm volatile("" :: "v"(my_brick)); const unsigned long long t1 = stamp_now(); ph[7] += t1 - t0; t0 = t1; }
 
-        // step 3: flush
+        // step 3: flush.  lane = voxel v of a brick (Morton order of the low 6 code bits).  This wave's bricks: (bx, by) = 0..3 x 0..3 in
+        // slab bz = wave; brick b sits at voxel offset 4 * (b - 1) from the super block's corner.
+        const int vx = int((lane_here & 1u) | ((lane_here >> 2) & 2u)), vy = int(((lane_here >> 1) & 1u) | ((lane_here >> 3) & 2u)), vz = int(((lane_here >> 2) & 1u) | ((lane_here >> 4) & 2u));
+        const int tz = 4 * int(wave) + vz + R - 4;
+        const int slab_cell = (vx + R - 4) + D * (vy + R - 4) + D * D * tz;   // this lane's cell in brick (0, 0) of the slab
         for (uint32_t left = touched; left;) {
             const int b = __ffs(int(left)) - 1;
             left &= left - 1u;
             const uint32_t brick = uint32_t(__builtin_amdgcn_readlane(int(my_brick), b));
-            const uint32_t at = cell_of(b);
-            const unsigned long long cell = ((lane_valid >> b) & 1u) ? tile[at] : 0ull;
+            // (a voxel outside the tile reads the spare zero cell)
+            const int tx = 4 * (b & 3) + vx + R - 4, ty = 4 * (b >> 2) + vy + R - 4;
+            const bool inside_tile = uint32_t(tx) < uint32_t(D) && uint32_t(ty) < uint32_t(D) && uint32_t(tz) < uint32_t(D);
+            const uint32_t at = inside_tile ? uint32_t(slab_cell + 4 * ((b & 3) + D * (b >> 2))) : cells;
+            const unsigned long long cell = tile[at];
             if (cell) {
                 const uint32_t c = uint32_t(cell >> kCountShift);
                 // sum of d in units of trunc / 2^30 = sum of biased fixed values - c * 2^30: an exact integer, added as such
@@ -389,8 +381,8 @@ inline TileLaunch tile_launch_shape(float res, float trunc, uint32_t cu_count) {
     const uint32_t d = 8 + 2 * t.reach;
     t.lds = uint32_t(((size_t(d) * d * d + 3) & ~size_t(1)) * 8 + 16 + 2 * (kListStripes + 1) * 4 + 8);   // tile + two spare zero cells (padded to 16 bytes) + next item's record + list index
     int resident[2] = {1, 1};
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[0], k_update_tiled<false, 5>, kTileThreads, t.lds);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[1], k_update_tiled<true, 5>, kTileThreads, t.lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[0], k_update_tiled<false, 6>, kTileThreads, t.lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[1], k_update_tiled<true, 6>, kTileThreads, t.lds);
     (void)hipGetLastError();
     uint32_t per_cu[2];
     for (int k = 0; k < 2; k++) per_cu[k] = uint32_t(std::max(1, std::min(8, resident[k])));
@@ -407,14 +399,16 @@ inline void tile_update_enqueue(const TileLaunch& shape, const float4* points0, 
                                 unsigned long long* stamps = nullptr, hipEvent_t started = nullptr, hipEvent_t stopped = nullptr) {
     const uint32_t reach = shape.reach;
     const size_t lds = shape.lds;
-    // 5 waves per SIMD (<= 96 VGPRs): a 6-wave build (80 VGPRs) spills and measured slower
+    // 6 waves per SIMD (<= 80 VGPRs; six workgroups of four waves per CU, 129 of its 160 KB of LDS): until round 5 that build spilled nine
+    // registers across the walk and was slower than five waves at 88; with what the chain behind the walk needs worked out behind the walk
+    // it fits in 79 and is level alone, 3-4 % faster with three frames in flight (profiles/round5_ab_six_waves.txt); 7 waves (72) spill sixteen
     if (stamps)
-        hipLaunchKernelGGL((k_update_tiled<true, 5>), dim3(shape.groups_stamped), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
+        hipLaunchKernelGGL((k_update_tiled<true, 6>), dim3(shape.groups_stamped), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
     else if (started && stopped)  // the events take the dispatch's own begin and end time stamps: the kernel's execution, without marker packets around it
-        hipExtLaunchKernelGGL((k_update_tiled<false, 5>), dim3(shape.groups), dim3(kTileThreads), uint32_t(lds), stream, started, stopped, 0u, points0, points1, normals, items, h, pos,
+        hipExtLaunchKernelGGL((k_update_tiled<false, 6>), dim3(shape.groups), dim3(kTileThreads), uint32_t(lds), stream, started, stopped, 0u, points0, points1, normals, items, h, pos,
                               res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
     else
-        hipLaunchKernelGGL((k_update_tiled<false, 5>), dim3(shape.groups), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
+        hipLaunchKernelGGL((k_update_tiled<false, 6>), dim3(shape.groups), dim3(kTileThreads), lds, stream, points0, points1, normals, items, h, pos, res, recip, trunc, m, reach, adaptive ? 1u : 0u, items_capacity, stamps, pack_counter, pack_seen_host);
 }
 
 }  // namespace chadhip
