@@ -55,17 +55,11 @@ constexpr uint32_t kCountShift = 44;        // tile cell = [count : 20 | sum of 
                                             // frames put thousands of points into the voxels next to the sensor)
 static_assert(uint64_t(kItemPoints) << 31 < (1ull << kCountShift) && kItemPoints < (1u << (64 - kCountShift)), "a tile cell must hold an item's worst case");
 
-// b where the lane's bit of `mask` is set, a elsewhere: v_cndmask_b32 with the lane mask in a scalar register pair
-__device__ __forceinline__ float select_f(float a, float b, uint64_t mask) {
-    float out;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
-    return out;
-}
-__device__ __forceinline__ uint32_t select_u(uint32_t a, uint32_t b, uint64_t mask) {
-    uint32_t out;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
-    return out;
-}
+// b where the lane's bit of `mask` is set, a elsewhere: v_cndmask_b32 with the lane mask in a scalar register pair (the inverse of a
+// ballot: the compiler takes the 64-bit mask as the select's condition as it stands.  Until round 5 these were inline asm, behind each
+// of which the compiler put an s_nop -- six per voxel step, an issue slot each)
+__device__ __forceinline__ float select_f(float a, float b, uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? b : a; }
+__device__ __forceinline__ uint32_t select_u(uint32_t a, uint32_t b, uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? b : a; }
 
 typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 __device__ __forceinline__ lds_u64_t* lds_cell(uint32_t byte_address) { return reinterpret_cast<lds_u64_t*>(byte_address); }
