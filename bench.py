@@ -2,7 +2,7 @@
 """bench.py -- BASELINE.json's metric on BASELINE.json's config: inserted points/sec on the 1 M-point room scan
 (cfg2: voxel 0.05 m, trunc 0.10 m), one process per GPU.
 
-A step = --frames-per-step (default 4) times: chad::TSDFMap::insert() of one 1 M-point synthetic scan into an EMPTY map on this
+A step = --frames-per-step (default: 4, or as many as make the timed region 320 scans -- 16 at the driver's 20 steps) times: chad::TSDFMap::insert() of one 1 M-point synthetic scan into an EMPTY map on this
 rank's GPU (map.reset() + map.insert(), both inside the timed region), with the scans already resident in HBM.  insert() is
 asynchronous, as in any streaming use: the library keeps up to three frames in flight (the map-independent stages
 of the next frames run beside the update of the current one), and the timed region ends with a full synchronisation.  With N > 1
@@ -48,8 +48,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000, help="points per scan (BASELINE config: 1 M)")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic scans cycled through per rank")
-    ap.add_argument("--frames-per-step", type=int, default=4, help="scans inserted per step (each into an empty map): a step of one 0.1 ms frame makes a 20-step "
-                                                                   "timed region 2 ms, a fifth of it the pipeline's fill and drain")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="scans inserted per step (each into an empty map).  0 = 4, or more where the timed region would hold fewer "
+                                                                   "than 320 scans: with three frames in flight the pipeline's fill and drain are ~0.2 ms, 8 %% of a 20-step "
+                                                                   "region of 4-scan steps (7.5 ms) and 1-2 %% of one of 16-scan steps (30 ms)")
     ap.add_argument("--update-mode", type=int, default=0, help="0 auto, 1 scatter, 2 LDS-tiled")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--backend", default="auto", help="exchange transport for N > 1: nccl (= RCCL), gloo (only to rehearse several ranks on one GPU), auto")
@@ -164,7 +165,7 @@ def main():
     # (weak scaling: every rank integrates ALL of its own steps, so the map is not attached to the communicator -- an attached map
     # integrates only every world-th insert; the exchange is called explicitly)
 
-    fps = max(1, args.frames_per_step)
+    fps = args.frames_per_step if args.frames_per_step > 0 else max(4, -(-320 // max(1, args.steps)))
 
     def step(i):
         for j in range(fps):
