@@ -14,17 +14,22 @@ import os
 import shutil
 import sys
 
+
+def newest(paths):
+    """the most recently written of several runs' files (a directory merged from two collections holds both)"""
+    return sorted(paths, key=os.path.getmtime)
+
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 os.makedirs(prof, exist_ok=True)
 
-stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True))[-1]
+stats = newest(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True))[-1]
 shutil.copy(stats, os.path.join(prof, f"{tag}_kernel_stats.csv"))
 
 per_kernel = collections.defaultdict(dict)
 for group in ("fetch", "write", "tcc", "rdreq"):
-    found = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
+    found = newest(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
     if not found:
         continue
     f = found[-1]
@@ -57,7 +62,7 @@ except Exception:
 # the calibration of scripts/calib_fetch.hip (256 MiB read once per kernel): what FETCH_SIZE and the request counters report of it
 calib = {}
 for group, label in (("calib_fetch", "FETCH_SIZE"), ("calib_rdreq", "rdreq")):
-    found = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
+    found = newest(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
     if not found:
         continue
     acc = collections.defaultdict(dict)
@@ -90,11 +95,11 @@ for k, v in sorted(durations.items(), key=lambda kv: -kv[1])[:8]:
 
 # cfg5 (scripts/outdoor_bench.py): the same two summaries, if collect_profiles.sh has taken them
 if glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursive=True):
-    stats5 = sorted(glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursive=True))[-1]
+    stats5 = newest(glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursive=True))[-1]
     shutil.copy(stats5, os.path.join(prof, f"{tag}_cfg5_kernel_stats.csv"))
     per5 = collections.defaultdict(dict)
     for group in ("cfg5_fetch", "cfg5_write", "cfg5_tcc", "cfg5_rdreq"):
-        found = sorted(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
+        found = newest(glob.glob(os.path.join(src, group, "**", "*counter_collection.csv"), recursive=True))
         if not found:
             continue
         f = found[-1]
@@ -121,9 +126,9 @@ if glob.glob(os.path.join(src, "cfg5_trace", "**", "*kernel_stats.csv"), recursi
         print("cfg5 update kernel counters per launch:", json.dumps(c5))
 
 # the same trajectory kept as its DAG only (scripts/cfg5_dagonly.py under the kernel trace)
-dag = sorted(glob.glob(os.path.join(src, "cfg5dag_trace", "**", "*kernel_stats.csv"), recursive=True))
+dag = newest(glob.glob(os.path.join(src, "cfg5dag_trace", "**", "*kernel_stats.csv"), recursive=True))
 if dag:
     shutil.copy(dag[-1], os.path.join(prof, f"{tag}_cfg5_dagonly_kernel_stats.csv"))
-xchg = sorted(glob.glob(os.path.join(src, "cfg5xchg_trace", "**", "*kernel_stats.csv"), recursive=True))
+xchg = newest(glob.glob(os.path.join(src, "cfg5xchg_trace", "**", "*kernel_stats.csv"), recursive=True))
 if xchg:
     shutil.copy(xchg[-1], os.path.join(prof, f"{tag}_cfg5_exchange_kernel_stats.csv"))
