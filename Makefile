@@ -26,13 +26,13 @@ asm: $(CSRC)/chad_hip.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -Iinclude --cuda-device-only -S -o build/chad_hip.s $(CSRC)/chad_hip.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true
 
 # CPU sanitizer configuration: the host-side C++ that runs without a GPU -- the oracle (oracle/chad_oracle.cpp) and
-# the DAG fold of Submap::finalize (chad_tsdf_amd/csrc/dag.hpp through tests/cpp/dag_check.cpp), the planning of the sparse multi-GPU exchange (exchange_plan.hpp through tests/cpp/plan_check.cpp) -- built with
+# the DAG fold of Submap::finalize (chad_tsdf_amd/csrc/dag.hpp through tests/cpp/dag_check.cpp), the planning of the sparse multi-GPU exchange (exchange_plan.hpp through tests/cpp/plan_check.cpp), the range bookkeeping of the DAG pool (range_pool.hpp through tests/cpp/pool_check.cpp) -- built with
 # -fsanitize=address,undefined and driven by the CPU test suite (GPU AddressSanitizer is not available on this pool).
 ASAN_RT := $(shell g++ -print-file-name=libasan.so):$(shell g++ -print-file-name=libubsan.so)
 asan:
 	$(MAKE) -C oracle -s asan
 	CHAD_SANITIZE=1 LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
-		python3 -m pytest tests/test_oracle_golden.py tests/test_oracle_survey_pins.py tests/test_dag_host.py tests/test_exchange_plan_host.py -x -q -p no:cacheprovider
+		python3 -m pytest tests/test_oracle_golden.py tests/test_oracle_survey_pins.py tests/test_dag_host.py tests/test_exchange_plan_host.py tests/test_range_pool_host.py tests/test_mc_table.py -x -q -p no:cacheprovider
 
 clean:
 	rm -rf chad_tsdf_amd/lib/*.so build examples/sphere_demo

@@ -18,6 +18,8 @@
 #include <iterator>
 #include <map>
 
+#include "range_pool.hpp"
+
 namespace chadhip {
 
 struct AllocMeter {   // per host thread (a map is driven by one thread at a time: include/chad_hip.h)
@@ -49,13 +51,10 @@ inline hipError_t chad_free(void* p) {
     return e;
 }
 
-// One reservation, handed out in pieces: best fit over a list of free ranges ordered by address, neighbours merged on release.  A few
-// hundred allocations over a map's life (twenty-one levels, each doubling a dozen times): the list stays short.
-struct DevPool {
+// One reservation, handed out in pieces: the bookkeeping is RangePool's (range_pool.hpp: plain C++, checked on the host under the
+// sanitizers by tests/test_range_pool_host.py); this adds the device memory behind it.
+struct DevPool : RangePool {
     char* base = nullptr;
-    size_t cap = 0, used = 0, peak = 0;
-    std::map<size_t, size_t> free_ranges;   // offset -> length
-    static constexpr size_t kAlign = 4096;
 
     hipError_t reserve(size_t bytes) {
         release();
@@ -63,59 +62,25 @@ struct DevPool {
         bytes = (bytes + kAlign - 1) & ~(kAlign - 1);
         const hipError_t e = chad_malloc(&base, bytes);
         if (e != hipSuccess) { base = nullptr; return e; }
-        cap = bytes;
-        free_ranges[0] = bytes;
+        init(bytes);
         return hipSuccess;
     }
     void release() {
         if (base) (void)chad_free(base);
-        base = nullptr; cap = used = peak = 0;
-        free_ranges.clear();
+        base = nullptr;
+        init(0);
     }
     bool owns(const void* p) const { return base && static_cast<const char*>(p) >= base && static_cast<const char*>(p) < base + cap; }
     void* take(size_t bytes) {   // nullptr: no range of that length left
         if (!base) return nullptr;
-        bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) & ~(kAlign - 1);
-        auto best = free_ranges.end();   // best fit: small requests fill small holes, the large ranges stay whole for the levels that grow into gigabytes
-        for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it)
-            if (it->second >= bytes && (best == free_ranges.end() || it->second < best->second)) best = it;
-        if (best == free_ranges.end()) return nullptr;
-        const size_t at = best->first, len = best->second;
-        free_ranges.erase(best);
-        used += bytes; peak = std::max(peak, used);
-        if (bytes >= cap / 32) {   // the few large stores are carved from the top of their range, the many small ones from the bottom: they meet last
-            if (len > bytes) free_ranges[at] = len - bytes;
-            return base + at + (len - bytes);
-        }
-        if (len > bytes) free_ranges[at + bytes] = len - bytes;
-        return base + at;
+        const size_t at = take_range(bytes);
+        return at == kNone ? nullptr : base + at;
     }
     // A range goes back -- and may be handed out again at once: the caller guarantees that every access to it was enqueued on ONE stream
-    // and that the next user's accesses are enqueued on that stream too (DeviceDag::pool_stream says which; store_alloc waits for an event
-    // when a level is first touched from another stream).  false: `p` is not a range this pool handed out -- nothing is changed (the caller
-    // reports it; a double release or a foreign pointer would otherwise corrupt the free list silently).
-    bool give(void* p, size_t bytes) {
-        bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) & ~(kAlign - 1);
-        if (!owns(p)) return false;
-        size_t at = size_t(static_cast<char*>(p) - base), len = bytes;
-        if (at % kAlign || at + bytes > cap || bytes > used) return false;
-        auto next = free_ranges.lower_bound(at);
-        if (next != free_ranges.end() && next->first < at + bytes) return false;                                             // overlaps the free range behind it
-        if (next != free_ranges.begin()) { auto prev = std::prev(next); if (prev->first + prev->second > at) return false; }   // ... or the one in front: already free
-        used -= bytes;
-        if (next != free_ranges.begin()) {
-            auto prev = std::prev(next);
-            if (prev->first + prev->second == at) { at = prev->first; len += prev->second; free_ranges.erase(prev); }
-        }
-        if (next != free_ranges.end() && at + len == next->first) { len += next->second; free_ranges.erase(next); }
-        free_ranges[at] = len;
-        return true;
-    }
-    void reset() {   // everything handed out is dead (the DAG was thrown away)
-        free_ranges.clear();
-        if (base) free_ranges[0] = cap;
-        used = 0;
-    }
+    // and that the next user's accesses are enqueued on that stream too (DeviceDag::store_alloc waits for an event when a level is first
+    // touched from another stream).  false: `p` is not a range this pool handed out -- nothing is changed (the caller reports it; a double
+    // release or a foreign pointer would otherwise corrupt the free list silently).
+    bool give(void* p, size_t bytes) { return owns(p) && give_range(size_t(static_cast<char*>(p) - base), bytes); }
 };
 
 }  // namespace chadhip
