@@ -31,3 +31,19 @@ def test_bench_with_two_gloo_ranks_prints_the_strong_scaling_legs():
     assert strong["n_gpus"] == 2 and strong["speedup_vs_1gpu"] == cfg4["speedup_vs_1gpu"]
     # the transport saw both ranks
     assert sharded["ranks_seen_by_transport"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_watchdog_prints_the_contract_line_and_fails_loudly():
+    """Extra legs that outlast --leg-timeout: the contract's line is still printed -- with what was measured until then and the leg that was
+    running -- and the process ends with a non-zero code (3), so that a hung leg cannot pass for a clean run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--points", "200000", "--cpu-seconds", "0", "--leg-timeout", "0.05"]
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 3, (done.returncode, done.stderr[-2000:])
+    lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["metric"] == "inserted points/sec" and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
+    assert "watchdog" in line and line["watchdog_leg"]
+    assert "roofline" in line
