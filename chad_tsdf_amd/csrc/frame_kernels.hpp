@@ -140,6 +140,32 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Inclusive sum over the 64 lanes of a wave on the VALU alone: four shifts inside the 16-lane rows (a lane shifted in from outside its row
+// reads 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3 (row_bcast:15 / :31).  Six DPP moves and six
+// adds instead of six ds_bpermute round trips with a compare and a select each.  Must be executed by all 64 lanes.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, true));    // row_shr:1
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, true));    // row_shr:2
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, true));    // row_shr:4
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, true));    // row_shr:8
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1 and 3
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// min over the lanes l .. 63, in every lane l: four shifts inside the 16-lane rows (a lane shifted in from outside its row keeps its
+// value), then the minima of the rows behind -- they stand in the rows' first lanes -- through scalar registers.  All 64 lanes.
+__device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v) {
+    v = min(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x101, 0xf, 0xf, false)));   // row_shl:1
+    v = min(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x102, 0xf, 0xf, false)));   // row_shl:2
+    v = min(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x104, 0xf, 0xf, false)));   // row_shl:4
+    v = min(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x108, 0xf, 0xf, false)));   // row_shl:8
+    const uint32_t r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48)), r2 = min(uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3),
+                   r1 = min(uint32_t(__builtin_amdgcn_readlane(int(v), 16)), r2);
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    return min(v, row == 0u ? r1 : row == 1u ? r2 : row == 2u ? r3 : 0xffffffffu);
+}
+
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -439,13 +465,9 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
             const uint32_t which = threadIdx.x >> 6, lane = threadIdx.x & 63u;
             const uint32_t word = (which ? head_bits : mark_bits)[lane];
             const uint32_t count = uint32_t(__popc(word));
-            uint32_t incl = count;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (int(lane) >= o) incl += t; }
+            const uint32_t incl = wave_inclusive_sum(count);
             word_rank[which][lane] = incl - count;
-            uint32_t first_mark = word ? lane * 32u + uint32_t(__ffs(int(word)) - 1) : chunk_len;   // chunk_len = "none"
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_down(first_mark, o); if (int(lane) + o < 64) first_mark = min(first_mark, t); }
+            const uint32_t first_mark = wave_suffix_min(word ? lane * 32u + uint32_t(__ffs(int(word)) - 1) : chunk_len);   // chunk_len = "none"
             const uint32_t after = __shfl_down(first_mark, 1);   // first mark in a later word
             word_next[which][lane] = lane == 63u ? chunk_len : after;
             if (which && lane == 63u) base_heads = stripe * list_stride + (incl ? atomicAdd(&h->list_count[kListBlocks][stripe * 16u], incl) : 0u);
@@ -616,19 +638,6 @@ __device__ __forceinline__ double team8_sum_f64(double v) {
     return v;
 }
 template <uint32_t kWidth> __device__ __forceinline__ double team_sum(double v) { return kWidth == 8u ? team8_sum_f64(v) : team_sum_f64(v); }
-
-// Inclusive sum over the 64 lanes of a wave on the VALU alone: four shifts inside the 16-lane rows (a lane shifted in from outside its row
-// reads 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3 (row_bcast:15 / :31).  Six DPP moves and six
-// adds instead of six ds_bpermute round trips with a compare and a select each.  Must be executed by all 64 lanes.
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, true));    // row_shr:1
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, true));    // row_shr:2
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, true));    // row_shr:4
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, true));    // row_shr:8
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1 and 3
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2 and 3
-    return v;
-}
 
 constexpr int kNormalWaves = 4;            // waves per workgroup of k_frame_normals
 constexpr uint32_t kNormalBigGroups = 512;  // its first workgroups (at most): one large point block each at a time, all four waves on it (scripts/sweep_big_blocks.sh)
