@@ -140,19 +140,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-// Inclusive sum over the 64 lanes of a wave on the VALU alone: four shifts inside the 16-lane rows (a lane shifted in from outside its row
-// reads 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3 (row_bcast:15 / :31).  Six DPP moves and six
-// adds instead of six ds_bpermute round trips with a compare and a select each.  Must be executed by all 64 lanes.
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, true));    // row_shr:1
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, true));    // row_shr:2
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, true));    // row_shr:4
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, true));    // row_shr:8
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1 and 3
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2 and 3
-    return v;
-}
-
 // min over the lanes l .. 63, in every lane l: four shifts inside the 16-lane rows (a lane shifted in from outside its row keeps its
 // value), then the minima of the rows behind -- they stand in the rows' first lanes -- through scalar registers.  All 64 lanes.
 __device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v) {

@@ -45,6 +45,19 @@ constexpr uint32_t kSpinLimit = 1u << 20;               // polls of one thread f
                                                         // dispatch-order assumption then reports kSortFaultStalled instead of hanging the GPU
 constexpr uint32_t kSortFaultStalled = 2u;              // bit set in RadixSortSignals::fault (bit 0 is the map's capacity overflow)
 
+// Inclusive sum over the 64 lanes of a wave on the VALU alone: four shifts inside the 16-lane rows (a lane shifted in from outside its row
+// reads 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3 (row_bcast:15 / :31).  Six DPP moves and six
+// adds instead of six ds_bpermute round trips with a compare and a select each.  Must be executed by all 64 lanes.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, true));    // row_shr:1
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, true));    // row_shr:2
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, true));    // row_shr:4
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, true));    // row_shr:8
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1 and 3
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Element (wave w, step j, lane l) of tile t sits at t*kSortTile + w*(64*kSortItems) + j*64 + l: consecutive
@@ -296,13 +309,8 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
     uint32_t carry = 0, carry_all = 0;
 #pragma unroll
     for (uint32_t q = 0; q < kPer; q++) {
-        uint32_t incl = count[q], incl_all = total[q];
+        const uint32_t incl = wave_inclusive_sum(count[q]), incl_all = wave_inclusive_sum(total[q]);   // (on DPP: twelve ds_bpermute round trips in every tile's chain before)
         const uint32_t l = threadIdx.x & 63;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o), u = __shfl_up(incl_all, o);
-            if (int(l) >= o) { incl += t; incl_all += u; }
-        }
         if (q) __syncthreads();   // (the previous round's wave totals have been read)
         if (l == 63) { wave_total[threadIdx.x >> 6] = incl; wave_total_all[threadIdx.x >> 6] = incl_all; }
         __syncthreads();
