@@ -125,21 +125,42 @@ __device__ __forceinline__ void frame_header_reset(FrameHeader* h) {
 }
 __global__ void k_frame_init(FrameHeader* h) { frame_header_reset(h); }
 
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
+// Reductions over the 64 lanes of a wave, the result in every lane: the scan network of wave_inclusive_sum (radix_sort.hpp) -- four shifts
+// inside the 16-lane rows, row_bcast:15, row_bcast:31: lane 63 holds the result -- on the VALU, then one v_readlane.  (As xor butterflies
+// over __shfl they were six ds_bpermute round trips each: forty-two in a row at the end of k_frame_bounds and again at the start of
+// k_frame_keys, two microseconds of each kernel.)  A lane shifted in from outside its row, or a row the broadcast does not reach, keeps
+// its own value: every step combines a value with itself or with another lane's.  All 64 lanes must execute them.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, kCtrl, kRowMask, 0xf, false); }
+template <class Op>
+__device__ __forceinline__ int wave_reduce(int v, Op op) {
+    v = op(v, dpp_keep<0x111, 0xf>(v));   // row_shr:1
+    v = op(v, dpp_keep<0x112, 0xf>(v));   // row_shr:2
+    v = op(v, dpp_keep<0x114, 0xf>(v));   // row_shr:4
+    v = op(v, dpp_keep<0x118, 0xf>(v));   // row_shr:8
+    v = op(v, dpp_keep<0x142, 0xa>(v));   // row_bcast:15 -> rows 1 and 3
+    v = op(v, dpp_keep<0x143, 0xc>(v));   // row_bcast:31 -> rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
+__device__ __forceinline__ int wave_min(int v) { return wave_reduce(v, [](int a, int b) { return min(a, b); }); }
+__device__ __forceinline__ int wave_max(int v) { return wave_reduce(v, [](int a, int b) { return max(a, b); }); }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return uint32_t(__builtin_amdgcn_readlane(int(wave_inclusive_sum(v)), 63)); }
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ unsigned long long dpp_keep_u64(unsigned long long v) {
+    const uint32_t lo = uint32_t(dpp_keep<kCtrl, kRowMask>(int(uint32_t(v)))), hi = uint32_t(dpp_keep<kCtrl, kRowMask>(int(uint32_t(v >> 32))));
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    unsigned long long t;
+    t = dpp_keep_u64<0x111, 0xf>(v); v = t < v ? t : v;
+    t = dpp_keep_u64<0x112, 0xf>(v); v = t < v ? t : v;
+    t = dpp_keep_u64<0x114, 0xf>(v); v = t < v ? t : v;
+    t = dpp_keep_u64<0x118, 0xf>(v); v = t < v ? t : v;
+    t = dpp_keep_u64<0x142, 0xa>(v); v = t < v ? t : v;
+    t = dpp_keep_u64<0x143, 0xc>(v); v = t < v ? t : v;
+    return (unsigned long long)uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v)), 63)) | ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v >> 32)), 63)) << 32);
 }
+
 // min over the lanes l .. 63, in every lane l: four shifts inside the 16-lane rows (a lane shifted in from outside its row keeps its
 // value), then the minima of the rows behind -- they stand in the rows' first lanes -- through scalar registers.  All 64 lanes.
 __device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v) {
@@ -151,15 +172,6 @@ __device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v) {
                    r1 = min(uint32_t(__builtin_amdgcn_readlane(int(v), 16)), r2);
     const uint32_t row = (threadIdx.x & 63u) >> 4;
     return min(v, row == 0u ? r1 : row == 1u ? r2 : row == 2u ? r3 : 0xffffffffu);
-}
-
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
 }
 
 __device__ __forceinline__ F3 load_point(const float* __restrict__ xyz, size_t i) { return {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}; }
