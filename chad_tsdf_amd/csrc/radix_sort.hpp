@@ -257,7 +257,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 
     uint64_t key[kSortItems];
     typename P::T val[kSortItems];
-    uint32_t rank[kSortItems];
+    uint32_t rank[kSortItems], from[kSortItems];
 #pragma unroll
     for (uint32_t j = 0; j < kSortItems; j++) {
         const size_t i = tile_index(tile, wave, j, lane);
@@ -276,16 +276,17 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
             const uint64_t vote = __ballot(bit);
             same &= bit ? vote : ~vote;
         }
-        uint32_t before = 0;
-        if (live) {
-            const uint32_t leader = uint32_t(__ffsll((unsigned long long)same)) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&wave_count[wave][digit], uint32_t(__popcll(same)));
-            base = __shfl(base, int(leader));
-            before = base + uint32_t(__popcll(same & lanes_below));
-        }
-        rank[j] = before;  // rank among this wave's keys of the same digit, in (j, lane) order
+        // the leader of every digit's lanes adds their number to the wave's count of that digit; what it gets back is asked for below,
+        // all eight steps' answers together: waited for step by step -- returning LDS add, wait, ds_bpermute, wait -- they were sixteen
+        // exposed LDS round trips per tile (a wave's LDS operations are performed in issue order: a later step's add finds an earlier one's)
+        const uint32_t leader = live ? uint32_t(__ffsll((unsigned long long)same)) - 1u : lane;
+        rank[j] = 0u;
+        if (live && lane == leader) rank[j] = atomicAdd(&wave_count[wave][digit], uint32_t(__popcll(same)));
+        from[j] = (leader << 8) | (live ? uint32_t(__popcll(same & lanes_below)) : 0u);   // whom to ask, and this key's place among the step's keys of its digit
     }
+#pragma unroll
+    for (uint32_t j = 0; j < kSortItems; j++)   // rank among this wave's keys of the same digit, in (j, lane) order
+        rank[j] = uint32_t(__shfl(int(rank[j]), int(from[j] >> 8))) + (from[j] & 0xffu);
     __syncthreads();
 
     // thread t owns digits t + q * 256 from here on
@@ -397,7 +398,7 @@ radix_onesweep_tile(const uint64_t* __restrict__ keys_in, const typename P::T* _
 // instead of five surplus launches per frame that return at once.  to_limit requires every workgroup of the grid to be
 // resident at once beside everything else in flight (tiles <= RadixSortBuffers::resident; radix_sort_enqueue_as checks).
 template <class P, int kBits = kRadixBits>
-__global__ void __launch_bounds__(kSortThreads)
+__global__ void __launch_bounds__(kSortThreads, 4)   // (<= 128 registers: four waves per SIMD, as before the ranking's answers were asked for together)
 k_radix_onesweep(uint64_t* __restrict__ keys0, typename P::T* __restrict__ pay0, uint64_t* __restrict__ keys1, typename P::T* __restrict__ pay1,
                  uint32_t n, uint32_t first_pass, uint32_t to_limit, uint32_t tiles, const uint32_t* __restrict__ digit_base, uint32_t base_stripes,
                  uint32_t* __restrict__ tile_status, uint32_t* __restrict__ tile_ticket, const uint32_t* __restrict__ pass_limit, const void* __restrict__ first_src,
