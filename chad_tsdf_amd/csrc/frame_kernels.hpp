@@ -496,10 +496,9 @@ k_frame_gather(float recip, FrameHeader* __restrict__ h, const FramePartial* __r
         }
         __syncthreads();
         // ... each class reserving its part of the list with one atomic per chunk: long items from the front, short ones from the back
-        if (threadIdx.x == 0) {
-            base_big = stripe * list_stride + (n_big ? atomicAdd(&h->list_count[kListLongItems][stripe * 16u], n_big) : 0u);
-            base_small = n_small ? atomicAdd(&h->list_count[kListShortItems][stripe * 16u], n_small) : 0u;
-        }
+        // (by lanes of two different waves: from one thread the second atomic was issued when the first had returned -- two round trips in a row)
+        if (threadIdx.x == 0) base_big = stripe * list_stride + (n_big ? atomicAdd(&h->list_count[kListLongItems][stripe * 16u], n_big) : 0u);
+        if (threadIdx.x == 64) base_small = n_small ? atomicAdd(&h->list_count[kListShortItems][stripe * 16u], n_small) : 0u;
         __syncthreads();
 #pragma unroll
         for (uint32_t j = 0; j < kGatherChunk / 256; j++) {
