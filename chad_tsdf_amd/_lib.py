@@ -161,6 +161,7 @@ SYMBOLS = {
     "chad_morton_codes": (_i32, [_vp, _sz, _f32, _vp]),
     "chad_sort_pairs": (_i32, [_vp, _sz, C.c_uint32, _vp, _vp]),
     "chad_selftest_reciprocal": (_i32, [_vp]),
+    "chad_selftest_wave_ops": (_i32, [_vp]),
     "chad_exchange_splitters": (_i32, [_vp, C.c_uint32, _vp]),
     "chad_exchange_layout": (_i32, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "chad_last_error": (C.c_char_p, []),

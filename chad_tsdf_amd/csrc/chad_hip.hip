@@ -3058,6 +3058,17 @@ chad_status chad_selftest_reciprocal(uint64_t out[4]) {
     return CHAD_OK;
 }
 
+chad_status chad_selftest_wave_ops(uint64_t out[7]) {
+    if (!out) return fail(CHAD_ERR_INVALID_ARG, "null argument");
+    DevBuf d;
+    HIP_TRY(d.alloc(56));
+    HIP_TRY(hipMemset(d.p, 0, 56));
+    hipLaunchKernelGGL(k_selftest_wave_ops, dim3(512), dim3(256), 0, 0, d.as<unsigned long long>(), 64u);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d.p, 56, hipMemcpyDeviceToHost));
+    return CHAD_OK;
+}
+
 chad_status chad_exchange_splitters(const uint64_t* heads, uint32_t world, uint64_t* splitters) {
     if (!heads || !splitters || world < 1 || world > uint32_t(kMaxRanks)) return fail(CHAD_ERR_INVALID_ARG, "null argument or world out of range");
     return xchg_splitters(heads, world, splitters) ? CHAD_OK : fail(CHAD_ERR_INVALID_ARG, "implausible block count in a head");

@@ -288,6 +288,49 @@ k_selftest_reciprocal(unsigned long long* __restrict__ out) {
     }
 }
 
+// Self-test of the wave-wide scans and reductions that run on the DPP network (radix_sort.hpp: wave_inclusive_sum; frame_kernels.hpp:
+// wave_suffix_min, wave_min / wave_max / wave_sum / wave_min_u64) against plain loops over the same 64 values, `rounds` times per wave
+// with values drawn from a hash of (wave, round, lane) -- some rounds all equal, some with the extreme in a single lane.
+// out[k] = lanes whose result differed, k = 0 inclusive sum, 1 suffix minimum, 2 minimum, 3 maximum, 4 sum, 5 64-bit minimum; out[6] = lanes checked.
+__global__ void __launch_bounds__(256)
+k_selftest_wave_ops(unsigned long long* __restrict__ out, uint32_t rounds) {
+    __shared__ uint32_t value[4][64];
+    __shared__ unsigned long long wide[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wave_global = blockIdx.x * 4u + wave;
+    uint32_t bad[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t r = 0; r < rounds; r++) {
+        uint64_t hsh = (uint64_t(wave_global) << 40) ^ (uint64_t(r) << 8) ^ lane;
+        hsh ^= hsh >> 33; hsh *= 0xff51afd7ed558ccdull; hsh ^= hsh >> 33; hsh *= 0xc4ceb9fe1a85ec53ull; hsh ^= hsh >> 33;
+        uint32_t v = uint32_t(hsh) >> ((r % 5u) * 6u);               // small and large magnitudes (the sum wraps: so does the loop's)
+        if (r % 7u == 3u) v = 12345u;                                // all lanes equal
+        if (r % 7u == 5u) v = lane == (r % 64u) ? 1u : 0xfffffff0u;  // the minimum in one lane only
+        const unsigned long long w = (hsh << 11) ^ v;
+        value[wave][lane] = v; wide[wave][lane] = w;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (a wave's own LDS writes, then its reads: in order)
+        uint32_t incl = 0, suffix = 0xffffffffu, lo = 0xffffffffu, total = 0;
+        int smin = 0x7fffffff, smax = int(0x80000000);
+        unsigned long long lo64 = ~0ull;
+        for (uint32_t l = 0; l < 64u; l++) {
+            const uint32_t x = value[wave][l];
+            if (l <= lane) incl += x;
+            if (l >= lane) suffix = min(suffix, x);
+            lo = min(lo, x); total += x;
+            smin = min(smin, int(x)); smax = max(smax, int(x));
+            lo64 = wide[wave][l] < lo64 ? wide[wave][l] : lo64;
+        }
+        (void)lo;
+        bad[0] += wave_inclusive_sum(v) != incl;
+        bad[1] += wave_suffix_min(v) != suffix;
+        bad[2] += wave_min(int(v)) != smin;
+        bad[3] += wave_max(int(v)) != smax;
+        bad[4] += wave_sum(v) != total;
+        bad[5] += wave_min_u64(w) != lo64;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int k = 0; k < 6; k++) if (bad[k]) atomicAdd(&out[k], (unsigned long long)bad[k]);
+    atomicAdd(&out[6], (unsigned long long)rounds);
+}
+
 // Morton codes of a frame's points in processing order (float4 x, y, z, index): the stage read-back of chad_map_last_frame
 __global__ void k_morton_codes_of_points(const float4* __restrict__ pts, uint32_t n, float recip, uint64_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -376,6 +376,13 @@ chad_status chad_sort_pairs(const uint64_t* keys, size_t n, uint32_t key_bits, u
  * for which the fast sequence alone would be wrong (why the range test exists).  Bit-exact voxel lists (octree.hpp:92-118) rest on this. */
 chad_status chad_selftest_reciprocal(uint64_t out[4]);
 
+/* Self-test: the wave-wide prefix sums, suffix minima and reductions of the frame kernels and the sort, which run on the DPP network of a
+ * 64-lane wave (row shifts, row_bcast:15, row_bcast:31: chad_tsdf_amd/csrc/radix_sort.hpp wave_inclusive_sum, frame_kernels.hpp wave_reduce),
+ * against plain loops over the same values, on the device: 2 048 waves x 64 rounds.  out[0..5] = lanes whose inclusive sum / suffix minimum /
+ * minimum / maximum / sum / 64-bit minimum differed (all must be 0), out[6] = lanes checked.  The order of a frame's points inside a block
+ * (normals.hpp:81-148) and the stability of the sort (morton.hpp:81-102) rest on these. */
+chad_status chad_selftest_wave_ops(uint64_t out[7]);
+
 /* Stage entries for the CPU tests of the sparse multi-GPU exchange (no device needed): the host arithmetic every rank runs on the words
  * it has all-gathered (chad_tsdf_amd/csrc/exchange_plan.hpp).  chad_exchange_splitters: heads[world][65] -- per rank its block count
  * (low 32 bits of word 0; bit 32: two payload words per voxel) and 64 sample keys of its sorted list -- -> the world - 1 splitter keys

@@ -330,3 +330,17 @@ def test_fast_reciprocal_equals_the_ieee_quotient_for_every_float(chad):
     assert bad_fast == 0, f"{bad_fast} inputs inside [2^-126, 2^126) where rcp + Newton is not the IEEE quotient"
     assert bad_any == 0, f"{bad_any} inputs where the kernels' reciprocal differs from 1.0f / x"
     assert bad_outside > 0                      # outside the range the fast sequence IS wrong somewhere: the range test is needed
+
+
+def test_wave_scans_and_reductions_on_dpp_equal_plain_loops(chad):
+    """The prefix sums, suffix minima and reductions over a wave's 64 lanes that the frame kernels and the sort take from the DPP network
+    (row shifts and row broadcasts instead of ds_bpermute round trips) against plain loops over the same values, on the device."""
+    import ctypes as C
+
+    from chad_tsdf_amd import _lib
+
+    out = (C.c_uint64 * 7)()
+    _lib.check(_lib.load().chad_selftest_wave_ops(out), "selftest")
+    *bad, checked = list(out)
+    assert checked == 512 * 256 * 64
+    assert bad == [0, 0, 0, 0, 0, 0], dict(zip(["inclusive sum", "suffix minimum", "minimum", "maximum", "sum", "64-bit minimum"], bad))
